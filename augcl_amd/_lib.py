@@ -1,0 +1,122 @@
+"""ctypes binding of libaugcl_hip.so (C ABI: include/augcl.h).
+
+The HIP library is THE product path.  There is no CPU fallback: if the shared
+object is missing, lacks a symbol, or no GPU is visible when an op is called,
+we raise -- loudly -- instead of computing the result some other way.
+"""
+import ctypes
+import os
+import re
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG)
+LIB_PATH = os.path.join(_PKG, "libaugcl_hip.so")
+HEADER_PATH = os.path.join(_ROOT, "include", "augcl.h")
+
+AUGCL_OK = 0
+
+
+class AugclError(RuntimeError):
+    pass
+
+
+def build(force=False, verbose=False):
+    """Compile libaugcl_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+    csrc = os.path.join(_PKG, "csrc")
+    cmd = ["make", "-C", csrc] + (["-B"] if force else [])
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose or r.returncode != 0:
+        print(r.stdout + r.stderr)
+    if r.returncode != 0:
+        raise AugclError("building libaugcl_hip.so failed")
+    return LIB_PATH
+
+
+def declared_symbols():
+    """Every function name include/augcl.h declares (used by the symbol-export test)."""
+    txt = open(HEADER_PATH).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(augcl_[a-z0-9_]+)\s*\(", txt)))
+
+
+_c = ctypes
+_P = _c.c_void_p
+_I = _c.c_int
+_U64 = _c.c_uint64
+_SZ = _c.c_size_t
+_F = _c.c_float
+_D = _c.c_double
+
+# name -> argtypes (restype is int unless listed in _RESTYPE)
+_SIGS = {
+    "augcl_abi_version": [],
+    "augcl_last_error": [],
+    "augcl_device_count": [],
+    "augcl_philox_shift_offsets": [_U64, _U64, _I, _I, _I, _P, _P, _P],
+    "augcl_philox_conv_weights": [_U64, _U64, _I, _I, _P, _P],
+    "augcl_philox_normal": [_U64, _U64, _SZ, _P, _P],
+    "augcl_random_shift_f32": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _U64, _U64, _I, _P],
+    "augcl_random_shift_u8": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _U64, _U64, _I, _P],
+    "augcl_random_shift_u8_f32": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _U64, _U64, _I, _P],
+    "augcl_random_conv_f32": [_P, _P, _I, _I, _I, _I, _P, _U64, _U64, _I, _P],
+    "augcl_random_overlay_f32": [_P, _P, _P, _I, _I, _I, _I, _F, _P],
+    "augcl_color_jitter_f32": [_P, _I, _I, _I, _I, _P, _I, _P, _D, _D, _D, _F, _F, _P],
+    "augcl_shift_conv_u8_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _U64, _U64, _I, _P],
+    "augcl_shift_conv_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _U64, _U64, _I, _P],
+}
+_RESTYPE = {"augcl_last_error": _c.c_char_p}
+
+_lib = None
+
+
+def load():
+    """dlopen the library and bind every declared entry point.  Raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AugclError(
+            f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
+            "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or `make -C augcl_amd/csrc`.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in _SIGS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise AugclError(f"libaugcl_hip.so does not export {name}") from e
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPE.get(name, _I)
+    ver = lib.augcl_abi_version()
+    if ver != 1:
+        raise AugclError(f"libaugcl_hip.so ABI version {ver} != 1")
+    _lib = lib
+    return lib
+
+
+def check(status, what=""):
+    if status != AUGCL_OK:
+        msg = load().augcl_last_error()
+        raise AugclError(f"{what} failed ({status}): {msg.decode() if msg else '?'}")
+
+
+def call(name, *args):
+    lib = load()
+    check(getattr(lib, name)(*args), name)
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else t.data_ptr()
+
+
+def current_stream(device=None):
+    import torch
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def require_cuda(t, name="tensor"):
+    if not t.is_cuda:
+        raise AugclError(f"{name} must live on the GPU: augcl_amd has no CPU path (got device {t.device})")
+    if not t.is_contiguous():
+        raise AugclError(f"{name} must be contiguous")

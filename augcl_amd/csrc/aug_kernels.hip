@@ -1,0 +1,769 @@
+// aug_kernels.hip -- CDNA4 (gfx950) kernels for AugCL's pixel augmentations.
+//
+// All four operators are HBM-bound: the design goal of every kernel
+// here is ONE coalesced 16-B/lane read and ONE 16-B/lane write per element, with the
+// 3x3 neighbourhoods of random_conv served from an LDS-staged row strip and the
+// per-sample random parameters (crop offset, 81 conv weights) wave-uniform: they are
+// derived from blockIdx only, so they live in SGPRs / are LDS-broadcast, never per lane.
+//
+// Compiled with -ffp-contract=off: random_overlay / color_jitter restate chains of
+// separate IEEE f32 ops of the reference and must not be fused; FMAs are written
+// explicitly (__builtin_fmaf) where a fused accumulate is intended (random_conv).
+#include "augcl_common.h"
+
+namespace augcl {
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// per-sample crop displacement (dy,dx) = (oy-pad, ox-pad): uniform per workgroup
+__device__ __forceinline__ void sample_shift(const int32_t *__restrict__ oy, const int32_t *__restrict__ ox,
+                                             uint64_t seed, uint64_t offset, int gsample, int b, int pad,
+                                             int &dy, int &dx)
+{
+    int y, x;
+    if (oy != nullptr) {
+        y = oy[b];
+        x = ox[b];
+    } else {
+        philox_shift_offsets(seed, offset, (uint32_t)gsample, pad, y, x);
+    }
+    dy = __builtin_amdgcn_readfirstlane(y - pad);
+    dx = __builtin_amdgcn_readfirstlane(x - pad);
+}
+
+// ---- 4 consecutive shifted pixels of one source row -------------------------------------
+// f32 source: two aligned float4 loads + a wave-uniform rotate (r = dx & 3); rows are 16-B
+// aligned (W % 4 == 0).  Border quads (source column clamped) take 4 clamped scalar loads.
+template <int W>
+__device__ __forceinline__ float4 load_shifted4(const float *__restrict__ row, int x4, int dx, int r)
+{
+    const int s0 = x4 + dx;
+    float4 o;
+    if (s0 >= 0 && s0 + 3 <= W - 1) {
+        const int a0 = s0 - r;
+        const float4 A = *reinterpret_cast<const float4 *>(row + a0);
+        if (r == 0) {
+            o = A;
+        } else {
+            const float4 Bv = *reinterpret_cast<const float4 *>(row + a0 + 4);
+            if (r == 1) o = make_float4(A.y, A.z, A.w, Bv.x);
+            else if (r == 2) o = make_float4(A.z, A.w, Bv.x, Bv.y);
+            else o = make_float4(A.w, Bv.x, Bv.y, Bv.z);
+        }
+    } else {
+        o.x = row[clampi(s0, 0, W - 1)];
+        o.y = row[clampi(s0 + 1, 0, W - 1)];
+        o.z = row[clampi(s0 + 2, 0, W - 1)];
+        o.w = row[clampi(s0 + 3, 0, W - 1)];
+    }
+    return o;
+}
+
+// u8 source: two aligned dword loads + v_alignbyte_b32; returns the 4 bytes packed
+template <int W>
+__device__ __forceinline__ uint32_t load_shifted4_u8(const uint8_t *__restrict__ row, int x4, int dx, int r)
+{
+    const int s0 = x4 + dx;
+    uint32_t v;
+    if (s0 >= 0 && s0 + 3 <= W - 1) {
+        const int a0 = s0 - r;
+        const uint32_t lo = *reinterpret_cast<const uint32_t *>(row + a0);
+        if (r == 0) {
+            v = lo;
+        } else {
+            const uint32_t hi = *reinterpret_cast<const uint32_t *>(row + a0 + 4);
+            v = __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)r);
+        }
+    } else {
+        v = (uint32_t)row[clampi(s0, 0, W - 1)] | ((uint32_t)row[clampi(s0 + 1, 0, W - 1)] << 8) |
+            ((uint32_t)row[clampi(s0 + 2, 0, W - 1)] << 16) | ((uint32_t)row[clampi(s0 + 3, 0, W - 1)] << 24);
+    }
+    return v;
+}
+
+__device__ __forceinline__ float4 unpack_u8x4(uint32_t v)
+{
+    return make_float4((float)(v & 0xffu), (float)((v >> 8) & 0xffu), (float)((v >> 16) & 0xffu), (float)(v >> 24));
+}
+
+// =========================================================================================
+// random_shift: one workgroup per (sample, channel) plane; each thread moves 4-pixel quads.
+// =========================================================================================
+template <int H, int W, typename TIn, typename TOut>
+__global__ __launch_bounds__(256) void k_random_shift(const TIn *__restrict__ in, TOut *__restrict__ out, int C,
+                                                      int pad, const int32_t *__restrict__ oy,
+                                                      const int32_t *__restrict__ ox, uint64_t seed, uint64_t offset,
+                                                      int sample0)
+{
+    constexpr int W4 = W / 4;
+    constexpr int N4 = H * W4;
+    const int plane = blockIdx.x;
+    const int b = plane / C;
+    int dy, dx;
+    sample_shift(oy, ox, seed, offset, sample0 + b, b, pad, dy, dx);
+    const int r = dx & 3;
+    const TIn *__restrict__ src = in + (size_t)plane * (H * W);
+    TOut *__restrict__ dst = out + (size_t)plane * (H * W);
+#pragma unroll 2
+    for (int j = threadIdx.x; j < N4; j += 256) {
+        const int y = j / W4;
+        const int x4 = (j - y * W4) * 4;
+        const int sy = clampi(y + dy, 0, H - 1);
+        if constexpr (sizeof(TIn) == 4) {
+            const float4 v = load_shifted4<W>(reinterpret_cast<const float *>(src) + sy * W, x4, dx, r);
+            *reinterpret_cast<float4 *>(reinterpret_cast<float *>(dst) + y * W + x4) = v;
+        } else {
+            const uint32_t v = load_shifted4_u8<W>(reinterpret_cast<const uint8_t *>(src) + sy * W, x4, dx, r);
+            if constexpr (sizeof(TOut) == 1)
+                *reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(dst) + y * W + x4) = v;
+            else
+                *reinterpret_cast<float4 *>(reinterpret_cast<float *>(dst) + y * W + x4) = unpack_u8x4(v);
+        }
+    }
+}
+
+// any shape / alignment: one element per thread (correctness fallback, not tuned)
+template <typename TIn, typename TOut>
+__global__ __launch_bounds__(256) void k_random_shift_generic(const TIn *__restrict__ in, TOut *__restrict__ out,
+                                                              int C, int H, int W, int pad,
+                                                              const int32_t *__restrict__ oy,
+                                                              const int32_t *__restrict__ ox, uint64_t seed,
+                                                              uint64_t offset, int sample0)
+{
+    const int plane = blockIdx.y;
+    const int b = plane / C;
+    int dy, dx;
+    sample_shift(oy, ox, seed, offset, sample0 + b, b, pad, dy, dx);
+    const int n = H * W;
+    const TIn *__restrict__ src = in + (size_t)plane * n;
+    TOut *__restrict__ dst = out + (size_t)plane * n;
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
+        const int y = j / W, x = j - y * W;
+        dst[j] = (TOut)src[clampi(y + dy, 0, H - 1) * W + clampi(x + dx, 0, W - 1)];
+    }
+}
+
+// =========================================================================================
+// random_conv (+ optional fused random_shift front end)
+//   workgroup = one R-row strip of one RGB frame; the (R+2) x 3 x W input rows are staged
+//   ONCE into LDS already divided by 255 (the reference's x/255.0, one IEEE division per
+//   input element instead of 27), 3x3 windows are then read from LDS: one ds_read_b128 +
+//   two edge ds_read_b32 per (channel,row), 81 FMAs per output pixel triple against
+//   LDS-broadcast weights, sigmoid, *255, one float4 store per output channel.
+// =========================================================================================
+template <int H, int W, int R>
+struct ConvSmem {
+    float tile[3][R + 2][W]; // x/255, rows y0-1 .. y0+R (row-clamped = replicate pad)
+    float w[84];             // 81 weights [o][i][ky][kx] (+3 pad)
+};
+
+__device__ __forceinline__ float sigmoid255(float a)
+{
+    // torch.sigmoid = 1/(1+exp(-a)); v_rcp_f32 is 1 ulp, far inside the 1e-5 budget
+    const float e = expf(-a);
+    return __builtin_amdgcn_rcpf(1.0f + e) * 255.0f;
+}
+
+template <int H, int W, int R>
+__device__ __forceinline__ void conv_stage_weights(ConvSmem<H, W, R> &sm, const float *__restrict__ weights,
+                                                   uint64_t seed, uint64_t offset, int gsample, int b)
+{
+    const int tid = threadIdx.x;
+    if (weights != nullptr) {
+        if (tid < 81) sm.w[tid] = weights[(size_t)b * 81 + tid];
+    } else if (tid < 21) {
+        float w4[4];
+        philox_conv_weights4(seed, offset, (uint32_t)gsample, tid, w4);
+        sm.w[4 * tid + 0] = w4[0];
+        sm.w[4 * tid + 1] = w4[1];
+        sm.w[4 * tid + 2] = w4[2];
+        sm.w[4 * tid + 3] = w4[3];
+    }
+}
+
+template <int H, int W, int R>
+__device__ __forceinline__ void conv_compute_store(const ConvSmem<H, W, R> &sm, float *__restrict__ out_frame,
+                                                   int y0)
+{
+    constexpr int W4 = W / 4;
+    const int tid = threadIdx.x;
+    if (tid >= R * W4) return;
+    const int ry = tid / W4;
+    const int x4 = (tid - ry * W4) * 4;
+    const int xl = x4 > 0 ? x4 - 1 : 0;
+    const int xr = x4 + 4 < W ? x4 + 4 : W - 1;
+
+    float v[3][3][6];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const float *row = sm.tile[i][ry + ky];
+            const float4 m = *reinterpret_cast<const float4 *>(row + x4);
+            v[i][ky][0] = row[xl];
+            v[i][ky][1] = m.x;
+            v[i][ky][2] = m.y;
+            v[i][ky][3] = m.z;
+            v[i][ky][4] = m.w;
+            v[i][ky][5] = row[xr];
+        }
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float wv = sm.w[((o * 3 + i) * 3 + ky) * 3 + kx];
+                    a0 = __builtin_fmaf(wv, v[i][ky][kx + 0], a0);
+                    a1 = __builtin_fmaf(wv, v[i][ky][kx + 1], a1);
+                    a2 = __builtin_fmaf(wv, v[i][ky][kx + 2], a2);
+                    a3 = __builtin_fmaf(wv, v[i][ky][kx + 3], a3);
+                }
+        const float4 res = make_float4(sigmoid255(a0), sigmoid255(a1), sigmoid255(a2), sigmoid255(a3));
+        *reinterpret_cast<float4 *>(out_frame + ((size_t)o * H + (y0 + ry)) * W + x4) = res;
+    }
+}
+
+template <int H, int W, int R>
+__global__ __launch_bounds__(256) void k_random_conv(const float *__restrict__ in, float *__restrict__ out,
+                                                     int frames, const float *__restrict__ weights, uint64_t seed,
+                                                     uint64_t offset, int sample0)
+{
+    constexpr int NS = H / R;
+    constexpr int W4 = W / 4;
+    __shared__ __attribute__((aligned(16))) ConvSmem<H, W, R> sm;
+    const int strip = blockIdx.x % NS;
+    const int fidx = blockIdx.x / NS; // b*frames + f
+    const int b = fidx / frames;
+    const int y0 = strip * R;
+    conv_stage_weights<H, W, R>(sm, weights, seed, offset, sample0 + b, b);
+    const float *__restrict__ src = in + (size_t)fidx * 3 * H * W;
+    constexpr int NQ = 3 * (R + 2) * W4;
+    for (int j = threadIdx.x; j < NQ; j += 256) {
+        const int ch = j / ((R + 2) * W4);
+        const int rem = j - ch * ((R + 2) * W4);
+        const int rr = rem / W4;
+        const int x4 = (rem - rr * W4) * 4;
+        const int sy = clampi(y0 - 1 + rr, 0, H - 1);
+        float4 q = *reinterpret_cast<const float4 *>(src + ((size_t)ch * H + sy) * W + x4);
+        q.x = q.x / 255.0f;
+        q.y = q.y / 255.0f;
+        q.z = q.z / 255.0f;
+        q.w = q.w / 255.0f;
+        *reinterpret_cast<float4 *>(&sm.tile[ch][rr][x4]) = q;
+    }
+    __syncthreads();
+    conv_compute_store<H, W, R>(sm, out + (size_t)fidx * 3 * H * W, y0);
+}
+
+// fused random_shift -> (out_shift) -> random_conv -> (out_aug), u8 or f32 observation in
+template <int H, int W, int R, typename TIn>
+__global__ __launch_bounds__(256) void k_shift_conv(const TIn *__restrict__ in, float *__restrict__ out_shift,
+                                                    float *__restrict__ out_aug, int frames, int pad,
+                                                    const int32_t *__restrict__ oy, const int32_t *__restrict__ ox,
+                                                    const float *__restrict__ weights, uint64_t seed,
+                                                    uint64_t offset, int sample0)
+{
+    constexpr int NS = H / R;
+    constexpr int W4 = W / 4;
+    __shared__ __attribute__((aligned(16))) ConvSmem<H, W, R> sm;
+    const int strip = blockIdx.x % NS;
+    const int fidx = blockIdx.x / NS;
+    const int b = fidx / frames;
+    const int y0 = strip * R;
+    int dy, dx;
+    sample_shift(oy, ox, seed, offset, sample0 + b, b, pad, dy, dx);
+    const int r = dx & 3;
+    if (out_aug != nullptr) conv_stage_weights<H, W, R>(sm, weights, seed, offset, sample0 + b, b);
+    const TIn *__restrict__ src = in + (size_t)fidx * 3 * H * W;
+    constexpr int NQ = 3 * (R + 2) * W4;
+    for (int j = threadIdx.x; j < NQ; j += 256) {
+        const int ch = j / ((R + 2) * W4);
+        const int rem = j - ch * ((R + 2) * W4);
+        const int rr = rem / W4;
+        const int x4 = (rem - rr * W4) * 4;
+        const int ys = y0 - 1 + rr;               // row of the SHIFTED image (may be -1 / H: halo)
+        const int yc = clampi(ys, 0, H - 1);      // conv's replicate pad on the shifted image
+        const int sy = clampi(yc + dy, 0, H - 1); // shift's replicate pad on the source
+        float4 q;
+        if constexpr (sizeof(TIn) == 4)
+            q = load_shifted4<W>(reinterpret_cast<const float *>(src) + ((size_t)ch * H + sy) * W, x4, dx, r);
+        else
+            q = unpack_u8x4(
+                load_shifted4_u8<W>(reinterpret_cast<const uint8_t *>(src) + ((size_t)ch * H + sy) * W, x4, dx, r));
+        if (out_shift != nullptr && ys >= y0 && ys < y0 + R)
+            *reinterpret_cast<float4 *>(out_shift + ((size_t)(fidx * 3 + ch) * H + ys) * W + x4) = q;
+        q.x = q.x / 255.0f;
+        q.y = q.y / 255.0f;
+        q.z = q.z / 255.0f;
+        q.w = q.w / 255.0f;
+        *reinterpret_cast<float4 *>(&sm.tile[ch][rr][x4]) = q;
+    }
+    if (out_aug == nullptr) return;
+    __syncthreads();
+    conv_compute_store<H, W, R>(sm, out_aug + (size_t)fidx * 3 * H * W, y0);
+}
+
+// any shape: one output pixel (3 channels) per thread straight from global memory
+__global__ __launch_bounds__(256) void k_random_conv_generic(const float *__restrict__ in, float *__restrict__ out,
+                                                             int frames, int H, int W,
+                                                             const float *__restrict__ weights, uint64_t seed,
+                                                             uint64_t offset, int sample0)
+{
+    __shared__ float w[84];
+    const int fidx = blockIdx.y;
+    const int b = fidx / frames;
+    const int tid = threadIdx.x;
+    if (weights != nullptr) {
+        if (tid < 81) w[tid] = weights[(size_t)b * 81 + tid];
+    } else if (tid < 21) {
+        float w4[4];
+        philox_conv_weights4(seed, offset, (uint32_t)(sample0 + b), tid, w4);
+        for (int k = 0; k < 4; ++k) w[4 * tid + k] = w4[k];
+    }
+    __syncthreads();
+    const int n = H * W;
+    const float *__restrict__ src = in + (size_t)fidx * 3 * n;
+    float *__restrict__ dst = out + (size_t)fidx * 3 * n;
+    for (int j = blockIdx.x * 256 + tid; j < n; j += gridDim.x * 256) {
+        const int y = j / W, x = j - y * W;
+        float acc[3] = {0.f, 0.f, 0.f};
+        for (int i = 0; i < 3; ++i)
+            for (int ky = 0; ky < 3; ++ky)
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float v =
+                        src[(size_t)i * n + clampi(y + ky - 1, 0, H - 1) * W + clampi(x + kx - 1, 0, W - 1)] / 255.0f;
+                    for (int o = 0; o < 3; ++o)
+                        acc[o] = __builtin_fmaf(w[((o * 3 + i) * 3 + ky) * 3 + kx], v, acc[o]);
+                }
+        for (int o = 0; o < 3; ++o) dst[(size_t)o * n + j] = sigmoid255(acc[o]);
+    }
+}
+
+// =========================================================================================
+// random_overlay: out = ((1-a)*(x/255.0) + a*ov)*255.0, literal op order, no contraction.
+//   one thread = one float4 of the (3,H,W) overlay image, reused for all frames of the sample
+// =========================================================================================
+__global__ __launch_bounds__(256) void k_random_overlay(const float *__restrict__ in,
+                                                        const float *__restrict__ overlay, float *__restrict__ out,
+                                                        int frames, int plane4 /* 3*H*W/4 */, float alpha,
+                                                        float one_minus_alpha)
+{
+    const int b = blockIdx.y;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= plane4) return;
+    const float4 ov = reinterpret_cast<const float4 *>(overlay)[(size_t)b * plane4 + q];
+    const float4 c = make_float4(alpha * ov.x, alpha * ov.y, alpha * ov.z, alpha * ov.w);
+    for (int f = 0; f < frames; ++f) {
+        const size_t idx = ((size_t)b * frames + f) * plane4 + q;
+        const float4 x = reinterpret_cast<const float4 *>(in)[idx];
+        float4 o;
+        o.x = (one_minus_alpha * (x.x / 255.0f) + c.x) * 255.0f;
+        o.y = (one_minus_alpha * (x.y / 255.0f) + c.y) * 255.0f;
+        o.z = (one_minus_alpha * (x.z / 255.0f) + c.z) * 255.0f;
+        o.w = (one_minus_alpha * (x.w / 255.0f) + c.w) * 255.0f;
+        reinterpret_cast<float4 *>(out)[idx] = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_random_overlay_generic(const float *__restrict__ in,
+                                                                const float *__restrict__ overlay,
+                                                                float *__restrict__ out, int frames, int plane,
+                                                                float alpha, float one_minus_alpha)
+{
+    const int b = blockIdx.y;
+    for (int q = blockIdx.x * 256 + threadIdx.x; q < plane; q += gridDim.x * 256) {
+        const float c = alpha * overlay[(size_t)b * plane + q];
+        for (int f = 0; f < frames; ++f) {
+            const size_t idx = ((size_t)b * frames + f) * plane + q;
+            out[idx] = (one_minus_alpha * (in[idx] / 255.0f) + c) * 255.0f;
+        }
+    }
+}
+
+// =========================================================================================
+// color_jitter (torchvision 0.8.2 float path, restated): one workgroup per RGB frame; the
+// whole frame (3*H*W f32 = 84.7 KB at 84x84) lives in LDS, so HBM sees one read + one write
+// even though adjust_contrast needs the frame's mean before it can touch a pixel.
+// A frame is processed iff it appears in idx (duplicates collapse, matching the reference's
+// gather-then-scatter semantics; idx == NULL selects every frame); the workgroup scans the
+// short idx list itself, so no flag workspace is needed and unselected frames cost no HBM.
+// =========================================================================================
+struct JitterParams {
+    int order[4];
+    float c_r, c_inv; // contrast ratio, (1 - ratio) rounded from double
+    float s_r, s_inv;
+    float hue;
+    float bound, scale;
+};
+
+__device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+__device__ __forceinline__ float gray(float r, float g, float b) { return (0.2989f * r + 0.587f * g) + 0.114f * b; }
+__device__ __forceinline__ float blend(float a, float b, float ratio, float inv, float bound)
+{
+    return clampf(ratio * a + inv * b, 0.0f, bound);
+}
+
+__device__ __forceinline__ void hue_shift(float &r, float &g, float &b, float hue)
+{
+    const float maxc = fmaxf(r, fmaxf(g, b)), minc = fminf(r, fminf(g, b));
+    const bool eqc = (maxc == minc);
+    const float cr = maxc - minc;
+    const float sat = cr / (eqc ? 1.0f : maxc);
+    const float dv = eqc ? 1.0f : cr;
+    const float rc = (maxc - r) / dv, gc = (maxc - g) / dv, bc = (maxc - b) / dv;
+    const float hr = (maxc == r) ? (bc - gc) : 0.0f;
+    const float hg = ((maxc == g) && (maxc != r)) ? (2.0f + rc - bc) : 0.0f;
+    const float hb = ((maxc != g) && (maxc != r)) ? (4.0f + gc - rc) : 0.0f;
+    float h = (hr + hg) + hb;
+    h = fmodf(h / 6.0f + 1.0f, 1.0f);
+    float hh = fmodf(h + hue, 1.0f);
+    if (hh != 0.0f && hh < 0.0f) hh += 1.0f;
+    const float v = maxc;
+    const float h6 = hh * 6.0f;
+    const float fl = floorf(h6);
+    const float f = h6 - fl;
+    int i = ((int)fl) % 6;
+    if (i < 0) i += 6;
+    const float p = clampf(v * (1.0f - sat), 0.0f, 1.0f);
+    const float q = clampf(v * (1.0f - sat * f), 0.0f, 1.0f);
+    const float t = clampf(v * (1.0f - sat * (1.0f - f)), 0.0f, 1.0f);
+    switch (i) {
+    case 0: r = v; g = t; b = p; break;
+    case 1: r = q; g = v; b = p; break;
+    case 2: r = p; g = v; b = t; break;
+    case 3: r = p; g = q; b = v; break;
+    case 4: r = t; g = p; b = v; break;
+    default: r = v; g = p; b = q; break;
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void k_color_jitter(float *__restrict__ inout, int n /* H*W, %4==0 */,
+                                                     const int32_t *__restrict__ idx, int n_idx, JitterParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float fr[]; // [3][n] then [NT/64] partial sums (double)
+    const int frame = blockIdx.x;
+    const int tid = threadIdx.x;
+    if (idx != nullptr) {
+        int hit = 0;
+        for (int k = tid; k < n_idx; k += NT) hit |= (idx[k] == frame);
+        if (!__syncthreads_or(hit)) return;
+    }
+    float *__restrict__ g = inout + (size_t)frame * 3 * n;
+    const int n4 = n / 4;
+    for (int q = tid; q < 3 * n4; q += NT) {
+        float4 v = reinterpret_cast<const float4 *>(g)[q];
+        if (p.scale != 1.0f) {
+            v.x = v.x / p.scale; v.y = v.y / p.scale; v.z = v.z / p.scale; v.w = v.w / p.scale;
+        }
+        reinterpret_cast<float4 *>(fr)[q] = v;
+    }
+    __syncthreads();
+    float *R = fr, *G = fr + n, *Bc = fr + 2 * n;
+    double *red = reinterpret_cast<double *>(fr + 3 * n);
+    for (int s = 0; s < 4; ++s) {
+        const int op = p.order[s];
+        if (op == 1) {
+            // frame mean of the grayscale image; fixed-order tree (f64 partials) => deterministic
+            double acc = 0.0;
+            for (int k = tid; k < n; k += NT) acc += (double)gray(R[k], G[k], Bc[k]);
+            for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+            if ((tid & 63) == 0) red[tid >> 6] = acc;
+            __syncthreads();
+            double tot = 0.0;
+            for (int w = 0; w < NT / 64; ++w) tot += red[w];
+            const float mean = (float)(tot / (double)n);
+            __syncthreads();
+            for (int k = tid; k < n; k += NT) {
+                R[k] = blend(R[k], mean, p.c_r, p.c_inv, p.bound);
+                G[k] = blend(G[k], mean, p.c_r, p.c_inv, p.bound);
+                Bc[k] = blend(Bc[k], mean, p.c_r, p.c_inv, p.bound);
+            }
+        } else if (op == 2) {
+            for (int k = tid; k < n; k += NT) {
+                const float gy = gray(R[k], G[k], Bc[k]);
+                R[k] = blend(R[k], gy, p.s_r, p.s_inv, p.bound);
+                G[k] = blend(G[k], gy, p.s_r, p.s_inv, p.bound);
+                Bc[k] = blend(Bc[k], gy, p.s_r, p.s_inv, p.bound);
+            }
+        } else if (op == 3) {
+            for (int k = tid; k < n; k += NT) {
+                float r = R[k], gg = G[k], b = Bc[k];
+                hue_shift(r, gg, b, p.hue);
+                R[k] = r; G[k] = gg; Bc[k] = b;
+            }
+        }
+        // each thread touches only its own pixels k = tid (mod NT) across ops; only the mean needs a barrier
+    }
+    __syncthreads();
+    for (int q = tid; q < 3 * n4; q += NT) {
+        float4 v = reinterpret_cast<const float4 *>(fr)[q];
+        if (p.scale != 1.0f) {
+            v.x = v.x * p.scale; v.y = v.y * p.scale; v.z = v.z * p.scale; v.w = v.w * p.scale;
+        }
+        reinterpret_cast<float4 *>(g)[q] = v;
+    }
+}
+
+// ---- Philox parameter export (same device functions the kernels inline) ------------------
+__global__ void k_philox_shift(uint64_t seed, uint64_t offset, int sample0, int B, int pad, int32_t *oy, int32_t *ox)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) {
+        int y, x;
+        philox_shift_offsets(seed, offset, (uint32_t)(sample0 + b), pad, y, x);
+        oy[b] = y;
+        ox[b] = x;
+    }
+}
+
+__global__ void k_philox_conv_w(uint64_t seed, uint64_t offset, int sample0, int B, float *w)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = t / 21, j = t - b * 21;
+    if (b < B) {
+        float w4[4];
+        philox_conv_weights4(seed, offset, (uint32_t)(sample0 + b), j, w4);
+        for (int k = 0; k < 4; ++k)
+            if (4 * j + k < 81) w[(size_t)b * 81 + 4 * j + k] = w4[k];
+    }
+}
+
+__global__ void k_philox_normal(uint64_t seed, uint64_t offset, size_t n, float *out)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; // one Philox call = 4 normals
+    if (4 * t >= n) return;
+    u32x4 c{(uint32_t)t, (uint32_t)(t >> 32), (uint32_t)offset, (uint32_t)(offset >> 32)};
+    u32x4 r = philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32) ^ 0x5eedu);
+    float v[4];
+    box_muller(r.x, r.y, v[0], v[1]);
+    box_muller(r.z, r.w, v[2], v[3]);
+    for (int k = 0; k < 4; ++k)
+        if (4 * t + k < n) out[4 * t + k] = v[k];
+}
+
+} // namespace augcl
+
+// =========================================================================================
+// C ABI
+// =========================================================================================
+using namespace augcl;
+
+#define LAUNCH_CHECK(name) return augcl::check_launch(name)
+
+static bool fast_shape(int H, int W) { return (H == 84 && W == 84) || (H == 100 && W == 100); }
+
+template <typename TIn, typename TOut>
+static int shift_dispatch(const TIn *in, TOut *out, int B, int C, int H, int W, int pad, const int32_t *oy,
+                          const int32_t *ox, uint64_t seed, uint64_t offset, int sample0, augcl_stream_t stream,
+                          const char *name)
+{
+    AUGCL_REQUIRE(in && out, "%s: null tensor", name);
+    AUGCL_REQUIRE(B >= 0 && C > 0 && H > 0 && W > 0 && pad >= 0, "%s: bad shape B=%d C=%d H=%d W=%d pad=%d", name, B,
+                  C, H, W, pad);
+    AUGCL_REQUIRE((oy == nullptr) == (ox == nullptr), "%s: oy/ox must both be given or both NULL", name);
+    AUGCL_REQUIRE((const void *)in != (const void *)out, "%s: in-place not supported", name);
+    if (B == 0) return AUGCL_OK;
+    hipStream_t s = as_stream(stream);
+    const bool vec_ok = fast_shape(H, W) && aligned16(in) && aligned16(out);
+    if (vec_ok && H == 84)
+        hipLaunchKernelGGL((k_random_shift<84, 84, TIn, TOut>), dim3(B * C), dim3(256), 0, s, in, out, C, pad, oy, ox,
+                           seed, offset, sample0);
+    else if (vec_ok && H == 100)
+        hipLaunchKernelGGL((k_random_shift<100, 100, TIn, TOut>), dim3(B * C), dim3(256), 0, s, in, out, C, pad, oy,
+                           ox, seed, offset, sample0);
+    else {
+        const int gx = (H * W + 255) / 256 < 64 ? (H * W + 255) / 256 : 64;
+        hipLaunchKernelGGL((k_random_shift_generic<TIn, TOut>), dim3(gx, B * C), dim3(256), 0, s, in, out, C, H, W,
+                           pad, oy, ox, seed, offset, sample0);
+    }
+    LAUNCH_CHECK(name);
+}
+
+template <typename TIn>
+static int shift_conv_dispatch(const TIn *in, float *out_shift, float *out_aug, int B, int frames, int H, int W,
+                               int pad, const int32_t *oy, const int32_t *ox, const float *weights, uint64_t seed,
+                               uint64_t offset, int sample0, augcl_stream_t stream, const char *name)
+{
+    AUGCL_REQUIRE(in && (out_shift || out_aug), "%s: null tensor", name);
+    AUGCL_REQUIRE(B >= 0 && frames > 0 && pad >= 0, "%s: bad shape", name);
+    AUGCL_REQUIRE((oy == nullptr) == (ox == nullptr), "%s: oy/ox must both be given or both NULL", name);
+    AUGCL_REQUIRE(fast_shape(H, W), "%s: only 84x84 / 100x100 frames are supported (got %dx%d)", name, H, W);
+    AUGCL_REQUIRE(aligned16(in) && aligned16(out_shift) && aligned16(out_aug), "%s: tensors must be 16-byte aligned",
+                  name);
+    if (B == 0) return AUGCL_OK;
+    hipStream_t s = as_stream(stream);
+    if (H == 84)
+        hipLaunchKernelGGL((k_shift_conv<84, 84, 12, TIn>), dim3(B * frames * 7), dim3(256), 0, s, in, out_shift,
+                           out_aug, frames, pad, oy, ox, weights, seed, offset, sample0);
+    else
+        hipLaunchKernelGGL((k_shift_conv<100, 100, 10, TIn>), dim3(B * frames * 10), dim3(256), 0, s, in, out_shift,
+                           out_aug, frames, pad, oy, ox, weights, seed, offset, sample0);
+    LAUNCH_CHECK(name);
+}
+
+extern "C" {
+
+int augcl_random_shift_f32(const float *in, float *out, int B, int C, int H, int W, int pad, const int32_t *oy,
+                           const int32_t *ox, uint64_t seed, uint64_t offset, int sample0, augcl_stream_t stream)
+{
+    return shift_dispatch<float, float>(in, out, B, C, H, W, pad, oy, ox, seed, offset, sample0, stream,
+                                        "augcl_random_shift_f32");
+}
+
+int augcl_random_shift_u8(const uint8_t *in, uint8_t *out, int B, int C, int H, int W, int pad, const int32_t *oy,
+                          const int32_t *ox, uint64_t seed, uint64_t offset, int sample0, augcl_stream_t stream)
+{
+    return shift_dispatch<uint8_t, uint8_t>(in, out, B, C, H, W, pad, oy, ox, seed, offset, sample0, stream,
+                                            "augcl_random_shift_u8");
+}
+
+int augcl_random_shift_u8_f32(const uint8_t *in, float *out, int B, int C, int H, int W, int pad, const int32_t *oy,
+                              const int32_t *ox, uint64_t seed, uint64_t offset, int sample0, augcl_stream_t stream)
+{
+    return shift_dispatch<uint8_t, float>(in, out, B, C, H, W, pad, oy, ox, seed, offset, sample0, stream,
+                                          "augcl_random_shift_u8_f32");
+}
+
+int augcl_random_conv_f32(const float *in, float *out, int B, int frames, int H, int W, const float *weights,
+                          uint64_t seed, uint64_t offset, int sample0, augcl_stream_t stream)
+{
+    const char *name = "augcl_random_conv_f32";
+    AUGCL_REQUIRE(in && out, "%s: null tensor", name);
+    AUGCL_REQUIRE(B >= 0 && frames > 0 && H > 0 && W > 0, "%s: bad shape", name);
+    AUGCL_REQUIRE(in != out, "%s: in-place not supported", name);
+    if (B == 0) return AUGCL_OK;
+    hipStream_t s = as_stream(stream);
+    const bool vec_ok = fast_shape(H, W) && aligned16(in) && aligned16(out);
+    if (vec_ok && H == 84)
+        hipLaunchKernelGGL((k_random_conv<84, 84, 12>), dim3(B * frames * 7), dim3(256), 0, s, in, out, frames,
+                           weights, seed, offset, sample0);
+    else if (vec_ok && H == 100)
+        hipLaunchKernelGGL((k_random_conv<100, 100, 10>), dim3(B * frames * 10), dim3(256), 0, s, in, out, frames,
+                           weights, seed, offset, sample0);
+    else {
+        const int gx = (H * W + 255) / 256 < 64 ? (H * W + 255) / 256 : 64;
+        hipLaunchKernelGGL(k_random_conv_generic, dim3(gx, B * frames), dim3(256), 0, s, in, out, frames, H, W,
+                           weights, seed, offset, sample0);
+    }
+    LAUNCH_CHECK(name);
+}
+
+int augcl_shift_conv_u8_f32(const uint8_t *in, float *out_shift, float *out_aug, int B, int frames, int H, int W,
+                            int pad, const int32_t *oy, const int32_t *ox, const float *weights, uint64_t seed,
+                            uint64_t offset, int sample0, augcl_stream_t stream)
+{
+    return shift_conv_dispatch<uint8_t>(in, out_shift, out_aug, B, frames, H, W, pad, oy, ox, weights, seed, offset,
+                                        sample0, stream, "augcl_shift_conv_u8_f32");
+}
+
+int augcl_shift_conv_f32(const float *in, float *out_shift, float *out_aug, int B, int frames, int H, int W, int pad,
+                         const int32_t *oy, const int32_t *ox, const float *weights, uint64_t seed, uint64_t offset,
+                         int sample0, augcl_stream_t stream)
+{
+    return shift_conv_dispatch<float>(in, out_shift, out_aug, B, frames, H, W, pad, oy, ox, weights, seed, offset,
+                                      sample0, stream, "augcl_shift_conv_f32");
+}
+
+int augcl_random_overlay_f32(const float *in, const float *overlay, float *out, int B, int frames, int H, int W,
+                             float alpha, augcl_stream_t stream)
+{
+    const char *name = "augcl_random_overlay_f32";
+    AUGCL_REQUIRE(in && overlay && out, "%s: null tensor", name);
+    AUGCL_REQUIRE(B >= 0 && frames > 0 && H > 0 && W > 0, "%s: bad shape", name);
+    if (B == 0) return AUGCL_OK;
+    hipStream_t s = as_stream(stream);
+    const float om = (float)(1.0 - (double)alpha);
+    const int plane = 3 * H * W;
+    if ((plane & 3) == 0 && aligned16(in) && aligned16(out) && aligned16(overlay)) {
+        const int plane4 = plane / 4;
+        hipLaunchKernelGGL(k_random_overlay, dim3((plane4 + 255) / 256, B), dim3(256), 0, s, in, overlay, out, frames,
+                           plane4, alpha, om);
+    } else {
+        const int gx = (plane + 255) / 256 < 128 ? (plane + 255) / 256 : 128;
+        hipLaunchKernelGGL(k_random_overlay_generic, dim3(gx, B), dim3(256), 0, s, in, overlay, out, frames, plane,
+                           alpha, om);
+    }
+    LAUNCH_CHECK(name);
+}
+
+int augcl_color_jitter_f32(float *inout, int B, int frames, int H, int W, const int32_t *idx, int n_idx,
+                           const int32_t *order_host, double contrast, double saturation, double hue, float bound,
+                           float scale, augcl_stream_t stream)
+{
+    const char *name = "augcl_color_jitter_f32";
+    AUGCL_REQUIRE(inout && order_host, "%s: null argument", name);
+    AUGCL_REQUIRE(B >= 0 && frames > 0 && H > 0 && W > 0 && n_idx >= 0, "%s: bad shape", name);
+    AUGCL_REQUIRE(idx != nullptr || n_idx == 0, "%s: n_idx > 0 with idx == NULL", name);
+    AUGCL_REQUIRE(scale > 0.0f && bound > 0.0f, "%s: scale and bound must be positive", name);
+    JitterParams p;
+    int seen = 0;
+    for (int k = 0; k < 4; ++k) {
+        AUGCL_REQUIRE(order_host[k] >= 0 && order_host[k] < 4 && !(seen & (1 << order_host[k])),
+                      "%s: order must be a permutation of 0..3", name);
+        seen |= 1 << order_host[k];
+        p.order[k] = order_host[k];
+    }
+    // python-float scalars meet f32 tensors: ratio and (1.0 - ratio) are each rounded to f32 (torchvision _blend)
+    p.c_r = (float)contrast;
+    p.c_inv = (float)(1.0 - contrast);
+    p.s_r = (float)saturation;
+    p.s_inv = (float)(1.0 - saturation);
+    p.hue = (float)hue;
+    p.bound = bound;
+    p.scale = scale;
+    const int n = H * W;
+    constexpr int NT = 1024;
+    const size_t smem = (size_t)3 * n * sizeof(float) + (NT / 64) * sizeof(double);
+    AUGCL_REQUIRE((n & 3) == 0 && aligned16(inout), "%s: H*W must be a multiple of 4 and the tensor 16-B aligned", name);
+    if (smem > 160 * 1024)
+        return augcl::fail(AUGCL_E_UNSUPPORTED, "%s: a %dx%d RGB frame (%zu B) exceeds the 160 KiB LDS of a CU", name, H,
+                           W, smem);
+    if (B == 0 || (idx != nullptr && n_idx == 0)) return AUGCL_OK;
+    static bool attr_set = false; // idempotent; a benign race at worst repeats the call
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_color_jitter<NT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return augcl::fail(AUGCL_E_LAUNCH, "%s: cannot raise dynamic LDS limit", name);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_color_jitter<NT>), dim3(B * frames), dim3(NT), smem, as_stream(stream), inout, n, idx, n_idx,
+                       p);
+    LAUNCH_CHECK(name);
+}
+
+int augcl_philox_shift_offsets(uint64_t seed, uint64_t offset, int sample0, int B, int pad, int32_t *oy, int32_t *ox,
+                               augcl_stream_t stream)
+{
+    AUGCL_REQUIRE(oy && ox && B >= 0 && pad >= 0, "augcl_philox_shift_offsets: bad argument");
+    if (B == 0) return AUGCL_OK;
+    hipLaunchKernelGGL(k_philox_shift, dim3((B + 255) / 256), dim3(256), 0, as_stream(stream), seed, offset, sample0,
+                       B, pad, oy, ox);
+    LAUNCH_CHECK("augcl_philox_shift_offsets");
+}
+
+int augcl_philox_conv_weights(uint64_t seed, uint64_t offset, int sample0, int B, float *weights,
+                              augcl_stream_t stream)
+{
+    AUGCL_REQUIRE(weights && B >= 0, "augcl_philox_conv_weights: bad argument");
+    if (B == 0) return AUGCL_OK;
+    hipLaunchKernelGGL(k_philox_conv_w, dim3((B * 21 + 255) / 256), dim3(256), 0, as_stream(stream), seed, offset,
+                       sample0, B, weights);
+    LAUNCH_CHECK("augcl_philox_conv_weights");
+}
+
+int augcl_philox_normal(uint64_t seed, uint64_t offset, size_t n, float *out, augcl_stream_t stream)
+{
+    AUGCL_REQUIRE(out || n == 0, "augcl_philox_normal: null output");
+    if (n == 0) return AUGCL_OK;
+    const size_t calls = (n + 3) / 4;
+    hipLaunchKernelGGL(k_philox_normal, dim3((unsigned)((calls + 255) / 256)), dim3(256), 0, as_stream(stream), seed,
+                       offset, n, out);
+    LAUNCH_CHECK("augcl_philox_normal");
+}
+
+} // extern "C"

@@ -1,0 +1,88 @@
+// augcl_common.h -- shared device/host helpers for libaugcl_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/augcl.h"
+
+namespace augcl {
+
+// ---- error plumbing (thread-local message, no exceptions across the ABI) ----
+extern thread_local char g_err[512];
+int fail(int code, const char *fmt, ...);
+int check_launch(const char *what);
+
+#define AUGCL_REQUIRE(cond, ...)                                 \
+    do {                                                         \
+        if (!(cond)) return augcl::fail(AUGCL_E_INVALID, __VA_ARGS__); \
+    } while (0)
+
+static inline hipStream_t as_stream(augcl_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline bool aligned4(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 3u) == 0; }
+
+// ---- Philox4x32-10 (Salmon et al. 2011), counter-based: no state, any lane can
+// compute any sample's parameters, so per-sample params are sharding-invariant.
+struct u32x4 {
+    uint32_t x, y, z, w;
+};
+
+__host__ __device__ inline u32x4 philox4x32_10(u32x4 ctr, uint32_t k0, uint32_t k1)
+{
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)M0 * ctr.x;
+        uint64_t p1 = (uint64_t)M1 * ctr.z;
+        u32x4 n;
+        n.x = (uint32_t)(p1 >> 32) ^ ctr.y ^ k0;
+        n.y = (uint32_t)p1;
+        n.z = (uint32_t)(p0 >> 32) ^ ctr.w ^ k1;
+        n.w = (uint32_t)p0;
+        ctr = n;
+        k0 += W0;
+        k1 += W1;
+    }
+    return ctr;
+}
+
+// counter layout: (global sample index, slot, offset_lo, offset_hi); key = seed
+__host__ __device__ inline u32x4 philox_sample(uint64_t seed, uint64_t offset, uint32_t sample, uint32_t slot)
+{
+    u32x4 c{sample, slot, (uint32_t)offset, (uint32_t)(offset >> 32)};
+    return philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+
+// slot 0: crop offsets, uniform over {0..2*pad} by multiply-high (no modulo bias worth the name: 2^32/9)
+__host__ __device__ inline void philox_shift_offsets(uint64_t seed, uint64_t offset, uint32_t sample, int pad,
+                                                     int &oy, int &ox)
+{
+    u32x4 r = philox_sample(seed, offset, sample, 0u);
+    const uint32_t n = (uint32_t)(2 * pad + 1);
+    oy = (int)(((uint64_t)r.x * n) >> 32);
+    ox = (int)(((uint64_t)r.y * n) >> 32);
+}
+
+// Box-Muller on two 24-bit uniforms in (0,1)
+__device__ inline void box_muller(uint32_t a, uint32_t b, float &n0, float &n1)
+{
+    const float u1 = ((float)(a >> 8) + 0.5f) * 5.9604644775390625e-8f; // 2^-24
+    const float u2 = ((float)(b >> 8) + 0.5f) * 5.9604644775390625e-8f;
+    const float rad = sqrtf(-2.0f * logf(u1));
+    float s, c;
+    sincosf(6.283185307179586f * u2, &s, &c);
+    n0 = rad * c;
+    n1 = rad * s;
+}
+
+// slots 1..21: the 81 N(0,1) conv weights of a sample, 4 per Philox call (j = 0..20 -> weights 4j..4j+3)
+__device__ inline void philox_conv_weights4(uint64_t seed, uint64_t offset, uint32_t sample, int j, float w[4])
+{
+    u32x4 r = philox_sample(seed, offset, sample, 1u + (uint32_t)j);
+    box_muller(r.x, r.y, w[0], w[1]);
+    box_muller(r.z, r.w, w[2], w[3]);
+}
+
+} // namespace augcl

@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the hot path (BASELINE.json: "augmented obs/sec + SAC
+grad-steps/sec, walker_walk 84x84x9 batch=256").
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the config-2 augmentation (SVEA's strong augmentation `random_conv`,
+f32 -> f32 drop-in, src/augmentations.py:265-274) over one synthetic batch of B=256 stacked
+84x84x9 observations per GPU, inputs already resident in HBM.  The batch ring is larger than the
+256 MiB Infinity Cache so every step streams from HBM (as freshly sampled replay batches do).
+`value` = observations/s over all ranks (weak scaling: every rank owns its own B=256 shard; the
+augmentation path has no collective).  Extra keys report the other operators, the fused u8
+front end and SAC grad-steps/s, each measured the same way.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+OBS_ELEMS = 9 * 84 * 84
+BYTES_PER_OBS = {  # algorithmic bytes per observation
+    "random_conv_f32": 2 * OBS_ELEMS * 4 + 324,
+    "random_shift_f32": 2 * OBS_ELEMS * 4,
+    "random_shift_u8_f32": OBS_ELEMS * 5,
+    "random_overlay_f32": 2 * OBS_ELEMS * 4 + 3 * 84 * 84 * 4,
+    "color_jitter_f32": 2 * OBS_ELEMS * 4,
+    "shift_conv_u8_f32": OBS_ELEMS * 9,  # u8 in, two f32 outputs
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--batch", type=int, default=256, help="observations per GPU per step")
+    ap.add_argument("--ring", type=int, default=8, help="distinct batches cycled through (defeats the 256 MiB L3)")
+    ap.add_argument("--no-extras", action="store_true", help="headline metric only")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline work (s)")
+    return ap.parse_args()
+
+
+def timed(fn, steps, warmup, dist, torch):
+    """warmup, then time exactly `steps` calls: barrier + synchronize on both sides, wall clock;
+    HIP events on the launch stream give the device-side average per launch."""
+    for i in range(warmup):
+        fn(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for i in range(steps):
+        fn(i)
+    e1.record()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    dev_ms = e0.elapsed_time(e1) / steps
+    if dist is not None:
+        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    return wall, dev_ms
+
+
+def cpu_baseline(target_s):
+    """The oracle (C restatement, OpenMP over frames) of the SAME op on this box's host cores."""
+    import numpy as np
+
+    import inputs as gi
+    from oracle import aug_oracle as orc
+    cores = os.cpu_count() or 1
+    x = gi.obs_u8(0, 8).astype(np.float32)
+    w = gi.conv_weights(1, 8)
+    orc.random_conv_c(x, w)  # warm (thread pool, page faults)
+    t0 = time.perf_counter()
+    orc.random_conv_c(x, w)
+    per_obs = (time.perf_counter() - t0) / 8
+    B = int(min(4096, max(16, target_s / max(per_obs, 1e-9))))
+    x = gi.obs_u8(0, B).astype(np.float32)
+    w = gi.conv_weights(1, B)
+    t0 = time.perf_counter()
+    orc.random_conv_c(x, w)
+    dt = time.perf_counter() - t0
+    model = ""
+    try:
+        model = [ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name")][0]
+    except Exception:
+        pass
+    return {"value": B / dt, "unit": "obs/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/aug_oracle.c random_conv f32, {B} obs of 9x84x84 in {dt:.1f} s, OpenMP {cores} threads, {model}"}
+
+
+def main():
+    args = parse()
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path is the only path (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from augcl_amd import _lib, augmentations as aug
+    _lib.load()
+    B, R = args.batch, args.ring
+    g = torch.Generator(device=dev)
+    g.manual_seed(1000 + rank)
+    ring_u8 = [torch.randint(0, 256, (B, 9, 84, 84), dtype=torch.uint8, device=dev, generator=g) for _ in range(R)]
+    ring_f32 = [t.float() for t in ring_u8]
+    outs = [torch.empty((B, 9, 84, 84), dtype=torch.float32, device=dev) for _ in range(R)]
+    outs2 = [torch.empty((B, 9, 84, 84), dtype=torch.float32, device=dev) for _ in range(2)]
+    weights = torch.randn((B, 81), device=dev, generator=g)
+    oy = torch.randint(0, 9, (B,), dtype=torch.int32, device=dev, generator=g)
+    ox = torch.randint(0, 9, (B,), dtype=torch.int32, device=dev, generator=g)
+    overlay = torch.rand((B, 3, 84, 84), device=dev, generator=g)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    call = _lib.call
+    p = _lib.ptr
+
+    def conv_step(i):
+        k = i % R
+        call("augcl_random_conv_f32", p(ring_f32[k]), p(outs[k]), B, 3, 84, 84, p(weights), 0, 0, 0, stream)
+
+    wall, dev_ms = timed(conv_step, args.steps, args.warmup, dist, torch)
+    value = world * B * args.steps / wall
+    ach = BYTES_PER_OBS["random_conv_f32"] * B / (dev_ms * 1e-3) / 1e9
+    res = {
+        "metric": "augmented obs/sec + SAC grad-steps/sec, walker_walk 84x84x9 batch=256",
+        "value": value, "unit": "obs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "walker_walk SVEA strong augmentation: random_conv f32->f32 drop-in on (256,9,84,84) "
+                               "per GPU, explicit per-sample 3x3x3x3 weights, ring of %d batches (> L3)" % R,
+                   "batch_per_gpu": B, "obs_shape": [9, 84, 84], "parallelism": f"dp{world} (batch-sharded, no collective)"},
+        "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                     "traffic": None, "kernel": "k_random_conv<84,84,12>", "bytes_per_launch": BYTES_PER_OBS["random_conv_f32"] * B,
+                     "avg_launch_ms": dev_ms},
+    }
+    prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(prof):
+        try:
+            t = json.load(open(prof)).get("k_random_conv", {})
+            if t.get("batch") == B:
+                res["roofline"]["traffic"] = t.get("hbm_bytes_per_launch")
+        except Exception:
+            pass
+
+    if not args.no_extras:
+        extras = {}
+        n2 = max(20, args.steps // 4)
+
+        def rate(name, fn):
+            w_, d_ = timed(fn, n2, 10, dist, torch)
+            a_ = BYTES_PER_OBS[name] * B / (d_ * 1e-3) / 1e9
+            extras[name] = {"obs_per_s": world * B * n2 / w_, "GB/s": a_, "frac": a_ / HBM_PEAK_GBS, "avg_launch_ms": d_}
+
+        rate("random_shift_f32", lambda i: call("augcl_random_shift_f32", p(ring_f32[i % R]), p(outs[i % R]), B, 9, 84, 84, 4,
+                                                p(oy), p(ox), 0, 0, 0, stream))
+        rate("random_shift_u8_f32", lambda i: call("augcl_random_shift_u8_f32", p(ring_u8[i % R]), p(outs[i % R]), B, 9, 84,
+                                                   84, 4, p(oy), p(ox), 0, 0, 0, stream))
+        rate("random_overlay_f32", lambda i: call("augcl_random_overlay_f32", p(ring_f32[i % R]), p(overlay), p(outs[i % R]),
+                                                  B, 3, 84, 84, 0.5, stream))
+        rate("shift_conv_u8_f32", lambda i: call("augcl_shift_conv_u8_f32", p(ring_u8[i % R]), p(outs[i % R]),
+                                                 p(outs2[i % 2]), B, 3, 84, 84, 4, p(oy), p(ox), p(weights), 0, 0, 0, stream))
+        order = (_lib.ctypes.c_int32 * 4)(1, 2, 3, 0)
+        order_p = _lib.ctypes.cast(order, _lib.ctypes.c_void_p)
+        rate("color_jitter_f32", lambda i: call("augcl_color_jitter_f32", p(outs[i % R]), B, 3, 84, 84, None, 0, order_p,
+                                                1.2, 0.8, 0.1, 1.0, 255.0, stream))
+        res["extras"] = extras
+        try:
+            from augcl_amd import bench_update
+            res["sac"] = bench_update.run(dev, dist, world, rank, steps=max(10, args.steps // 20))
+        except ImportError:
+            res["sac"] = None
+
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        res["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+    elif rank == 0:
+        res["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(res))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,118 @@
+/*
+ * include/augcl.h -- C ABI of libaugcl_hip.so, the MI355X (gfx950) implementation of
+ * AugCL's data-parallel hot path: pixel augmentations on stacked 84x84 frames, the
+ * shared conv encoder, and the fused optimiser / target-network kernels of the
+ * SAC / SVEA / DrQ / AugCL update().
+ *
+ * The reference (GT-RIPL/AugCL) has no FFI layer: its boundary is the Python call
+ * surface `augmentations.<fn>(x, **params)` / `algorithms.<algo>.update(...)`.
+ * Each entry point below names the reference function (file:line under
+ * /root/reference) whose device work it replaces; augcl_amd/ (Python) is the only
+ * caller and keeps the reference's names and argument meaning.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer borrowed from the caller (torch tensors);
+ *    the library never allocates, frees or retains user buffers;
+ *  - every call is asynchronous on `stream` (a hipStream_t passed as void*;
+ *    NULL = the null stream) and safe to capture in a hipGraph: no hipMalloc,
+ *    no synchronisation, no host<->device copies inside;
+ *  - return value: AUGCL_OK or a negative AUGCL_E_* code; augcl_last_error()
+ *    returns a thread-local message for the last failure on this thread;
+ *  - no global state; re-entrant.
+ *  - tensors are contiguous NCHW; "frames" = C/3 RGB frames per observation.
+ *  - random parameters come in two forms: EXPLICIT (device arrays; what the parity
+ *    tests use) or RNG-INTERNAL (pass NULL for the array: the kernel derives the
+ *    parameters from Philox4x32-10 keyed by (seed, global sample index), so results
+ *    do not depend on how a batch is sharded over ranks).  augcl_philox_* export
+ *    the same streams so a checker can recover the parameters that were used.
+ */
+#ifndef AUGCL_H
+#define AUGCL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AUGCL_ABI_VERSION 1
+
+#define AUGCL_OK 0
+#define AUGCL_E_INVALID (-1)   /* bad argument (null pointer, bad shape, misalignment) */
+#define AUGCL_E_LAUNCH (-2)    /* HIP reported a launch/runtime error */
+#define AUGCL_E_UNSUPPORTED (-3)
+
+typedef void *augcl_stream_t; /* hipStream_t */
+
+int augcl_abi_version(void);
+const char *augcl_last_error(void);
+/* number of HIP devices visible, or a negative error: lets a host verify the GPU
+ * path exists before relying on it (the Python shim raises if this fails). */
+int augcl_device_count(void);
+
+/* ---- RNG parameter streams (Philox4x32-10; counter = (sample, slot, offset_lo, offset_hi), key = seed) */
+int augcl_philox_shift_offsets(uint64_t seed, uint64_t offset, int sample0, int B, int pad,
+                               int32_t *oy, int32_t *ox, augcl_stream_t stream);
+int augcl_philox_conv_weights(uint64_t seed, uint64_t offset, int sample0, int B,
+                              float *weights /* B x 81 */, augcl_stream_t stream);
+int augcl_philox_normal(uint64_t seed, uint64_t offset, size_t n, float *out, augcl_stream_t stream);
+
+/* ---- random_shift: src/augmentations.py:378-382 (F.pad replicate + kornia RandomCrop((h,w)))
+ * out[b,c,y,x] = in[b,c,clamp(y+oy[b]-pad,0,H-1),clamp(x+ox[b]-pad,0,W-1)], oy/ox in [0,2*pad].
+ * oy/ox: device int32[B], or both NULL => Philox (seed, offset, sample0 + b).
+ * _u8 / _u8_f32 read the replay buffer's uint8 frames directly (fusing the `.float()` of
+ * src/utils.py:208-209 for _u8_f32).  Integer index op: bit-exact. */
+int augcl_random_shift_f32(const float *in, float *out, int B, int C, int H, int W, int pad,
+                           const int32_t *oy, const int32_t *ox,
+                           uint64_t seed, uint64_t offset, int sample0, augcl_stream_t stream);
+int augcl_random_shift_u8(const uint8_t *in, uint8_t *out, int B, int C, int H, int W, int pad,
+                          const int32_t *oy, const int32_t *ox,
+                          uint64_t seed, uint64_t offset, int sample0, augcl_stream_t stream);
+int augcl_random_shift_u8_f32(const uint8_t *in, float *out, int B, int C, int H, int W, int pad,
+                              const int32_t *oy, const int32_t *ox,
+                              uint64_t seed, uint64_t offset, int sample0, augcl_stream_t stream);
+
+/* ---- random_conv: src/augmentations.py:265-274
+ * per sample b, W_b = weights[b] laid out [o][i][ky][kx] (3,3,3,3): every RGB frame f of the
+ * sample: out = sigmoid(conv2d(replicate_pad1(in/255.0), W_b)) * 255.0.
+ * weights: device float[B*81], or NULL => Philox normals (seed, offset, sample0 + b). */
+int augcl_random_conv_f32(const float *in, float *out, int B, int frames, int H, int W,
+                          const float *weights,
+                          uint64_t seed, uint64_t offset, int sample0, augcl_stream_t stream);
+
+/* ---- random_overlay: src/augmentations.py:253-262 (arithmetic at L262; the image batch comes
+ * from _get_data_batch L76-86, `.repeat(1, C//3, 1, 1)` L260)
+ * out = ((1-alpha)*(in/255.0) + alpha*overlay[b]) * 255.0, overlay (B,3,H,W) in [0,1],
+ * the same image for every frame of a sample.  Literal op order: bit-exact vs torch f32. */
+int augcl_random_overlay_f32(const float *in, const float *overlay, float *out,
+                             int B, int frames, int H, int W, float alpha, augcl_stream_t stream);
+
+/* ---- color_jitter: src/augmentations.py:225-237 (+ get_jitter_model L15-16)
+ * In place.  idx: device int32[n_idx] indices into the (B*frames,3,H,W) view (duplicates
+ * allowed, as np.random.randint draws them); order[4]: torchvision op ids in application
+ * order (0 brightness=disabled, 1 contrast, 2 saturation, 3 hue), HOST array; factors are
+ * the python floats torchvision would draw.  bound = clamp ceiling of _blend (1.0 = the
+ * literal float path the reference runs on its 0..255 floats); scale: frame is divided by
+ * scale before and multiplied after (1 = literal/compat, 255 = documented "sane" mode). */
+int augcl_color_jitter_f32(float *inout, int B, int frames, int H, int W,
+                           const int32_t *idx, int n_idx, const int32_t *order_host,
+                           double contrast, double saturation, double hue,
+                           float bound, float scale, augcl_stream_t stream);
+
+/* ---- fused SVEA/AugCL front end: src/algorithms/svea.py:68 + :49 (random_shift, then
+ * apply_aug=random_conv on the shifted clone) in one pass over the uint8/f32 observation:
+ * out_shift = random_shift(in); out_aug = random_conv(out_shift).  Either output may be NULL. */
+int augcl_shift_conv_u8_f32(const uint8_t *in, float *out_shift, float *out_aug,
+                            int B, int frames, int H, int W, int pad,
+                            const int32_t *oy, const int32_t *ox, const float *weights,
+                            uint64_t seed, uint64_t offset, int sample0, augcl_stream_t stream);
+int augcl_shift_conv_f32(const float *in, float *out_shift, float *out_aug,
+                         int B, int frames, int H, int W, int pad,
+                         const int32_t *oy, const int32_t *ox, const float *weights,
+                         uint64_t seed, uint64_t offset, int sample0, augcl_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AUGCL_H */

@@ -1,0 +1,261 @@
+/*
+ * oracle/aug_oracle.c -- CPU restatement of AugCL's pixel-augmentation operators.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under augcl_amd/ may include, link or call
+ * this file; it exists so that tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg have an independent checker for the HIP kernels.
+ *
+ * Each function restates one reference operator with EXPLICIT random parameters
+ * (crop offsets, conv weights, overlay images, jitter factors) so that parity
+ * never depends on reproducing an RNG stream.
+ *
+ * Pinning status (see DESIGN.md "Oracle"):
+ *   random_conv / random_overlay : pinned -- checked against outputs of the
+ *       reference's own functions run in the build container
+ *       (tests/golden/make_golden.py -> tests/golden/aug_*.npz).
+ *   random_shift : the replicate-pad half is pinned (F.pad is torch); the crop
+ *       half lives in kornia (unpinned version, absent) => integer-offset copy
+ *       semantics are restatement-defined: "parity unpinned" for the crop.
+ *   color_jitter : arithmetic lives in torchvision 0.8.2 (absent) =>
+ *       restatement of its published functional_tensor algorithm:
+ *       "parity unpinned".
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -fopenmp -shared).
+ * -ffp-contract=off matters: the reference is a chain of separate IEEE f32
+ * ops, so the checker must not fuse multiply-adds.
+ */
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <string.h>
+
+static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+/* reference: src/augmentations.py:378-382  random_shift(imgs, pad=4)
+ *   F.pad(imgs, (pad,)*4, mode="replicate")  then a per-sample (h,w) crop at
+ *   integer offset (oy, ox) in [0, 2*pad].  All C channels of a sample share the
+ *   offset.  out[b,c,y,x] = in[b,c,clamp(y+oy-pad), clamp(x+ox-pad)].          */
+void oracle_random_shift_f32(const float *in, float *out, int B, int C, int H, int W,
+                             int pad, const int32_t *oy, const int32_t *ox)
+{
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int c = 0; c < C; ++c) {
+            const float *src = in + ((size_t)b * C + c) * H * W;
+            float *dst = out + ((size_t)b * C + c) * H * W;
+            for (int y = 0; y < H; ++y) {
+                int sy = clampi(y + oy[b] - pad, 0, H - 1);
+                for (int x = 0; x < W; ++x) {
+                    int sx = clampi(x + ox[b] - pad, 0, W - 1);
+                    dst[(size_t)y * W + x] = src[(size_t)sy * W + sx];
+                }
+            }
+        }
+}
+
+/* u8 replay-buffer frames in, u8 out (same index arithmetic, SURVEY 8d variant column) */
+void oracle_random_shift_u8(const uint8_t *in, uint8_t *out, int B, int C, int H, int W,
+                            int pad, const int32_t *oy, const int32_t *ox)
+{
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int c = 0; c < C; ++c) {
+            const uint8_t *src = in + ((size_t)b * C + c) * H * W;
+            uint8_t *dst = out + ((size_t)b * C + c) * H * W;
+            for (int y = 0; y < H; ++y) {
+                int sy = clampi(y + oy[b] - pad, 0, H - 1);
+                for (int x = 0; x < W; ++x) {
+                    int sx = clampi(x + ox[b] - pad, 0, W - 1);
+                    dst[(size_t)y * W + x] = src[(size_t)sy * W + sx];
+                }
+            }
+        }
+}
+
+/* u8 in -> f32 out: fuses ReplayBuffer.tensor_buffer_samples' .float()
+ * (src/utils.py:208-209) into the shift.  u8 -> f32 conversion is exact.       */
+void oracle_random_shift_u8_f32(const uint8_t *in, float *out, int B, int C, int H, int W,
+                                int pad, const int32_t *oy, const int32_t *ox)
+{
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int c = 0; c < C; ++c) {
+            const uint8_t *src = in + ((size_t)b * C + c) * H * W;
+            float *dst = out + ((size_t)b * C + c) * H * W;
+            for (int y = 0; y < H; ++y) {
+                int sy = clampi(y + oy[b] - pad, 0, H - 1);
+                for (int x = 0; x < W; ++x) {
+                    int sx = clampi(x + ox[b] - pad, 0, W - 1);
+                    dst[(size_t)y * W + x] = (float)src[(size_t)sy * W + sx];
+                }
+            }
+        }
+}
+
+/* reference: src/augmentations.py:265-274  random_conv(x)
+ *   per sample b: W_b (3 out, 3 in, 3, 3); the sample is viewed as `frames`
+ *   RGB images; x/255.0 -> replicate pad 1 -> conv2d(no bias) -> sigmoid -> *255.0
+ *   weights layout: [B][o][i][ky][kx] = B x 81 floats (torch.randn(3,3,3,3)).
+ *   Summation order here: i, ky, kx ascending (cross-correlation, like conv2d).
+ *   The reference's order is whatever ATen's CPU conv picks => float tolerance. */
+void oracle_random_conv_f32(const float *in, float *out, int B, int frames, int H, int W,
+                            const float *weights)
+{
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int f = 0; f < frames; ++f) {
+            const float *wb = weights + (size_t)b * 81;
+            const float *src = in + ((size_t)b * frames + f) * 3 * H * W;
+            float *dst = out + ((size_t)b * frames + f) * 3 * H * W;
+            for (int o = 0; o < 3; ++o)
+                for (int y = 0; y < H; ++y)
+                    for (int x = 0; x < W; ++x) {
+                        float acc = 0.0f;
+                        for (int i = 0; i < 3; ++i)
+                            for (int ky = 0; ky < 3; ++ky) {
+                                int sy = clampi(y + ky - 1, 0, H - 1);
+                                for (int kx = 0; kx < 3; ++kx) {
+                                    int sx = clampi(x + kx - 1, 0, W - 1);
+                                    float v = src[((size_t)i * H + sy) * W + sx] / 255.0f;
+                                    acc += wb[((o * 3 + i) * 3 + ky) * 3 + kx] * v;
+                                }
+                            }
+                        float s = 1.0f / (1.0f + expf(-acc));
+                        dst[((size_t)o * H + y) * W + x] = s * 255.0f;
+                    }
+        }
+}
+
+/* reference: src/augmentations.py:253-262  random_overlay(x)
+ *   ((1-alpha)*(x/255.0) + alpha*imgs) * 255.0, alpha = 0.5; `overlay` is the
+ *   (B,3,H,W) image batch in [0,1] repeated over the frames of each sample
+ *   (.repeat(1, C//3, 1, 1)).  Literal op order kept => bit-exact vs torch.     */
+void oracle_random_overlay_f32(const float *in, const float *overlay, float *out,
+                               int B, int frames, int H, int W, float alpha)
+{
+    const float one_minus = (float)(1.0 - (double)alpha); /* python: (1 - alpha) in double, then f32 scalar */
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int f = 0; f < frames; ++f) {
+            const size_t plane = (size_t)3 * H * W;
+            const float *src = in + ((size_t)b * frames + f) * plane;
+            const float *ov = overlay + (size_t)b * plane;
+            float *dst = out + ((size_t)b * frames + f) * plane;
+            for (size_t k = 0; k < plane; ++k) {
+                float t = src[k] / 255.0f;
+                float a = one_minus * t;
+                float c = alpha * ov[k];
+                dst[k] = (a + c) * 255.0f;
+            }
+        }
+}
+
+/* ---- color_jitter: restatement of torchvision 0.8.2 functional_tensor -------
+ * call site: src/augmentations.py:225-237 (get_jitter_model L15-16:
+ * ColorJitter(brightness=0, contrast=(0,2), saturation=(0,3), hue=(-.5,.5))).
+ * One parameter set + one op order for the whole call; applied in place to the
+ * RGB frames listed in idx (indices into the (B*frames, 3, H, W) view).
+ * ops in `order[4]` use torchvision's ids: 0 brightness (skipped: brightness=0
+ * collapses to None), 1 contrast, 2 saturation, 3 hue.
+ * bound: 1.0 reproduces the literal float path (`_blend(...).clamp(0, 1)`),
+ * which is what the reference executes on its 0..255 floats ("compat");
+ * scale: the frame is divided by `scale` before and multiplied after the chain
+ * (scale=1 compat; scale=255 is the documented "sane" mode).
+ * PARITY UNPINNED: torchvision is absent from the container and from
+ * /root/reference; this follows its published algorithm.                       */
+static inline float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
+static inline float grayf(float r, float g, float b) { return (0.2989f * r + 0.587f * g) + 0.114f * b; }
+static inline float blendf(float a, float b, double ratio, float bound)
+{
+    /* _blend: ratio * img1 + (1.0 - ratio) * img2 with `ratio` a python float:
+     * each scalar is rounded to f32 when it meets the f32 tensor.              */
+    float rf = (float)ratio, inv = (float)(1.0 - ratio);
+    return clampf(rf * a + inv * b, 0.0f, bound);
+}
+
+static void jitter_frame(float *fr, int H, int W, const int32_t *order, double contrast,
+                         double saturation, double hue, float bound, float scale)
+{
+    const size_t n = (size_t)H * W;
+    float *R = fr, *G = fr + n, *Bc = fr + 2 * n;
+    if (scale != 1.0f)
+        for (size_t k = 0; k < 3 * n; ++k) fr[k] = fr[k] / scale;
+    for (int s = 0; s < 4; ++s) {
+        int op = order[s];
+        if (op == 1) { /* adjust_contrast: blend with the mean of the grayscale image */
+            double acc = 0.0; /* torch.mean over H*W f32 uses pairwise/vector sums; f64 acc is the neutral choice */
+            for (size_t k = 0; k < n; ++k) acc += (double)grayf(R[k], G[k], Bc[k]);
+            float mean = (float)(acc / (double)n);
+            for (size_t k = 0; k < n; ++k) {
+                R[k] = blendf(R[k], mean, contrast, bound);
+                G[k] = blendf(G[k], mean, contrast, bound);
+                Bc[k] = blendf(Bc[k], mean, contrast, bound);
+            }
+        } else if (op == 2) { /* adjust_saturation: blend with the grayscale image */
+            for (size_t k = 0; k < n; ++k) {
+                float g = grayf(R[k], G[k], Bc[k]);
+                R[k] = blendf(R[k], g, saturation, bound);
+                G[k] = blendf(G[k], g, saturation, bound);
+                Bc[k] = blendf(Bc[k], g, saturation, bound);
+            }
+        } else if (op == 3) { /* adjust_hue: _rgb2hsv -> h=(h+f)%1 -> _hsv2rgb */
+            for (size_t k = 0; k < n; ++k) {
+                float r = R[k], g = G[k], b = Bc[k];
+                float maxc = fmaxf(r, fmaxf(g, b)), minc = fminf(r, fminf(g, b));
+                int eqc = (maxc == minc);
+                float cr = maxc - minc;
+                float sat = cr / (eqc ? 1.0f : maxc);
+                float div = eqc ? 1.0f : cr;
+                float rc = (maxc - r) / div, gc = (maxc - g) / div, bc = (maxc - b) / div;
+                float hr = (maxc == r) ? (bc - gc) : 0.0f;
+                float hg = ((maxc == g) && (maxc != r)) ? (2.0f + rc - bc) : 0.0f;
+                float hb = ((maxc != g) && (maxc != r)) ? (4.0f + gc - rc) : 0.0f;
+                float h = (hr + hg) + hb;
+                h = fmodf(h / 6.0f + 1.0f, 1.0f);
+                /* h = (h + hue_factor) % 1.0 : python-style (floor) modulo */
+                float hh = fmodf(h + (float)hue, 1.0f); /* torch.remainder: fmod, then fix the sign */
+                if (hh != 0.0f && hh < 0.0f) hh += 1.0f; /* may round to exactly 1.0f, as in torch */
+                float v = maxc;
+                float h6 = hh * 6.0f;
+                float fl = floorf(h6);
+                float f = h6 - fl;
+                int i = ((int)fl) % 6;
+                if (i < 0) i += 6;
+                float p = clampf(v * (1.0f - sat), 0.0f, 1.0f);
+                float q = clampf(v * (1.0f - sat * f), 0.0f, 1.0f);
+                float t = clampf(v * (1.0f - sat * (1.0f - f)), 0.0f, 1.0f);
+                float ro, go, bo;
+                switch (i) {
+                case 0: ro = v; go = t; bo = p; break;
+                case 1: ro = q; go = v; bo = p; break;
+                case 2: ro = p; go = v; bo = t; break;
+                case 3: ro = p; go = q; bo = v; break;
+                case 4: ro = t; go = p; bo = v; break;
+                default: ro = v; go = p; bo = q; break;
+                }
+                R[k] = ro; G[k] = go; Bc[k] = bo;
+            }
+        }
+        /* op == 0 (brightness): disabled by brightness=0 -> None */
+    }
+    if (scale != 1.0f)
+        for (size_t k = 0; k < 3 * n; ++k) fr[k] = fr[k] * scale;
+}
+
+void oracle_color_jitter_f32(float *inout, int B, int frames, int H, int W,
+                             const int32_t *idx, int n_idx, const int32_t *order,
+                             double contrast, double saturation, double hue, float bound, float scale)
+{
+    /* imgs[idx] = model(imgs[idx]): gather -> transform -> scatter.  Duplicate
+     * indices all receive the transform of the ORIGINAL frame (the gather happens
+     * before any write), so each distinct frame is transformed exactly once.   */
+    const int total = B * frames;
+    uint8_t *seen = (uint8_t *)__builtin_alloca((size_t)total);
+    memset(seen, 0, (size_t)total);
+    for (int k = 0; k < n_idx; ++k)
+        if (idx[k] >= 0 && idx[k] < total) seen[idx[k]] = 1;
+#pragma omp parallel for schedule(dynamic)
+    for (int fidx = 0; fidx < total; ++fidx)
+        if (seen[fidx])
+            jitter_frame(inout + (size_t)fidx * 3 * H * W, H, W, order, contrast, saturation, hue, bound, scale);
+}

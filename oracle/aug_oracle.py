@@ -1,0 +1,136 @@
+"""oracle/aug_oracle.py -- numpy restatement of AugCL's augmentation operators
+plus a ctypes view of the C restatement (oracle/aug_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  Nothing under augcl_amd/ imports this module.
+
+Every function takes the random parameters explicitly; none touches an RNG.
+Pinning status per operator is stated in aug_oracle.c's header and DESIGN.md.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle_aug.so")
+_lib = None
+
+_f32p = ctypes.POINTER(ctypes.c_float)
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+_i32p = ctypes.POINTER(ctypes.c_int32)
+
+
+def build(force=False):
+    """Compile the C checker with gcc (no GPU, no reference needed)."""
+    src = os.path.join(_HERE, "aug_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle_aug.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(_LIB_PATH)
+    return _lib
+
+
+def _p(a, ty):
+    return a.ctypes.data_as(ty)
+
+
+# --------------------------------------------------------------------------- numpy
+def random_shift_np(x, oy, ox, pad=4):
+    """src/augmentations.py:378-382: replicate pad + per-sample integer crop.
+    x: (B,C,H,W) any dtype; oy/ox: (B,) ints in [0, 2*pad]."""
+    B, C, H, W = x.shape
+    ys = np.clip(np.arange(H)[None, :] + np.asarray(oy)[:, None] - pad, 0, H - 1)  # (B,H)
+    xs = np.clip(np.arange(W)[None, :] + np.asarray(ox)[:, None] - pad, 0, W - 1)  # (B,W)
+    b = np.arange(B)[:, None, None, None]
+    c = np.arange(C)[None, :, None, None]
+    return x[b, c, ys[:, None, :, None], xs[:, None, None, :]]
+
+
+def random_conv_np(x, weights):
+    """src/augmentations.py:265-274. x (B,C,H,W) f32 in 0..255; weights (B,3,3,3,3)."""
+    B, C, H, W = x.shape
+    fr = C // 3
+    xn = (x.reshape(B, fr, 3, H, W) / np.float32(255.0)).astype(np.float32)
+    xp = np.pad(xn, ((0, 0), (0, 0), (0, 0), (1, 1), (1, 1)), mode="edge")
+    w = np.asarray(weights, dtype=np.float32).reshape(B, 3, 3, 3, 3)
+    acc = np.zeros((B, fr, 3, H, W), dtype=np.float32)
+    for i in range(3):
+        for ky in range(3):
+            for kx in range(3):
+                win = xp[:, :, i, ky:ky + H, kx:kx + W]  # (B,fr,H,W)
+                acc += w[:, None, :, i, ky, kx, None, None] * win[:, :, None]
+    one = np.float32(1.0)
+    out = one / (one + np.exp(-acc, dtype=np.float32))
+    return (out * np.float32(255.0)).reshape(B, C, H, W)
+
+
+def random_overlay_np(x, overlay, alpha=0.5):
+    """src/augmentations.py:253-262, literal op order (bit-exact vs torch f32)."""
+    B, C, H, W = x.shape
+    imgs = np.tile(np.asarray(overlay, dtype=np.float32), (1, C // 3, 1, 1))
+    a = np.float32(alpha)
+    om = np.float32(1.0 - alpha)
+    return ((om * (x / np.float32(255.0))) + a * imgs) * np.float32(255.0)
+
+
+# --------------------------------------------------------------------------- C
+def random_shift_c(x, oy, ox, pad=4, out_dtype=None):
+    x = np.ascontiguousarray(x)
+    B, C, H, W = x.shape
+    oy = np.ascontiguousarray(oy, dtype=np.int32)
+    ox = np.ascontiguousarray(ox, dtype=np.int32)
+    L = lib()
+    if x.dtype == np.float32:
+        out = np.empty_like(x)
+        L.oracle_random_shift_f32(_p(x, _f32p), _p(out, _f32p), B, C, H, W, pad, _p(oy, _i32p), _p(ox, _i32p))
+    elif x.dtype == np.uint8 and out_dtype in (None, np.uint8):
+        out = np.empty_like(x)
+        L.oracle_random_shift_u8(_p(x, _u8p), _p(out, _u8p), B, C, H, W, pad, _p(oy, _i32p), _p(ox, _i32p))
+    elif x.dtype == np.uint8:
+        out = np.empty(x.shape, dtype=np.float32)
+        L.oracle_random_shift_u8_f32(_p(x, _u8p), _p(out, _f32p), B, C, H, W, pad, _p(oy, _i32p), _p(ox, _i32p))
+    else:
+        raise TypeError(x.dtype)
+    return out
+
+
+def random_conv_c(x, weights):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    B, C, H, W = x.shape
+    w = np.ascontiguousarray(weights, dtype=np.float32).reshape(B, 81)
+    out = np.empty_like(x)
+    lib().oracle_random_conv_f32(_p(x, _f32p), _p(out, _f32p), B, C // 3, H, W, _p(w, _f32p))
+    return out
+
+
+def random_overlay_c(x, overlay, alpha=0.5):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    B, C, H, W = x.shape
+    ov = np.ascontiguousarray(overlay, dtype=np.float32)
+    assert ov.shape == (B, 3, H, W)
+    out = np.empty_like(x)
+    lib().oracle_random_overlay_f32(_p(x, _f32p), _p(ov, _f32p), _p(out, _f32p), B, C // 3, H, W,
+                                    ctypes.c_float(alpha))
+    return out
+
+
+def color_jitter_c(x, idx, order, contrast, saturation, hue, bound=1.0, scale=1.0):
+    """In-place on a copy; returns the jittered (B,C,H,W) array.
+    idx indexes the (B*frames,3,H,W) view (src/augmentations.py:233-236)."""
+    out = np.array(x, dtype=np.float32, order="C", copy=True)
+    B, C, H, W = out.shape
+    idx = np.ascontiguousarray(idx, dtype=np.int32)
+    order = np.ascontiguousarray(order, dtype=np.int32)
+    assert order.shape == (4,)
+    lib().oracle_color_jitter_f32(_p(out, _f32p), B, C // 3, H, W, _p(idx, _i32p), int(idx.size), _p(order, _i32p),
+                                  ctypes.c_double(contrast), ctypes.c_double(saturation), ctypes.c_double(hue),
+                                  ctypes.c_float(bound), ctypes.c_float(scale))
+    return out

@@ -1,0 +1,61 @@
+"""Seeded synthetic inputs shared by the golden generator and the tests
+(np.random.RandomState is a frozen legacy stream: identical on every box).
+Shapes follow SURVEY.md 8(d): obs u8 (B,9,84,84); action U(-1,1); reward U(0,4);
+not_done = 1; overlay images f32 U[0,1) (B,3,84,84)."""
+import numpy as np
+
+C, H, W = 9, 84, 84
+
+
+def obs_u8(seed, B, C=C, H=H, W=W):
+    return np.random.RandomState(seed).randint(0, 256, size=(B, C, H, W)).astype(np.uint8)
+
+
+def overlay_imgs(seed, B, H=H, W=W):
+    return np.random.RandomState(seed).random_sample((B, 3, H, W)).astype(np.float32)
+
+
+def shift_offsets(seed, B, pad=4):
+    rs = np.random.RandomState(seed)
+    return (rs.randint(0, 2 * pad + 1, size=B).astype(np.int32),
+            rs.randint(0, 2 * pad + 1, size=B).astype(np.int32))
+
+
+def conv_weights(seed, B):
+    return np.random.RandomState(seed).standard_normal((B, 3, 3, 3, 3)).astype(np.float32)
+
+
+def jitter_params(seed):
+    rs = np.random.RandomState(seed)
+    order = rs.permutation(4).astype(np.int32)
+    return order, float(rs.uniform(0, 2)), float(rs.uniform(0, 3)), float(rs.uniform(-0.5, 0.5))
+
+
+def transition_batch(seed, B, A):
+    """(obs_u8, action, reward, next_obs_u8, not_done) as numpy arrays."""
+    rs = np.random.RandomState(seed)
+    obs = rs.randint(0, 256, size=(B, C, H, W)).astype(np.uint8)
+    next_obs = rs.randint(0, 256, size=(B, C, H, W)).astype(np.uint8)
+    action = rs.uniform(-1, 1, size=(B, A)).astype(np.float32)
+    reward = rs.uniform(0, 4, size=(B, 1)).astype(np.float32)
+    not_done = np.ones((B, 1), dtype=np.float32)
+    return obs, action, reward, next_obs, not_done
+
+
+def smooth_obs_u8(seed, B, C=C, H=H, W=W):
+    """Image-like (spatially correlated) frames: exercises hue/saturation branches
+    that uniform noise rarely hits (gray pixels, saturated primaries)."""
+    rs = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+    out = np.empty((B, C, H, W), dtype=np.uint8)
+    for b in range(B):
+        for c in range(C):
+            fx, fy, ph = rs.uniform(0.02, 0.2), rs.uniform(0.02, 0.2), rs.uniform(0, 6.28)
+            img = 127.5 + 127.5 * np.sin(fx * xx + fy * yy + ph)
+            out[b, c] = np.clip(img, 0, 255).astype(np.uint8)
+    # a flat gray patch and saturated primaries (eqc / maxc==r branches of rgb2hsv)
+    out[:, :, :6, :6] = 90
+    out[:, 0::3, 6:12, :6] = 255
+    out[:, 1::3, 6:12, :6] = 0
+    out[:, 2::3, 6:12, :6] = 0
+    return out

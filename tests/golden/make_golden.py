@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""Mint golden vectors from the UNMODIFIED reference (build container only).
+
+Run:  PYTHONDONTWRITEBYTECODE=1 python3 -O tests/golden/make_golden.py [aug|nets|update|all]
+
+The reference (/root/reference/src) is imported on CPU with empty placeholder
+modules for the third-party packages that are absent here (torchvision, kornia,
+termcolor, tensorboard) and `.cuda()` neutralised (recipe: SURVEY.md Appendix A).
+`-O` strips `assert x.is_cuda`.  Nothing from the reference is copied: only the
+numeric OUTPUTS of its functions on seeded inputs are stored, together with the
+explicit random parameters that were drawn, as small .npz files next to this
+script.  Inputs are regenerated on both sides by tests/golden/inputs.py.
+
+Stand-ins for absent libraries (restatement-defined, "parity unpinned"):
+  * kornia.augmentation.RandomCrop -> integer slice at recorded offsets.
+  * torchvision.transforms.ColorJitter -> torch restatement of torchvision
+    0.8.2's functional_tensor algorithm (see _ColorJitter below).
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import inputs as gi  # noqa: E402
+
+REF = "/root/reference/src"
+
+
+def _install_stubs():
+    sys.path.insert(0, REF)
+    for n in ["torchvision", "torchvision.transforms", "torchvision.datasets", "kornia",
+              "kornia.augmentation", "kornia.color", "termcolor", "torch.utils.tensorboard"]:
+        sys.modules[n] = types.ModuleType(n)
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    sys.modules["torchvision"].datasets = sys.modules["torchvision.datasets"]
+    sys.modules["kornia"].augmentation = sys.modules["kornia.augmentation"]
+    sys.modules["kornia"].color = sys.modules["kornia.color"]
+    sys.modules["termcolor"].colored = lambda s, *a, **k: s
+    sys.modules["torch.utils.tensorboard"].SummaryWriter = object
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    torch.Tensor.get_device = lambda self: "cpu"
+
+    class RandomCrop:  # stand-in for the absent kornia op; records what it drew
+        last = None
+
+        def __init__(self, size):
+            self.size = size
+
+        def __call__(self, x):
+            n, c, H, W = x.shape
+            h, w = self.size
+            oy = torch.randint(0, H - h + 1, (n,))
+            ox = torch.randint(0, W - w + 1, (n,))
+            RandomCrop.last = (oy.numpy().astype(np.int32), ox.numpy().astype(np.int32))
+            return torch.stack([x[i, :, oy[i]:oy[i] + h, ox[i]:ox[i] + w] for i in range(n)])
+
+    sys.modules["kornia.augmentation"].RandomCrop = RandomCrop
+
+    class _ColorJitter:
+        """torchvision 0.8.2 ColorJitter on float tensors, restated with torch ops."""
+        last = None
+
+        def __init__(self, brightness, contrast, saturation, hue):
+            assert brightness == 0
+            self.contrast, self.saturation, self.hue = contrast, saturation, hue
+
+        def to(self, *_a, **_k):
+            return self
+
+        @staticmethod
+        def _gray(img):
+            r, g, b = img.unbind(dim=-3)
+            return (0.2989 * r + 0.587 * g + 0.114 * b).unsqueeze(-3)
+
+        @staticmethod
+        def _blend(a, b, ratio):
+            return (ratio * a + (1.0 - ratio) * b).clamp(0, 1.0)
+
+        @staticmethod
+        def _rgb2hsv(img):
+            r, g, b = img.unbind(dim=-3)
+            maxc = torch.max(img, dim=-3).values
+            minc = torch.min(img, dim=-3).values
+            eqc = maxc == minc
+            cr = maxc - minc
+            ones = torch.ones_like(maxc)
+            s = cr / torch.where(eqc, ones, maxc)
+            div = torch.where(eqc, ones, cr)
+            rc, gc, bc = (maxc - r) / div, (maxc - g) / div, (maxc - b) / div
+            hr = (maxc == r) * (bc - gc)
+            hg = ((maxc == g) & (maxc != r)) * (2.0 + rc - bc)
+            hb = ((maxc != g) & (maxc != r)) * (4.0 + gc - rc)
+            h = torch.fmod((hr + hg + hb) / 6.0 + 1.0, 1.0)
+            return torch.stack((h, s, maxc), dim=-3)
+
+        @staticmethod
+        def _hsv2rgb(img):
+            h, s, v = img.unbind(dim=-3)
+            i = torch.floor(h * 6.0)
+            f = (h * 6.0) - i
+            i = i.to(torch.int32) % 6
+            p = torch.clamp(v * (1.0 - s), 0.0, 1.0)
+            q = torch.clamp(v * (1.0 - (s * f)), 0.0, 1.0)
+            t = torch.clamp(v * (1.0 - (s * (1.0 - f))), 0.0, 1.0)
+            mask = i.unsqueeze(-3) == torch.arange(6).view(-1, 1, 1)
+            a1 = torch.stack((v, q, p, p, t, v), dim=-3)
+            a2 = torch.stack((t, v, v, q, p, p), dim=-3)
+            a3 = torch.stack((p, p, t, v, v, q), dim=-3)
+            a4 = torch.stack((a1, a2, a3), dim=-4)
+            return torch.einsum("...ijk,...xijk->...xjk", mask.to(img.dtype), a4)
+
+        def __call__(self, img):
+            order = torch.randperm(4)
+            rec = dict(order=order.numpy().astype(np.int32), contrast=1.0, saturation=1.0, hue=0.0)
+            for fn in order.tolist():
+                if fn == 1:
+                    c = float(torch.tensor(1.0).uniform_(self.contrast[0], self.contrast[1]).item())
+                    rec["contrast"] = c
+                    mean = torch.mean(self._gray(img), dim=(-3, -2, -1), keepdim=True)
+                    img = self._blend(img, mean, c)
+                elif fn == 2:
+                    s = float(torch.tensor(1.0).uniform_(self.saturation[0], self.saturation[1]).item())
+                    rec["saturation"] = s
+                    img = self._blend(img, self._gray(img), s)
+                elif fn == 3:
+                    hf = float(torch.tensor(1.0).uniform_(self.hue[0], self.hue[1]).item())
+                    rec["hue"] = hf
+                    hsv = self._rgb2hsv(img)
+                    h, s_, v = hsv.unbind(dim=-3)
+                    h = (h + hf) % 1.0
+                    img = self._hsv2rgb(torch.stack((h, s_, v), dim=-3))
+            _ColorJitter.last = rec
+            return img
+
+    sys.modules["torchvision.transforms"].ColorJitter = _ColorJitter
+    return RandomCrop, _ColorJitter
+
+
+def make_aug():
+    RandomCrop, CJ = _install_stubs()
+    import augmentations as ref_aug
+
+    B = 2
+    out = {}
+    obs_u8 = gi.obs_u8(seed=11, B=B)
+    x = torch.from_numpy(obs_u8.astype(np.float32))
+
+    # random_shift (augmentations.py:378-382) -- F.pad half is the reference's; crop is the stand-in
+    torch.manual_seed(101)
+    y = ref_aug.random_shift(x.clone(), pad=4)
+    oy, ox = RandomCrop.last
+    out["shift_out_u8"] = y.numpy().astype(np.uint8)
+    assert np.array_equal(out["shift_out_u8"].astype(np.float32), y.numpy())
+    out["shift_oy"], out["shift_ox"] = oy, ox
+
+    # random_conv (augmentations.py:265-274): per-sample torch.randn(3,3,3,3) on the default generator
+    torch.manual_seed(202)
+    y = ref_aug.random_conv(x.clone())
+    torch.manual_seed(202)
+    w = torch.stack([torch.randn(3, 3, 3, 3) for _ in range(B)])
+    out["conv_out"] = y.numpy()
+    out["conv_weights"] = w.numpy()
+
+    # random_overlay (augmentations.py:253-262) with a seeded U[0,1) image batch in place of the dataset
+    ov = torch.from_numpy(gi.overlay_imgs(seed=12, B=B))
+    ref_aug.dataloader = object()
+    ref_aug._get_data_batch = lambda batch_size: ov.clone()
+    y = ref_aug.random_overlay(x.clone())
+    out["overlay_out"] = y.numpy()
+
+    # color_jitter (augmentations.py:225-237), literal ("compat") path on 0..255 floats
+    torch.manual_seed(303)
+    np.random.seed(303)
+    xin = x.clone()
+    y = ref_aug.color_jitter(xin, p=1)
+    assert y.data_ptr() == xin.data_ptr()  # in place
+    np.random.seed(303)
+    idx = np.random.randint(0, B, int(1 * B * 3))
+    rec = CJ.last
+    out["jitter_out"] = y.numpy()
+    out["jitter_idx"] = idx.astype(np.int32)
+    out["jitter_order"] = rec["order"]
+    out["jitter_params"] = np.array([rec["contrast"], rec["saturation"], rec["hue"]], dtype=np.float64)
+
+    # same call on [0,1]-scaled input: exercises the non-degenerate arithmetic ("sane" mode, scale=255)
+    # on image-like frames (gray patches, saturated primaries: every rgb2hsv branch)
+    torch.manual_seed(808)
+    np.random.seed(808)
+    xin = torch.from_numpy(gi.smooth_obs_u8(seed=13, B=B).astype(np.float32)) / 255.0
+    y = ref_aug.color_jitter(xin, p=1)
+    np.random.seed(808)
+    idx = np.random.randint(0, B, int(1 * B * 3))
+    rec = CJ.last
+    out["jitter01_out"] = y.numpy()
+    out["jitter01_idx"] = idx.astype(np.int32)
+    out["jitter01_order"] = rec["order"]
+    out["jitter01_params"] = np.array([rec["contrast"], rec["saturation"], rec["hue"]], dtype=np.float64)
+
+    np.savez_compressed(os.path.join(HERE, "aug_golden.npz"), **out)
+    print("wrote aug_golden.npz", {k: v.shape for k, v in out.items()})
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what in ("aug", "all"):
+        make_aug()
+    if what in ("nets", "update", "all"):
+        import make_golden_sac
+        make_golden_sac.main(what)
