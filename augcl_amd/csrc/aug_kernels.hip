@@ -562,9 +562,10 @@ static int shift_dispatch(const TIn *in, TOut *out, int B, int C, int H, int W, 
                           const int32_t *ox, uint64_t seed, uint64_t offset, int sample0, augcl_stream_t stream,
                           const char *name)
 {
-    AUGCL_REQUIRE(in && out, "%s: null tensor", name);
     AUGCL_REQUIRE(B >= 0 && C > 0 && H > 0 && W > 0 && pad >= 0, "%s: bad shape B=%d C=%d H=%d W=%d pad=%d", name, B,
                   C, H, W, pad);
+    if (B == 0) return AUGCL_OK; // an empty batch has no storage: nothing to check, nothing to do
+    AUGCL_REQUIRE(in && out, "%s: null tensor", name);
     AUGCL_REQUIRE((oy == nullptr) == (ox == nullptr), "%s: oy/ox must both be given or both NULL", name);
     AUGCL_REQUIRE((const void *)in != (const void *)out, "%s: in-place not supported", name);
     if (B == 0) return AUGCL_OK;
@@ -589,8 +590,9 @@ static int shift_conv_dispatch(const TIn *in, float *out_shift, float *out_aug, 
                                int pad, const int32_t *oy, const int32_t *ox, const float *weights, uint64_t seed,
                                uint64_t offset, int sample0, augcl_stream_t stream, const char *name)
 {
-    AUGCL_REQUIRE(in && (out_shift || out_aug), "%s: null tensor", name);
     AUGCL_REQUIRE(B >= 0 && frames > 0 && pad >= 0, "%s: bad shape", name);
+    if (B == 0) return AUGCL_OK;
+    AUGCL_REQUIRE(in && (out_shift || out_aug), "%s: null tensor", name);
     AUGCL_REQUIRE((oy == nullptr) == (ox == nullptr), "%s: oy/ox must both be given or both NULL", name);
     AUGCL_REQUIRE(fast_shape(H, W), "%s: only 84x84 / 100x100 frames are supported (got %dx%d)", name, H, W);
     AUGCL_REQUIRE(aligned16(in) && aligned16(out_shift) && aligned16(out_aug), "%s: tensors must be 16-byte aligned",
@@ -633,10 +635,10 @@ int augcl_random_conv_f32(const float *in, float *out, int B, int frames, int H,
                           uint64_t seed, uint64_t offset, int sample0, augcl_stream_t stream)
 {
     const char *name = "augcl_random_conv_f32";
-    AUGCL_REQUIRE(in && out, "%s: null tensor", name);
     AUGCL_REQUIRE(B >= 0 && frames > 0 && H > 0 && W > 0, "%s: bad shape", name);
-    AUGCL_REQUIRE(in != out, "%s: in-place not supported", name);
     if (B == 0) return AUGCL_OK;
+    AUGCL_REQUIRE(in && out, "%s: null tensor", name);
+    AUGCL_REQUIRE(in != out, "%s: in-place not supported", name);
     hipStream_t s = as_stream(stream);
     const bool vec_ok = fast_shape(H, W) && aligned16(in) && aligned16(out);
     if (vec_ok && H == 84)
@@ -673,9 +675,9 @@ int augcl_random_overlay_f32(const float *in, const float *overlay, float *out, 
                              float alpha, augcl_stream_t stream)
 {
     const char *name = "augcl_random_overlay_f32";
-    AUGCL_REQUIRE(in && overlay && out, "%s: null tensor", name);
     AUGCL_REQUIRE(B >= 0 && frames > 0 && H > 0 && W > 0, "%s: bad shape", name);
     if (B == 0) return AUGCL_OK;
+    AUGCL_REQUIRE(in && overlay && out, "%s: null tensor", name);
     hipStream_t s = as_stream(stream);
     const float om = (float)(1.0 - (double)alpha);
     const int plane = 3 * H * W;
@@ -696,8 +698,8 @@ int augcl_color_jitter_f32(float *inout, int B, int frames, int H, int W, const 
                            float scale, augcl_stream_t stream)
 {
     const char *name = "augcl_color_jitter_f32";
-    AUGCL_REQUIRE(inout && order_host, "%s: null argument", name);
     AUGCL_REQUIRE(B >= 0 && frames > 0 && H > 0 && W > 0 && n_idx >= 0, "%s: bad shape", name);
+    AUGCL_REQUIRE((inout || B == 0) && order_host, "%s: null argument", name);
     AUGCL_REQUIRE(idx != nullptr || n_idx == 0, "%s: n_idx > 0 with idx == NULL", name);
     AUGCL_REQUIRE(scale > 0.0f && bound > 0.0f, "%s: scale and bound must be positive", name);
     JitterParams p;
@@ -720,16 +722,18 @@ int augcl_color_jitter_f32(float *inout, int B, int frames, int H, int W, const 
     constexpr int NT = 1024;
     const size_t smem = (size_t)3 * n * sizeof(float) + (NT / 64) * sizeof(double);
     AUGCL_REQUIRE((n & 3) == 0 && aligned16(inout), "%s: H*W must be a multiple of 4 and the tensor 16-B aligned", name);
-    if (smem > 160 * 1024)
+    if (smem > 160 * 1024 - 512)
         return augcl::fail(AUGCL_E_UNSUPPORTED, "%s: a %dx%d RGB frame (%zu B) exceeds the 160 KiB LDS of a CU", name, H,
                            W, smem);
     if (B == 0 || (idx != nullptr && n_idx == 0)) return AUGCL_OK;
-    static bool attr_set = false; // idempotent; a benign race at worst repeats the call
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_color_jitter<NT>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return augcl::fail(AUGCL_E_LAUNCH, "%s: cannot raise dynamic LDS limit", name);
-        attr_set = true;
+    static size_t attr_max = 48 * 1024; // idempotent; a benign race at worst repeats the call
+    if (smem > attr_max) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_color_jitter<NT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess)
+            return augcl::fail(AUGCL_E_LAUNCH, "%s: cannot raise dynamic LDS limit to %zu: %s", name, smem,
+                               hipGetErrorString(e));
+        attr_max = smem;
     }
     hipLaunchKernelGGL((k_color_jitter<NT>), dim3(B * frames), dim3(NT), smem, as_stream(stream), inout, n, idx, n_idx,
                        p);
