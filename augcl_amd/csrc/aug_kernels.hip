@@ -13,6 +13,8 @@
 
 namespace augcl {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // per-sample crop displacement (dy,dx) = (oy-pad, ox-pad): uniform per workgroup
@@ -154,13 +156,30 @@ __global__ __launch_bounds__(256) void k_random_shift_generic(const TIn *__restr
 template <int H, int W, int R>
 struct ConvSmem {
     float tile[3][R + 2][W]; // x/255, rows y0-1 .. y0+R (row-clamped = replicate pad)
-    float w[84];             // 81 weights [o][i][ky][kx] (+3 pad)
+    f32x2 w[84];             // 81 weights [o][i][ky][kx] (+3 pad), each stored twice: one aligned
+                             // ds_read_b64 yields the (w,w) operand of v_pk_fma_f32 with no v_mov
 };
+
+// x / 255.0f, correctly rounded, in 3 VALU ops instead of the ~10 of the IEEE division
+// sequence: q = x*r; q' = fma(fma(-q,255,x), r, q) with r = RN(1/255).  Verified EXHAUSTIVELY
+// (all 2^31 non-negative finite f32, denormals included; tests/test_div255.c) to equal the IEEE
+// quotient bit for bit; +-inf would turn into NaN in the residual, so it is passed through.
+__device__ __forceinline__ float div255(float x)
+{
+    const float r = 1.0f / 255.0f;
+    const float q = x * r;
+    const float e = __builtin_fmaf(-q, 255.0f, x);
+    const float y = __builtin_fmaf(e, r, q);
+    return __builtin_isinf(x) ? x : y;
+}
 
 __device__ __forceinline__ float sigmoid255(float a)
 {
-    // torch.sigmoid = 1/(1+exp(-a)); v_rcp_f32 is 1 ulp, far inside the 1e-5 budget
-    const float e = expf(-a);
+    // torch.sigmoid = 1/(1+exp(-a)).  exp(-a) = 2^(-a*log2 e) on the v_exp_f32 unit: the rounding of
+    // the product perturbs the result by <= |a| * 2^-24 relative, i.e. s(1-s)|a| * 6e-8 <= 1.4e-8 on
+    // the sigmoid (x255: < 4e-6), and v_exp_f32 / v_rcp_f32 are 1 ulp: all far inside the 1e-5 budget
+    // and an order of magnitude below the conv's own summation-order noise.
+    const float e = __builtin_amdgcn_exp2f(a * -1.4426950408889634f);
     return __builtin_amdgcn_rcpf(1.0f + e) * 255.0f;
 }
 
@@ -170,17 +189,23 @@ __device__ __forceinline__ void conv_stage_weights(ConvSmem<H, W, R> &sm, const 
 {
     const int tid = threadIdx.x;
     if (weights != nullptr) {
-        if (tid < 81) sm.w[tid] = weights[(size_t)b * 81 + tid];
+        if (tid < 81) {
+            const float wv = weights[(size_t)b * 81 + tid];
+            sm.w[tid] = f32x2{wv, wv};
+        }
     } else if (tid < 21) {
         float w4[4];
         philox_conv_weights4(seed, offset, (uint32_t)gsample, tid, w4);
-        sm.w[4 * tid + 0] = w4[0];
-        sm.w[4 * tid + 1] = w4[1];
-        sm.w[4 * tid + 2] = w4[2];
-        sm.w[4 * tid + 3] = w4[3];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sm.w[4 * tid + k] = f32x2{w4[k], w4[k]};
     }
 }
 
+// one thread = 4 consecutive pixels of one row, all 3 output channels.  FMAs are issued as
+// v_pk_fma_f32 on the pixel pairs (0,1) and (2,3): for tap kx the operand pairs are
+// (v[kx],v[kx+1]) and (v[kx+2],v[kx+3]) of the 6-wide window v = [left, m0..m3, right]; the even
+// pairs come from ds_read2_b32, the odd pairs are the two halves of one aligned ds_read_b128.
+// Accumulation order per output: i, ky, kx ascending (same as oracle/aug_oracle.c).
 template <int H, int W, int R>
 __device__ __forceinline__ void conv_compute_store(const ConvSmem<H, W, R> &sm, float *__restrict__ out_frame,
                                                    int y0)
@@ -193,36 +218,39 @@ __device__ __forceinline__ void conv_compute_store(const ConvSmem<H, W, R> &sm, 
     const int xl = x4 > 0 ? x4 - 1 : 0;
     const int xr = x4 + 4 < W ? x4 + 4 : W - 1;
 
-    float v[3][3][6];
+    f32x2 acc[3][2];
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int o = 0; o < 3; ++o) acc[o][0] = acc[o][1] = f32x2{0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        f32x2 pe[3][3], po[3][2]; // even pairs (v0v1,v2v3,v4v5), odd pairs (v1v2,v3v4)
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
             const float *row = sm.tile[i][ry + ky];
             const float4 m = *reinterpret_cast<const float4 *>(row + x4);
-            v[i][ky][0] = row[xl];
-            v[i][ky][1] = m.x;
-            v[i][ky][2] = m.y;
-            v[i][ky][3] = m.z;
-            v[i][ky][4] = m.w;
-            v[i][ky][5] = row[xr];
+            po[ky][0] = f32x2{m.x, m.y};
+            po[ky][1] = f32x2{m.z, m.w};
+            pe[ky][0] = f32x2{row[xl], m.x};
+            pe[ky][1] = f32x2{m.y, m.z};
+            pe[ky][2] = f32x2{m.w, row[xr]};
         }
 #pragma unroll
-    for (int o = 0; o < 3; ++o) {
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+            for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const float wv = sm.w[((o * 3 + i) * 3 + ky) * 3 + kx];
-                    a0 = __builtin_fmaf(wv, v[i][ky][kx + 0], a0);
-                    a1 = __builtin_fmaf(wv, v[i][ky][kx + 1], a1);
-                    a2 = __builtin_fmaf(wv, v[i][ky][kx + 2], a2);
-                    a3 = __builtin_fmaf(wv, v[i][ky][kx + 3], a3);
+                for (int o = 0; o < 3; ++o) {
+                    const f32x2 w2 = sm.w[((o * 3 + i) * 3 + ky) * 3 + kx];
+                    const f32x2 in01 = (kx == 1) ? po[ky][0] : pe[ky][kx / 2];
+                    const f32x2 in23 = (kx == 1) ? po[ky][1] : pe[ky][kx / 2 + 1];
+                    acc[o][0] = __builtin_elementwise_fma(w2, in01, acc[o][0]);
+                    acc[o][1] = __builtin_elementwise_fma(w2, in23, acc[o][1]);
                 }
-        const float4 res = make_float4(sigmoid255(a0), sigmoid255(a1), sigmoid255(a2), sigmoid255(a3));
+    }
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        const float4 res = make_float4(sigmoid255(acc[o][0].x), sigmoid255(acc[o][0].y), sigmoid255(acc[o][1].x),
+                                       sigmoid255(acc[o][1].y));
         *reinterpret_cast<float4 *>(out_frame + ((size_t)o * H + (y0 + ry)) * W + x4) = res;
     }
 }
@@ -249,10 +277,10 @@ __global__ __launch_bounds__(256) void k_random_conv(const float *__restrict__ i
         const int x4 = (rem - rr * W4) * 4;
         const int sy = clampi(y0 - 1 + rr, 0, H - 1);
         float4 q = *reinterpret_cast<const float4 *>(src + ((size_t)ch * H + sy) * W + x4);
-        q.x = q.x / 255.0f;
-        q.y = q.y / 255.0f;
-        q.z = q.z / 255.0f;
-        q.w = q.w / 255.0f;
+        q.x = div255(q.x);
+        q.y = div255(q.y);
+        q.z = div255(q.z);
+        q.w = div255(q.w);
         *reinterpret_cast<float4 *>(&sm.tile[ch][rr][x4]) = q;
     }
     __syncthreads();
@@ -296,10 +324,10 @@ __global__ __launch_bounds__(256) void k_shift_conv(const TIn *__restrict__ in, 
                 load_shifted4_u8<W>(reinterpret_cast<const uint8_t *>(src) + ((size_t)ch * H + sy) * W, x4, dx, r));
         if (out_shift != nullptr && ys >= y0 && ys < y0 + R)
             *reinterpret_cast<float4 *>(out_shift + ((size_t)(fidx * 3 + ch) * H + ys) * W + x4) = q;
-        q.x = q.x / 255.0f;
-        q.y = q.y / 255.0f;
-        q.z = q.z / 255.0f;
-        q.w = q.w / 255.0f;
+        q.x = div255(q.x);
+        q.y = div255(q.y);
+        q.z = div255(q.z);
+        q.w = div255(q.w);
         *reinterpret_cast<float4 *>(&sm.tile[ch][rr][x4]) = q;
     }
     if (out_aug == nullptr) return;
@@ -361,10 +389,10 @@ __global__ __launch_bounds__(256) void k_random_overlay(const float *__restrict_
         const size_t idx = ((size_t)b * frames + f) * plane4 + q;
         const float4 x = reinterpret_cast<const float4 *>(in)[idx];
         float4 o;
-        o.x = (one_minus_alpha * (x.x / 255.0f) + c.x) * 255.0f;
-        o.y = (one_minus_alpha * (x.y / 255.0f) + c.y) * 255.0f;
-        o.z = (one_minus_alpha * (x.z / 255.0f) + c.z) * 255.0f;
-        o.w = (one_minus_alpha * (x.w / 255.0f) + c.w) * 255.0f;
+        o.x = (one_minus_alpha * div255(x.x) + c.x) * 255.0f;
+        o.y = (one_minus_alpha * div255(x.y) + c.y) * 255.0f;
+        o.z = (one_minus_alpha * div255(x.z) + c.z) * 255.0f;
+        o.w = (one_minus_alpha * div255(x.w) + c.w) * 255.0f;
         reinterpret_cast<float4 *>(out)[idx] = o;
     }
 }

@@ -1,0 +1,203 @@
+// tools/kbench.hip -- developer microbenchmark for kernel VARIANTS (not part of the product).
+// Build:  hipcc -O3 --offload-arch=gfx950 -std=c++17 -ffp-contract=off -Iinclude tools/kbench.hip \
+//               augcl_amd/csrc/capi_core.cpp -x hip -o tools/kbench
+// It #includes the product kernels and times experimental variants against them on a ring of
+// batches larger than the 256 MiB Infinity Cache, interleaved rounds in ONE process.
+#include "../augcl_amd/csrc/aug_kernels.hip"
+
+#include <algorithm>
+#include <functional>
+#include <string>
+#include <vector>
+
+using namespace augcl;
+
+#define CK(x)                                                                    \
+    do {                                                                         \
+        hipError_t e_ = (x);                                                     \
+        if (e_ != hipSuccess) {                                                  \
+            printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+            exit(1);                                                             \
+        }                                                                        \
+    } while (0)
+
+// ---------------------------------------------------------------- experimental shift variants
+// S1: one block per third of a plane (28 rows): 3x more, shorter blocks -> smaller tail
+template <int H, int W, int PARTS>
+__global__ __launch_bounds__(256) void k_shift_parts(const float *__restrict__ in, float *__restrict__ out, int C,
+                                                     int pad, const int32_t *__restrict__ oy,
+                                                     const int32_t *__restrict__ ox)
+{
+    constexpr int W4 = W / 4;
+    constexpr int RP = H / PARTS;
+    constexpr int N4 = RP * W4;
+    const int plane = blockIdx.x / PARTS;
+    const int part = blockIdx.x - plane * PARTS;
+    const int b = plane / C;
+    int dy, dx;
+    sample_shift(oy, ox, 0, 0, b, b, pad, dy, dx);
+    const int r = dx & 3;
+    const float *__restrict__ src = in + (size_t)plane * (H * W);
+    float *__restrict__ dst = out + (size_t)plane * (H * W);
+#pragma unroll
+    for (int j = threadIdx.x; j < N4; j += 256) {
+        const int yy = j / W4;
+        const int y = part * RP + yy;
+        const int x4 = (j - yy * W4) * 4;
+        const int sy = clampi(y + dy, 0, H - 1);
+        const float4 v = load_shifted4<W>(src + sy * W, x4, dx, r);
+        *reinterpret_cast<float4 *>(dst + y * W + x4) = v;
+    }
+}
+
+// S2: single UNALIGNED float4 load (dword-aligned address) + per-lane border select
+template <int W>
+__device__ __forceinline__ float4 load_shifted4_unaligned(const float *__restrict__ row, int x4, int dx)
+{
+    const int s0 = x4 + dx;
+    const int base = clampi(s0, 0, W - 4);
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+    const f4u V = *reinterpret_cast<const f4u *>(row + base);
+    const int d = s0 - base;
+    float4 o = make_float4(V.x, V.y, V.z, V.w);
+    if (d != 0) {
+        float vv[4] = {V.x, V.y, V.z, V.w};
+        float oo[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int idx = clampi(d + k, 0, 3);
+            oo[k] = idx == 0 ? vv[0] : idx == 1 ? vv[1] : idx == 2 ? vv[2] : vv[3];
+        }
+        o = make_float4(oo[0], oo[1], oo[2], oo[3]);
+    }
+    return o;
+}
+
+template <int H, int W, int PARTS>
+__global__ __launch_bounds__(256) void k_shift_unaligned(const float *__restrict__ in, float *__restrict__ out,
+                                                         int C, int pad, const int32_t *__restrict__ oy,
+                                                         const int32_t *__restrict__ ox)
+{
+    constexpr int W4 = W / 4;
+    constexpr int RP = H / PARTS;
+    constexpr int N4 = RP * W4;
+    const int plane = blockIdx.x / PARTS;
+    const int part = blockIdx.x - plane * PARTS;
+    const int b = plane / C;
+    int dy, dx;
+    sample_shift(oy, ox, 0, 0, b, b, pad, dy, dx);
+    const float *__restrict__ src = in + (size_t)plane * (H * W);
+    float *__restrict__ dst = out + (size_t)plane * (H * W);
+#pragma unroll
+    for (int j = threadIdx.x; j < N4; j += 256) {
+        const int yy = j / W4;
+        const int y = part * RP + yy;
+        const int x4 = (j - yy * W4) * 4;
+        const int sy = clampi(y + dy, 0, H - 1);
+        const float4 v = load_shifted4_unaligned<W>(src + sy * W, x4, dx);
+        *reinterpret_cast<float4 *>(dst + y * W + x4) = v;
+    }
+}
+
+// S3: plain copy (upper bound for this access shape): same decomposition, no shift
+template <int H, int W, int PARTS>
+__global__ __launch_bounds__(256) void k_copy_parts(const float *__restrict__ in, float *__restrict__ out)
+{
+    constexpr int N4 = H * W / 4 / PARTS;
+    const float4 *__restrict__ src = reinterpret_cast<const float4 *>(in) + (size_t)blockIdx.x * N4;
+    float4 *__restrict__ dst = reinterpret_cast<float4 *>(out) + (size_t)blockIdx.x * N4;
+#pragma unroll
+    for (int j = threadIdx.x; j < N4; j += 256) dst[j] = src[j];
+}
+
+// S4: grid-stride copy with 2048 blocks (persistent-style)
+__global__ __launch_bounds__(256) void k_copy_gs(const float4 *__restrict__ in, float4 *__restrict__ out, size_t n4)
+{
+    for (size_t j = (size_t)blockIdx.x * 256 + threadIdx.x; j < n4; j += (size_t)gridDim.x * 256) out[j] = in[j];
+}
+
+struct Variant {
+    std::string name;
+    double bytes;
+    std::function<void(int)> launch; // arg = ring slot
+};
+
+int main(int argc, char **argv)
+{
+    const int B = argc > 1 ? atoi(argv[1]) : 256;
+    const int RING = 8, ROUNDS = 5, ITERS = 100;
+    const size_t n = (size_t)B * 9 * 84 * 84;
+    std::vector<float *> fin(RING), fout(RING), fout2(2);
+    std::vector<uint8_t *> uin(RING);
+    std::vector<float> h(n);
+    for (size_t i = 0; i < n; ++i) h[i] = (float)((i * 2654435761u >> 13) & 255);
+    std::vector<uint8_t> hu(n);
+    for (size_t i = 0; i < n; ++i) hu[i] = (uint8_t)h[i];
+    for (int k = 0; k < RING; ++k) {
+        CK(hipMalloc(&fin[k], n * 4));
+        CK(hipMalloc(&fout[k], n * 4));
+        CK(hipMalloc(&uin[k], n));
+        CK(hipMemcpy(fin[k], h.data(), n * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(uin[k], hu.data(), n, hipMemcpyHostToDevice));
+    }
+    for (int k = 0; k < 2; ++k) CK(hipMalloc(&fout2[k], n * 4));
+    std::vector<int32_t> hoy(B), hox(B);
+    for (int b = 0; b < B; ++b) { hoy[b] = (b * 7 + 3) % 9; hox[b] = (b * 5 + 1) % 9; }
+    int32_t *oy, *ox;
+    CK(hipMalloc(&oy, B * 4)); CK(hipMalloc(&ox, B * 4));
+    CK(hipMemcpy(oy, hoy.data(), B * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(ox, hox.data(), B * 4, hipMemcpyHostToDevice));
+    std::vector<float> hw(B * 81);
+    for (int i = 0; i < B * 81; ++i) hw[i] = (float)((i * 40503u >> 7) & 1023) / 512.f - 1.f;
+    float *w;
+    CK(hipMalloc(&w, B * 81 * 4));
+    CK(hipMemcpy(w, hw.data(), B * 81 * 4, hipMemcpyHostToDevice));
+    float *ov;
+    CK(hipMalloc(&ov, (size_t)B * 3 * 84 * 84 * 4));
+    CK(hipMemset(ov, 0, (size_t)B * 3 * 84 * 84 * 4));
+
+    const double f2f = 2.0 * n * 4;
+    std::vector<Variant> vs;
+    vs.push_back({"shift_f32 product", f2f, [&](int k) { augcl_random_shift_f32(fin[k], fout[k], B, 9, 84, 84, 4, oy, ox, 0, 0, 0, 0); }});
+    vs.push_back({"shift_f32 parts=3", f2f, [&](int k) { hipLaunchKernelGGL((k_shift_parts<84, 84, 3>), dim3(B * 9 * 3), dim3(256), 0, 0, fin[k], fout[k], 9, 4, oy, ox); }});
+    vs.push_back({"shift_f32 parts=7", f2f, [&](int k) { hipLaunchKernelGGL((k_shift_parts<84, 84, 7>), dim3(B * 9 * 7), dim3(256), 0, 0, fin[k], fout[k], 9, 4, oy, ox); }});
+    vs.push_back({"shift_f32 unaligned parts=3", f2f, [&](int k) { hipLaunchKernelGGL((k_shift_unaligned<84, 84, 3>), dim3(B * 9 * 3), dim3(256), 0, 0, fin[k], fout[k], 9, 4, oy, ox); }});
+    vs.push_back({"shift_f32 unaligned parts=7", f2f, [&](int k) { hipLaunchKernelGGL((k_shift_unaligned<84, 84, 7>), dim3(B * 9 * 7), dim3(256), 0, 0, fin[k], fout[k], 9, 4, oy, ox); }});
+    vs.push_back({"copy parts=1", f2f, [&](int k) { hipLaunchKernelGGL((k_copy_parts<84, 84, 1>), dim3(B * 9), dim3(256), 0, 0, fin[k], fout[k]); }});
+    vs.push_back({"copy parts=3", f2f, [&](int k) { hipLaunchKernelGGL((k_copy_parts<84, 84, 3>), dim3(B * 9 * 3), dim3(256), 0, 0, fin[k], fout[k]); }});
+    vs.push_back({"copy parts=7", f2f, [&](int k) { hipLaunchKernelGGL((k_copy_parts<84, 84, 7>), dim3(B * 9 * 7), dim3(256), 0, 0, fin[k], fout[k]); }});
+    vs.push_back({"copy gridstride 2048", f2f, [&](int k) { hipLaunchKernelGGL(k_copy_gs, dim3(2048), dim3(256), 0, 0, (const float4 *)fin[k], (float4 *)fout[k], n / 4); }});
+    vs.push_back({"copy gridstride 4096", f2f, [&](int k) { hipLaunchKernelGGL(k_copy_gs, dim3(4096), dim3(256), 0, 0, (const float4 *)fin[k], (float4 *)fout[k], n / 4); }});
+    vs.push_back({"hipMemcpyAsync d2d", f2f, [&](int k) { CK(hipMemcpyAsync(fout[k], fin[k], n * 4, hipMemcpyDeviceToDevice, 0)); }});
+    vs.push_back({"conv_f32 product", f2f, [&](int k) { augcl_random_conv_f32(fin[k], fout[k], B, 3, 84, 84, w, 0, 0, 0, 0); }});
+    vs.push_back({"shift_conv_u8 product", (double)n * 9, [&](int k) { augcl_shift_conv_u8_f32(uin[k], fout[k], fout2[k & 1], B, 3, 84, 84, 4, oy, ox, w, 0, 0, 0, 0); }});
+    vs.push_back({"shift_u8_f32 product", (double)n * 5, [&](int k) { augcl_random_shift_u8_f32(uin[k], fout[k], B, 9, 84, 84, 4, oy, ox, 0, 0, 0, 0); }});
+    vs.push_back({"overlay product", f2f + (double)B * 3 * 84 * 84 * 4, [&](int k) { augcl_random_overlay_f32(fin[k], ov, fout[k], B, 3, 84, 84, 0.5f, 0); }});
+#ifdef KBENCH_EXTRA
+#include KBENCH_EXTRA
+#endif
+
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    std::vector<std::vector<double>> us(vs.size());
+    for (int r = 0; r < ROUNDS; ++r)
+        for (size_t v = 0; v < vs.size(); ++v) {
+            for (int i = 0; i < 10; ++i) vs[v].launch(i % RING);
+            CK(hipEventRecord(e0, 0));
+            for (int i = 0; i < ITERS; ++i) vs[v].launch(i % RING);
+            CK(hipEventRecord(e1, 0));
+            CK(hipEventSynchronize(e1));
+            CK(hipGetLastError());
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            us[v].push_back(ms * 1000.0 / ITERS);
+        }
+    printf("B=%d  (%.1f MB in + out per launch for f32->f32)\n", B, f2f / 1e6);
+    printf("%-34s %9s %9s %9s %8s\n", "variant", "min us", "med us", "GB/s(med)", "Mobs/s");
+    for (size_t v = 0; v < vs.size(); ++v) {
+        std::sort(us[v].begin(), us[v].end());
+        const double med = us[v][us[v].size() / 2];
+        printf("%-34s %9.2f %9.2f %9.0f %8.2f\n", vs[v].name.c_str(), us[v][0], med, vs[v].bytes / med / 1e3, B / med);
+    }
+    return 0;
+}
