@@ -33,95 +33,102 @@ __device__ __forceinline__ void sample_shift(const int32_t *__restrict__ oy, con
     dx = __builtin_amdgcn_readfirstlane(x - pad);
 }
 
-// ---- 4 consecutive shifted pixels of one source row -------------------------------------
-// f32 source: two aligned float4 loads + a wave-uniform rotate (r = dx & 3); rows are 16-B
-// aligned (W % 4 == 0).  Border quads (source column clamped) take 4 clamped scalar loads.
-template <int W>
-__device__ __forceinline__ float4 load_shifted4(const float *__restrict__ row, int x4, int dx, int r)
-{
-    const int s0 = x4 + dx;
-    float4 o;
-    if (s0 >= 0 && s0 + 3 <= W - 1) {
-        const int a0 = s0 - r;
-        const float4 A = *reinterpret_cast<const float4 *>(row + a0);
-        if (r == 0) {
-            o = A;
-        } else {
-            const float4 Bv = *reinterpret_cast<const float4 *>(row + a0 + 4);
-            if (r == 1) o = make_float4(A.y, A.z, A.w, Bv.x);
-            else if (r == 2) o = make_float4(A.z, A.w, Bv.x, Bv.y);
-            else o = make_float4(A.w, Bv.x, Bv.y, Bv.z);
-        }
-    } else {
-        o.x = row[clampi(s0, 0, W - 1)];
-        o.y = row[clampi(s0 + 1, 0, W - 1)];
-        o.z = row[clampi(s0 + 2, 0, W - 1)];
-        o.w = row[clampi(s0 + 3, 0, W - 1)];
-    }
-    return o;
-}
-
-// u8 source: two aligned dword loads + v_alignbyte_b32; returns the 4 bytes packed
-template <int W>
-__device__ __forceinline__ uint32_t load_shifted4_u8(const uint8_t *__restrict__ row, int x4, int dx, int r)
-{
-    const int s0 = x4 + dx;
-    uint32_t v;
-    if (s0 >= 0 && s0 + 3 <= W - 1) {
-        const int a0 = s0 - r;
-        const uint32_t lo = *reinterpret_cast<const uint32_t *>(row + a0);
-        if (r == 0) {
-            v = lo;
-        } else {
-            const uint32_t hi = *reinterpret_cast<const uint32_t *>(row + a0 + 4);
-            v = __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)r);
-        }
-    } else {
-        v = (uint32_t)row[clampi(s0, 0, W - 1)] | ((uint32_t)row[clampi(s0 + 1, 0, W - 1)] << 8) |
-            ((uint32_t)row[clampi(s0 + 2, 0, W - 1)] << 16) | ((uint32_t)row[clampi(s0 + 3, 0, W - 1)] << 24);
-    }
-    return v;
-}
-
 __device__ __forceinline__ float4 unpack_u8x4(uint32_t v)
 {
     return make_float4((float)(v & 0xffu), (float)((v >> 8) & 0xffu), (float)((v >> 16) & 0xffu), (float)(v >> 24));
 }
 
+// ---- staging: 4 consecutive pixels of the (optionally shifted) source row ---------------------
+// ONE load per quad: global_load_dwordx4 / global_load_dword tolerate dword / byte alignment on
+// gfx950, and a wave's 64 lanes still sweep one contiguous span, so the x-shift costs no second
+// load and no rotate (measured: 5.06 TB/s vs 4.69 for two aligned loads + rotate, vs 5.4 plain
+// copy).  The start is clamped into the row, base = clamp(x4+dx, 0, W-4); only quads that stick out
+// of the row (d = x4+dx-base != 0: the first / last quad of a row) need the per-lane
+// replicate-select, out[k] = V[clamp(d+k, 0, 3)].
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint32_t u32u __attribute__((aligned(1)));
+
+template <int W, typename TIn>
+struct Quad;
+
+template <int W>
+struct Quad<W, float> {
+    f32x4u v;
+    __device__ __forceinline__ void load(const float *__restrict__ row, int base)
+    {
+        v = *reinterpret_cast<const f32x4u *>(row + base);
+    }
+    __device__ __forceinline__ float4 get(int d) const
+    {
+        float4 o = make_float4(v.x, v.y, v.z, v.w);
+        if (d != 0) {
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+            float oo[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int idx = clampi(d + k, 0, 3);
+                oo[k] = idx == 0 ? vv[0] : idx == 1 ? vv[1] : idx == 2 ? vv[2] : vv[3];
+            }
+            o = make_float4(oo[0], oo[1], oo[2], oo[3]);
+        }
+        return o;
+    }
+};
+
+template <int W>
+struct Quad<W, uint8_t> {
+    uint32_t v;
+    __device__ __forceinline__ void load(const uint8_t *__restrict__ row, int base)
+    {
+        v = *reinterpret_cast<const u32u *>(row + base);
+    }
+    __device__ __forceinline__ uint32_t packed(int d) const
+    {
+        uint32_t o = v;
+        if (d != 0) {
+            o = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o |= ((v >> (8 * clampi(d + k, 0, 3))) & 0xffu) << (8 * k);
+        }
+        return o;
+    }
+    __device__ __forceinline__ float4 get(int d) const { return unpack_u8x4(packed(d)); }
+};
+
 // =========================================================================================
-// random_shift: one workgroup per (sample, channel) plane; each thread moves 4-pixel quads.
+// random_shift: one workgroup per RP-row slab of one (sample, channel) plane, one 4-pixel quad
+// per thread (RP*W/4 <= 256): 16128 short workgroups at B=256 keep every CU busy to the end of
+// the launch (finer slabs measured 35 -> 26 us vs one workgroup per plane).
 // =========================================================================================
-template <int H, int W, typename TIn, typename TOut>
+template <int H, int W, int RP, typename TIn, typename TOut>
 __global__ __launch_bounds__(256) void k_random_shift(const TIn *__restrict__ in, TOut *__restrict__ out, int C,
                                                       int pad, const int32_t *__restrict__ oy,
                                                       const int32_t *__restrict__ ox, uint64_t seed, uint64_t offset,
                                                       int sample0)
 {
     constexpr int W4 = W / 4;
-    constexpr int N4 = H * W4;
-    const int plane = blockIdx.x;
+    constexpr int PARTS = H / RP;
+    static_assert(RP * W4 <= 256 && H % RP == 0, "one quad per thread");
+    const int plane = blockIdx.x / PARTS;
+    const int part = blockIdx.x - plane * PARTS;
     const int b = plane / C;
     int dy, dx;
     sample_shift(oy, ox, seed, offset, sample0 + b, b, pad, dy, dx);
-    const int r = dx & 3;
-    const TIn *__restrict__ src = in + (size_t)plane * (H * W);
-    TOut *__restrict__ dst = out + (size_t)plane * (H * W);
-#pragma unroll 2
-    for (int j = threadIdx.x; j < N4; j += 256) {
-        const int y = j / W4;
-        const int x4 = (j - y * W4) * 4;
-        const int sy = clampi(y + dy, 0, H - 1);
-        if constexpr (sizeof(TIn) == 4) {
-            const float4 v = load_shifted4<W>(reinterpret_cast<const float *>(src) + sy * W, x4, dx, r);
-            *reinterpret_cast<float4 *>(reinterpret_cast<float *>(dst) + y * W + x4) = v;
-        } else {
-            const uint32_t v = load_shifted4_u8<W>(reinterpret_cast<const uint8_t *>(src) + sy * W, x4, dx, r);
-            if constexpr (sizeof(TOut) == 1)
-                *reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(dst) + y * W + x4) = v;
-            else
-                *reinterpret_cast<float4 *>(reinterpret_cast<float *>(dst) + y * W + x4) = unpack_u8x4(v);
-        }
-    }
+    const int j = threadIdx.x;
+    if (j >= RP * W4) return;
+    const int yy = j / W4;
+    const int x4 = (j - yy * W4) * 4;
+    const int y = part * RP + yy;
+    const int sy = clampi(y + dy, 0, H - 1);
+    const int base = clampi(x4 + dx, 0, W - 4);
+    const TIn *__restrict__ src = in + (size_t)plane * (H * W) + sy * W;
+    TOut *__restrict__ dst = out + (size_t)plane * (H * W) + y * W + x4;
+    Quad<W, TIn> q;
+    q.load(src, base);
+    if constexpr (sizeof(TOut) == 1)
+        *reinterpret_cast<uint32_t *>(dst) = q.packed(x4 + dx - base);
+    else
+        *reinterpret_cast<float4 *>(dst) = q.get(x4 + dx - base);
 }
 
 // any shape / alignment: one element per thread (correctness fallback, not tuned)
@@ -206,7 +213,7 @@ __device__ __forceinline__ void conv_stage_weights(ConvSmem<H, W, R> &sm, const 
 // (v[kx],v[kx+1]) and (v[kx+2],v[kx+3]) of the 6-wide window v = [left, m0..m3, right]; the even
 // pairs come from ds_read2_b32, the odd pairs are the two halves of one aligned ds_read_b128.
 // Accumulation order per output: i, ky, kx ascending (same as oracle/aug_oracle.c).
-template <int H, int W, int R>
+template <int H, int W, int R, int ABL = 0> // ABL: developer ablation switch (tools/kbench), 0 = product
 __device__ __forceinline__ void conv_compute_store(const ConvSmem<H, W, R> &sm, float *__restrict__ out_frame,
                                                    int y0)
 {
@@ -222,7 +229,7 @@ __device__ __forceinline__ void conv_compute_store(const ConvSmem<H, W, R> &sm, 
 #pragma unroll
     for (int o = 0; o < 3; ++o) acc[o][0] = acc[o][1] = f32x2{0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < (ABL == 2 ? 1 : 3); ++i) {
         f32x2 pe[3][3], po[3][2]; // even pairs (v0v1,v2v3,v4v5), odd pairs (v1v2,v3v4)
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
@@ -249,90 +256,87 @@ __device__ __forceinline__ void conv_compute_store(const ConvSmem<H, W, R> &sm, 
     }
 #pragma unroll
     for (int o = 0; o < 3; ++o) {
-        const float4 res = make_float4(sigmoid255(acc[o][0].x), sigmoid255(acc[o][0].y), sigmoid255(acc[o][1].x),
-                                       sigmoid255(acc[o][1].y));
+        float4 res = make_float4(sigmoid255(acc[o][0].x), sigmoid255(acc[o][0].y), sigmoid255(acc[o][1].x),
+                                 sigmoid255(acc[o][1].y));
+        if (ABL == 1) res = make_float4(acc[o][0].x, acc[o][0].y, acc[o][1].x, acc[o][1].y);
         *reinterpret_cast<float4 *>(out_frame + ((size_t)o * H + (y0 + ry)) * W + x4) = res;
     }
 }
 
-template <int H, int W, int R>
-__global__ __launch_bounds__(256) void k_random_conv(const float *__restrict__ in, float *__restrict__ out,
-                                                     int frames, const float *__restrict__ weights, uint64_t seed,
-                                                     uint64_t offset, int sample0)
+// =========================================================================================
+// random_conv / fused random_shift -> (out_shift) -> random_conv -> (out_aug)
+//   SHIFT = false: plain random_conv (in -> out_aug);  TIn = float | uint8_t
+//   Every thread first issues ALL of its strip loads (NI quads in flight), then converts,
+//   optionally stores the shifted rows, divides by 255 and writes the LDS tile.
+// =========================================================================================
+template <int H, int W, int R, int NT, typename TIn, bool SHIFT, int ABL = 0>
+__global__ __launch_bounds__(NT) void k_conv(const TIn *__restrict__ in, float *__restrict__ out_shift,
+                                             float *__restrict__ out_aug, int frames, int pad,
+                                             const int32_t *__restrict__ oy, const int32_t *__restrict__ ox,
+                                             const float *__restrict__ weights, uint64_t seed, uint64_t offset,
+                                             int sample0)
 {
     constexpr int NS = H / R;
     constexpr int W4 = W / 4;
+    constexpr int NQ = 3 * (R + 2) * W4;
+    constexpr int NI = (NQ + NT - 1) / NT;
+    static_assert(R * W4 <= NT, "one compute task per thread");
     __shared__ __attribute__((aligned(16))) ConvSmem<H, W, R> sm;
     const int strip = blockIdx.x % NS;
     const int fidx = blockIdx.x / NS; // b*frames + f
     const int b = fidx / frames;
     const int y0 = strip * R;
-    conv_stage_weights<H, W, R>(sm, weights, seed, offset, sample0 + b, b);
-    const float *__restrict__ src = in + (size_t)fidx * 3 * H * W;
-    constexpr int NQ = 3 * (R + 2) * W4;
-    for (int j = threadIdx.x; j < NQ; j += 256) {
-        const int ch = j / ((R + 2) * W4);
-        const int rem = j - ch * ((R + 2) * W4);
-        const int rr = rem / W4;
-        const int x4 = (rem - rr * W4) * 4;
-        const int sy = clampi(y0 - 1 + rr, 0, H - 1);
-        float4 q = *reinterpret_cast<const float4 *>(src + ((size_t)ch * H + sy) * W + x4);
-        q.x = div255(q.x);
-        q.y = div255(q.y);
-        q.z = div255(q.z);
-        q.w = div255(q.w);
-        *reinterpret_cast<float4 *>(&sm.tile[ch][rr][x4]) = q;
-    }
-    __syncthreads();
-    conv_compute_store<H, W, R>(sm, out + (size_t)fidx * 3 * H * W, y0);
-}
-
-// fused random_shift -> (out_shift) -> random_conv -> (out_aug), u8 or f32 observation in
-template <int H, int W, int R, typename TIn>
-__global__ __launch_bounds__(256) void k_shift_conv(const TIn *__restrict__ in, float *__restrict__ out_shift,
-                                                    float *__restrict__ out_aug, int frames, int pad,
-                                                    const int32_t *__restrict__ oy, const int32_t *__restrict__ ox,
-                                                    const float *__restrict__ weights, uint64_t seed,
-                                                    uint64_t offset, int sample0)
-{
-    constexpr int NS = H / R;
-    constexpr int W4 = W / 4;
-    __shared__ __attribute__((aligned(16))) ConvSmem<H, W, R> sm;
-    const int strip = blockIdx.x % NS;
-    const int fidx = blockIdx.x / NS;
-    const int b = fidx / frames;
-    const int y0 = strip * R;
-    int dy, dx;
-    sample_shift(oy, ox, seed, offset, sample0 + b, b, pad, dy, dx);
-    const int r = dx & 3;
+    int dy = 0, dx = 0;
+    if constexpr (SHIFT) sample_shift(oy, ox, seed, offset, sample0 + b, b, pad, dy, dx);
     if (out_aug != nullptr) conv_stage_weights<H, W, R>(sm, weights, seed, offset, sample0 + b, b);
     const TIn *__restrict__ src = in + (size_t)fidx * 3 * H * W;
-    constexpr int NQ = 3 * (R + 2) * W4;
-    for (int j = threadIdx.x; j < NQ; j += 256) {
-        const int ch = j / ((R + 2) * W4);
-        const int rem = j - ch * ((R + 2) * W4);
-        const int rr = rem / W4;
-        const int x4 = (rem - rr * W4) * 4;
-        const int ys = y0 - 1 + rr;               // row of the SHIFTED image (may be -1 / H: halo)
-        const int yc = clampi(ys, 0, H - 1);      // conv's replicate pad on the shifted image
-        const int sy = clampi(yc + dy, 0, H - 1); // shift's replicate pad on the source
-        float4 q;
-        if constexpr (sizeof(TIn) == 4)
-            q = load_shifted4<W>(reinterpret_cast<const float *>(src) + ((size_t)ch * H + sy) * W, x4, dx, r);
-        else
-            q = unpack_u8x4(
-                load_shifted4_u8<W>(reinterpret_cast<const uint8_t *>(src) + ((size_t)ch * H + sy) * W, x4, dx, r));
-        if (out_shift != nullptr && ys >= y0 && ys < y0 + R)
-            *reinterpret_cast<float4 *>(out_shift + ((size_t)(fidx * 3 + ch) * H + ys) * W + x4) = q;
-        q.x = div255(q.x);
-        q.y = div255(q.y);
-        q.z = div255(q.z);
-        q.w = div255(q.w);
-        *reinterpret_cast<float4 *>(&sm.tile[ch][rr][x4]) = q;
+
+    Quad<W, TIn> raw[NI];
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+        const int j = threadIdx.x + k * NT;
+        if (j < NQ) {
+            const int ch = j / ((R + 2) * W4);
+            const int rem = j - ch * ((R + 2) * W4);
+            const int rr = rem / W4;
+            const int x4 = (rem - rr * W4) * 4;
+            const int yc = clampi(y0 - 1 + rr, 0, H - 1); // conv's replicate pad (on the shifted image)
+            const int sy = clampi(yc + dy, 0, H - 1);     // shift's replicate pad on the source
+            raw[k].load(src + ((size_t)ch * H + sy) * W, clampi(x4 + dx, 0, W - 4));
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+        const int j = threadIdx.x + k * NT;
+        if (j < NQ) {
+            const int ch = j / ((R + 2) * W4);
+            const int rem = j - ch * ((R + 2) * W4);
+            const int rr = rem / W4;
+            const int x4 = (rem - rr * W4) * 4;
+            const int ys = y0 - 1 + rr;
+            float4 q = raw[k].get(SHIFT ? x4 + dx - clampi(x4 + dx, 0, W - 4) : 0);
+            if (SHIFT && out_shift != nullptr && ys >= y0 && ys < y0 + R)
+                *reinterpret_cast<float4 *>(out_shift + ((size_t)(fidx * 3 + ch) * H + ys) * W + x4) = q;
+            q.x = div255(q.x);
+            q.y = div255(q.y);
+            q.z = div255(q.z);
+            q.w = div255(q.w);
+            *reinterpret_cast<float4 *>(&sm.tile[ch][rr][x4]) = q;
+        }
     }
     if (out_aug == nullptr) return;
     __syncthreads();
-    conv_compute_store<H, W, R>(sm, out_aug + (size_t)fidx * 3 * H * W, y0);
+    if (ABL == 3) { // staging only: copy the strip's rows back out of LDS
+        const int tid = threadIdx.x;
+        if (tid < R * W4) {
+            const int ry = tid / W4, x4 = (tid - ry * W4) * 4;
+            for (int o = 0; o < 3; ++o)
+                *reinterpret_cast<float4 *>(out_aug + ((size_t)(fidx * 3 + o) * H + y0 + ry) * W + x4) =
+                    *reinterpret_cast<const float4 *>(&sm.tile[o][ry + 1][x4]);
+        }
+        return;
+    }
+    conv_compute_store<H, W, R, ABL>(sm, out_aug + (size_t)fidx * 3 * H * W, y0);
 }
 
 // any shape: one output pixel (3 channels) per thread straight from global memory
@@ -600,11 +604,11 @@ static int shift_dispatch(const TIn *in, TOut *out, int B, int C, int H, int W, 
     hipStream_t s = as_stream(stream);
     const bool vec_ok = fast_shape(H, W) && aligned16(in) && aligned16(out);
     if (vec_ok && H == 84)
-        hipLaunchKernelGGL((k_random_shift<84, 84, TIn, TOut>), dim3(B * C), dim3(256), 0, s, in, out, C, pad, oy, ox,
-                           seed, offset, sample0);
+        hipLaunchKernelGGL((k_random_shift<84, 84, 12, TIn, TOut>), dim3(B * C * 7), dim3(256), 0, s, in, out, C, pad,
+                           oy, ox, seed, offset, sample0);
     else if (vec_ok && H == 100)
-        hipLaunchKernelGGL((k_random_shift<100, 100, TIn, TOut>), dim3(B * C), dim3(256), 0, s, in, out, C, pad, oy,
-                           ox, seed, offset, sample0);
+        hipLaunchKernelGGL((k_random_shift<100, 100, 10, TIn, TOut>), dim3(B * C * 10), dim3(256), 0, s, in, out, C,
+                           pad, oy, ox, seed, offset, sample0);
     else {
         const int gx = (H * W + 255) / 256 < 64 ? (H * W + 255) / 256 : 64;
         hipLaunchKernelGGL((k_random_shift_generic<TIn, TOut>), dim3(gx, B * C), dim3(256), 0, s, in, out, C, H, W,
@@ -628,10 +632,10 @@ static int shift_conv_dispatch(const TIn *in, float *out_shift, float *out_aug, 
     if (B == 0) return AUGCL_OK;
     hipStream_t s = as_stream(stream);
     if (H == 84)
-        hipLaunchKernelGGL((k_shift_conv<84, 84, 12, TIn>), dim3(B * frames * 7), dim3(256), 0, s, in, out_shift,
+        hipLaunchKernelGGL((k_conv<84, 84, 12, 256, TIn, true>), dim3(B * frames * 7), dim3(256), 0, s, in, out_shift,
                            out_aug, frames, pad, oy, ox, weights, seed, offset, sample0);
     else
-        hipLaunchKernelGGL((k_shift_conv<100, 100, 10, TIn>), dim3(B * frames * 10), dim3(256), 0, s, in, out_shift,
+        hipLaunchKernelGGL((k_conv<100, 100, 10, 256, TIn, true>), dim3(B * frames * 10), dim3(256), 0, s, in, out_shift,
                            out_aug, frames, pad, oy, ox, weights, seed, offset, sample0);
     LAUNCH_CHECK(name);
 }
@@ -670,10 +674,12 @@ int augcl_random_conv_f32(const float *in, float *out, int B, int frames, int H,
     hipStream_t s = as_stream(stream);
     const bool vec_ok = fast_shape(H, W) && aligned16(in) && aligned16(out);
     if (vec_ok && H == 84)
-        hipLaunchKernelGGL((k_random_conv<84, 84, 12>), dim3(B * frames * 7), dim3(256), 0, s, in, out, frames,
+        hipLaunchKernelGGL((k_conv<84, 84, 12, 256, float, false>), dim3(B * frames * 7), dim3(256), 0, s, in,
+                           (float *)nullptr, out, frames, 0, (const int32_t *)nullptr, (const int32_t *)nullptr,
                            weights, seed, offset, sample0);
     else if (vec_ok && H == 100)
-        hipLaunchKernelGGL((k_random_conv<100, 100, 10>), dim3(B * frames * 10), dim3(256), 0, s, in, out, frames,
+        hipLaunchKernelGGL((k_conv<100, 100, 10, 256, float, false>), dim3(B * frames * 10), dim3(256), 0, s, in,
+                           (float *)nullptr, out, frames, 0, (const int32_t *)nullptr, (const int32_t *)nullptr,
                            weights, seed, offset, sample0);
     else {
         const int gx = (H * W + 255) / 256 < 64 ? (H * W + 255) / 256 : 64;

@@ -21,84 +21,7 @@ using namespace augcl;
         }                                                                        \
     } while (0)
 
-// ---------------------------------------------------------------- experimental shift variants
-// S1: one block per third of a plane (28 rows): 3x more, shorter blocks -> smaller tail
-template <int H, int W, int PARTS>
-__global__ __launch_bounds__(256) void k_shift_parts(const float *__restrict__ in, float *__restrict__ out, int C,
-                                                     int pad, const int32_t *__restrict__ oy,
-                                                     const int32_t *__restrict__ ox)
-{
-    constexpr int W4 = W / 4;
-    constexpr int RP = H / PARTS;
-    constexpr int N4 = RP * W4;
-    const int plane = blockIdx.x / PARTS;
-    const int part = blockIdx.x - plane * PARTS;
-    const int b = plane / C;
-    int dy, dx;
-    sample_shift(oy, ox, 0, 0, b, b, pad, dy, dx);
-    const int r = dx & 3;
-    const float *__restrict__ src = in + (size_t)plane * (H * W);
-    float *__restrict__ dst = out + (size_t)plane * (H * W);
-#pragma unroll
-    for (int j = threadIdx.x; j < N4; j += 256) {
-        const int yy = j / W4;
-        const int y = part * RP + yy;
-        const int x4 = (j - yy * W4) * 4;
-        const int sy = clampi(y + dy, 0, H - 1);
-        const float4 v = load_shifted4<W>(src + sy * W, x4, dx, r);
-        *reinterpret_cast<float4 *>(dst + y * W + x4) = v;
-    }
-}
-
-// S2: single UNALIGNED float4 load (dword-aligned address) + per-lane border select
-template <int W>
-__device__ __forceinline__ float4 load_shifted4_unaligned(const float *__restrict__ row, int x4, int dx)
-{
-    const int s0 = x4 + dx;
-    const int base = clampi(s0, 0, W - 4);
-    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-    const f4u V = *reinterpret_cast<const f4u *>(row + base);
-    const int d = s0 - base;
-    float4 o = make_float4(V.x, V.y, V.z, V.w);
-    if (d != 0) {
-        float vv[4] = {V.x, V.y, V.z, V.w};
-        float oo[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int idx = clampi(d + k, 0, 3);
-            oo[k] = idx == 0 ? vv[0] : idx == 1 ? vv[1] : idx == 2 ? vv[2] : vv[3];
-        }
-        o = make_float4(oo[0], oo[1], oo[2], oo[3]);
-    }
-    return o;
-}
-
-template <int H, int W, int PARTS>
-__global__ __launch_bounds__(256) void k_shift_unaligned(const float *__restrict__ in, float *__restrict__ out,
-                                                         int C, int pad, const int32_t *__restrict__ oy,
-                                                         const int32_t *__restrict__ ox)
-{
-    constexpr int W4 = W / 4;
-    constexpr int RP = H / PARTS;
-    constexpr int N4 = RP * W4;
-    const int plane = blockIdx.x / PARTS;
-    const int part = blockIdx.x - plane * PARTS;
-    const int b = plane / C;
-    int dy, dx;
-    sample_shift(oy, ox, 0, 0, b, b, pad, dy, dx);
-    const float *__restrict__ src = in + (size_t)plane * (H * W);
-    float *__restrict__ dst = out + (size_t)plane * (H * W);
-#pragma unroll
-    for (int j = threadIdx.x; j < N4; j += 256) {
-        const int yy = j / W4;
-        const int y = part * RP + yy;
-        const int x4 = (j - yy * W4) * 4;
-        const int sy = clampi(y + dy, 0, H - 1);
-        const float4 v = load_shifted4_unaligned<W>(src + sy * W, x4, dx);
-        *reinterpret_cast<float4 *>(dst + y * W + x4) = v;
-    }
-}
-
+// ---------------------------------------------------------------- reference copies
 // S3: plain copy (upper bound for this access shape): same decomposition, no shift
 template <int H, int W, int PARTS>
 __global__ __launch_bounds__(256) void k_copy_parts(const float *__restrict__ in, float *__restrict__ out)
@@ -159,10 +82,11 @@ int main(int argc, char **argv)
     const double f2f = 2.0 * n * 4;
     std::vector<Variant> vs;
     vs.push_back({"shift_f32 product", f2f, [&](int k) { augcl_random_shift_f32(fin[k], fout[k], B, 9, 84, 84, 4, oy, ox, 0, 0, 0, 0); }});
-    vs.push_back({"shift_f32 parts=3", f2f, [&](int k) { hipLaunchKernelGGL((k_shift_parts<84, 84, 3>), dim3(B * 9 * 3), dim3(256), 0, 0, fin[k], fout[k], 9, 4, oy, ox); }});
-    vs.push_back({"shift_f32 parts=7", f2f, [&](int k) { hipLaunchKernelGGL((k_shift_parts<84, 84, 7>), dim3(B * 9 * 7), dim3(256), 0, 0, fin[k], fout[k], 9, 4, oy, ox); }});
-    vs.push_back({"shift_f32 unaligned parts=3", f2f, [&](int k) { hipLaunchKernelGGL((k_shift_unaligned<84, 84, 3>), dim3(B * 9 * 3), dim3(256), 0, 0, fin[k], fout[k], 9, 4, oy, ox); }});
-    vs.push_back({"shift_f32 unaligned parts=7", f2f, [&](int k) { hipLaunchKernelGGL((k_shift_unaligned<84, 84, 7>), dim3(B * 9 * 7), dim3(256), 0, 0, fin[k], fout[k], 9, 4, oy, ox); }});
+    vs.push_back({"conv R=6 NT=128", f2f, [&](int k) { hipLaunchKernelGGL((k_conv<84, 84, 6, 128, float, false>), dim3(B * 3 * 14), dim3(128), 0, 0, fin[k], (float *)nullptr, fout[k], 3, 0, (const int32_t *)nullptr, (const int32_t *)nullptr, w, 0, 0, 0); }});
+    vs.push_back({"shift_conv_u8 R=6 NT=128", (double)n * 9, [&](int k) { hipLaunchKernelGGL((k_conv<84, 84, 6, 128, uint8_t, true>), dim3(B * 3 * 14), dim3(128), 0, 0, uin[k], fout[k], fout2[k & 1], 3, 4, oy, ox, w, 0, 0, 0); }});
+    vs.push_back({"conv ABL1 no sigmoid", f2f, [&](int k) { hipLaunchKernelGGL((k_conv<84, 84, 12, 256, float, false, 1>), dim3(B * 3 * 7), dim3(256), 0, 0, fin[k], (float *)nullptr, fout[k], 3, 0, (const int32_t *)nullptr, (const int32_t *)nullptr, w, 0, 0, 0); }});
+    vs.push_back({"conv ABL2 1/3 fma", f2f, [&](int k) { hipLaunchKernelGGL((k_conv<84, 84, 12, 256, float, false, 2>), dim3(B * 3 * 7), dim3(256), 0, 0, fin[k], (float *)nullptr, fout[k], 3, 0, (const int32_t *)nullptr, (const int32_t *)nullptr, w, 0, 0, 0); }});
+    vs.push_back({"conv ABL3 stage+copy only", f2f, [&](int k) { hipLaunchKernelGGL((k_conv<84, 84, 12, 256, float, false, 3>), dim3(B * 3 * 7), dim3(256), 0, 0, fin[k], (float *)nullptr, fout[k], 3, 0, (const int32_t *)nullptr, (const int32_t *)nullptr, w, 0, 0, 0); }});
     vs.push_back({"copy parts=1", f2f, [&](int k) { hipLaunchKernelGGL((k_copy_parts<84, 84, 1>), dim3(B * 9), dim3(256), 0, 0, fin[k], fout[k]); }});
     vs.push_back({"copy parts=3", f2f, [&](int k) { hipLaunchKernelGGL((k_copy_parts<84, 84, 3>), dim3(B * 9 * 3), dim3(256), 0, 0, fin[k], fout[k]); }});
     vs.push_back({"copy parts=7", f2f, [&](int k) { hipLaunchKernelGGL((k_copy_parts<84, 84, 7>), dim3(B * 9 * 7), dim3(256), 0, 0, fin[k], fout[k]); }});
