@@ -29,6 +29,15 @@
 #include <stdint.h>
 #include <string.h>
 
+#ifdef _OPENMP
+#include <omp.h>
+void oracle_set_num_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+int oracle_get_max_threads(void) { return omp_get_max_threads(); }
+#else
+void oracle_set_num_threads(int n) { (void)n; }
+int oracle_get_max_threads(void) { return 1; }
+#endif
+
 static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 /* reference: src/augmentations.py:378-382  random_shift(imgs, pad=4)

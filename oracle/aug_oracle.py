@@ -38,6 +38,11 @@ def lib():
     return _lib
 
 
+def set_num_threads(n):
+    lib().oracle_set_num_threads(int(n))
+    return lib().oracle_get_max_threads()
+
+
 def _p(a, ty):
     return a.ctypes.data_as(ty)
 

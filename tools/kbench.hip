@@ -82,11 +82,11 @@ int main(int argc, char **argv)
     const double f2f = 2.0 * n * 4;
     std::vector<Variant> vs;
     vs.push_back({"shift_f32 product", f2f, [&](int k) { augcl_random_shift_f32(fin[k], fout[k], B, 9, 84, 84, 4, oy, ox, 0, 0, 0, 0); }});
-    vs.push_back({"conv R=6 NT=128", f2f, [&](int k) { hipLaunchKernelGGL((k_conv<84, 84, 6, 128, float, false>), dim3(B * 3 * 14), dim3(128), 0, 0, fin[k], (float *)nullptr, fout[k], 3, 0, (const int32_t *)nullptr, (const int32_t *)nullptr, w, 0, 0, 0); }});
-    vs.push_back({"shift_conv_u8 R=6 NT=128", (double)n * 9, [&](int k) { hipLaunchKernelGGL((k_conv<84, 84, 6, 128, uint8_t, true>), dim3(B * 3 * 14), dim3(128), 0, 0, uin[k], fout[k], fout2[k & 1], 3, 4, oy, ox, w, 0, 0, 0); }});
-    vs.push_back({"conv ABL1 no sigmoid", f2f, [&](int k) { hipLaunchKernelGGL((k_conv<84, 84, 12, 256, float, false, 1>), dim3(B * 3 * 7), dim3(256), 0, 0, fin[k], (float *)nullptr, fout[k], 3, 0, (const int32_t *)nullptr, (const int32_t *)nullptr, w, 0, 0, 0); }});
-    vs.push_back({"conv ABL2 1/3 fma", f2f, [&](int k) { hipLaunchKernelGGL((k_conv<84, 84, 12, 256, float, false, 2>), dim3(B * 3 * 7), dim3(256), 0, 0, fin[k], (float *)nullptr, fout[k], 3, 0, (const int32_t *)nullptr, (const int32_t *)nullptr, w, 0, 0, 0); }});
-    vs.push_back({"conv ABL3 stage+copy only", f2f, [&](int k) { hipLaunchKernelGGL((k_conv<84, 84, 12, 256, float, false, 3>), dim3(B * 3 * 7), dim3(256), 0, 0, fin[k], (float *)nullptr, fout[k], 3, 0, (const int32_t *)nullptr, (const int32_t *)nullptr, w, 0, 0, 0); }});
+    vs.push_back({"conv R=6 NT=128", f2f, [&](int k) { hipLaunchKernelGGL((k_conv<84, 84, 6, 128, float, false>), dim3(B * 3 * 14), dim3(128), 0, 0, fin[k], (float *)nullptr, fout[k], B * 3, 3, 0, (const int32_t *)nullptr, (const int32_t *)nullptr, w, 0, 0, 0); }});
+    vs.push_back({"shift_conv_u8 R=6 NT=128", (double)n * 9, [&](int k) { hipLaunchKernelGGL((k_conv<84, 84, 6, 128, uint8_t, true>), dim3(B * 3 * 14), dim3(128), 0, 0, uin[k], fout[k], fout2[k & 1], B * 3, 3, 4, oy, ox, w, 0, 0, 0); }});
+    vs.push_back({"conv ABL1 no sigmoid", f2f, [&](int k) { hipLaunchKernelGGL((k_conv<84, 84, 12, 256, float, false, 1>), dim3(B * 3 * 7), dim3(256), 0, 0, fin[k], (float *)nullptr, fout[k], B * 3, 3, 0, (const int32_t *)nullptr, (const int32_t *)nullptr, w, 0, 0, 0); }});
+    vs.push_back({"conv ABL2 1/3 fma", f2f, [&](int k) { hipLaunchKernelGGL((k_conv<84, 84, 12, 256, float, false, 2>), dim3(B * 3 * 7), dim3(256), 0, 0, fin[k], (float *)nullptr, fout[k], B * 3, 3, 0, (const int32_t *)nullptr, (const int32_t *)nullptr, w, 0, 0, 0); }});
+    vs.push_back({"conv ABL3 stage+copy only", f2f, [&](int k) { hipLaunchKernelGGL((k_conv<84, 84, 12, 256, float, false, 3>), dim3(B * 3 * 7), dim3(256), 0, 0, fin[k], (float *)nullptr, fout[k], B * 3, 3, 0, (const int32_t *)nullptr, (const int32_t *)nullptr, w, 0, 0, 0); }});
     vs.push_back({"copy parts=1", f2f, [&](int k) { hipLaunchKernelGGL((k_copy_parts<84, 84, 1>), dim3(B * 9), dim3(256), 0, 0, fin[k], fout[k]); }});
     vs.push_back({"copy parts=3", f2f, [&](int k) { hipLaunchKernelGGL((k_copy_parts<84, 84, 3>), dim3(B * 9 * 3), dim3(256), 0, 0, fin[k], fout[k]); }});
     vs.push_back({"copy parts=7", f2f, [&](int k) { hipLaunchKernelGGL((k_copy_parts<84, 84, 7>), dim3(B * 9 * 7), dim3(256), 0, 0, fin[k], fout[k]); }});
