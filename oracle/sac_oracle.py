@@ -1,0 +1,359 @@
+"""oracle/sac_oracle.py -- CPU (torch float32) restatement of the network stack and the
+SAC / RAD / Non-Naive-RAD / SVEA / DrQ / AugCL update() of the reference.
+
+TEST INFRASTRUCTURE ONLY (tests/, __graft_entry__.smoke(), bench.py's cpu_baseline leg).
+Nothing under augcl_amd/ imports this file.
+
+Written functionally (explicit parameter dicts, explicit noise / augmentation parameters,
+hand-written Adam) so it shares no structure with the product's nn.Module code, and pinned
+against outputs of the reference itself run in the build container
+(tests/golden/make_golden_sac.py -> tests/golden/sac_golden.npz): losses, Q values and
+parameter checksums of k update steps agree to <= 1e-5 (tests/test_oracle_golden_sac.py).
+
+Reference lines restated:
+  src/algorithms/modules.py:19-32   gaussian_logprob, squash
+  src/algorithms/modules.py:145-165 SharedCNN (x/255, conv3x3 s2, then [ReLU, conv3x3 s1]*)
+  src/algorithms/modules.py:101-111 RLProjection (Linear, LayerNorm, Tanh)
+  src/algorithms/modules.py:184-197 Encoder (detach between CNN and projection)
+  src/algorithms/modules.py:200-276 Actor, QFunction, Critic
+  src/algorithms/sac.py:94-164      calculate_target_Q, update_critic, update_actor_and_alpha,
+                                    soft_update_critic_target, update
+  src/algorithms/rad.py:24-36, non_naive_rad.py:8-18, svea.py:15-76, drq.py:15-86, augcl.py:16-89
+  src/utils.py:76-78                soft_update_params
+Hyper-parameter defaults: src/arguments.py:22-67.
+"""
+import copy
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+DEFAULTS = dict(discount=0.99, critic_tau=0.01, encoder_tau=0.05, actor_update_freq=2,
+                critic_target_update_freq=2, num_shared_layers=11, num_head_layers=0, num_filters=32,
+                projection_dim=100, hidden_dim=1024, actor_log_std_min=-10.0, actor_log_std_max=2.0,
+                init_temperature=0.1, actor_lr=1e-3, actor_beta=0.9, critic_lr=1e-3, critic_beta=0.9,
+                alpha_lr=1e-4, alpha_beta=0.5, svea_alpha=0.5, svea_beta=0.5, drq_k=1, drq_m=1)
+
+
+# ------------------------------------------------------------------ parameter inventory
+def conv_layer_ids(n_shared):
+    """nn.Sequential indices of the conv layers in SharedCNN.layers (modules.py:151-158)."""
+    return [2 + 2 * i for i in range(n_shared)]
+
+
+def cnn_out_hw(h, n_layers):
+    h = (h - 3) // 2 + 1
+    for _ in range(n_layers - 1):
+        h -= 2
+    return h
+
+
+def critic_shapes(obs_shape, A, hp):
+    C, H, W = obs_shape
+    nf = hp["num_filters"]
+    shapes = {}
+    for li, idx in enumerate(conv_layer_ids(hp["num_shared_layers"])):
+        shapes[f"encoder.shared_cnn.layers.{idx}.weight"] = (nf, C if li == 0 else nf, 3, 3)
+        shapes[f"encoder.shared_cnn.layers.{idx}.bias"] = (nf,)
+    for li in range(hp["num_head_layers"]):
+        shapes[f"encoder.head_cnn.layers.{2 * li + 1}.weight"] = (nf, nf, 3, 3)
+        shapes[f"encoder.head_cnn.layers.{2 * li + 1}.bias"] = (nf,)
+    hw = cnn_out_hw(H, hp["num_shared_layers"]) - 2 * hp["num_head_layers"]
+    flat = nf * hw * hw
+    pd, hd = hp["projection_dim"], hp["hidden_dim"]
+    shapes["encoder.projection.projection.0.weight"] = (pd, flat)
+    shapes["encoder.projection.projection.0.bias"] = (pd,)
+    shapes["encoder.projection.projection.1.weight"] = (pd,)
+    shapes["encoder.projection.projection.1.bias"] = (pd,)
+    for q in ("Q1", "Q2"):
+        shapes[f"{q}.trunk.0.weight"] = (hd, pd + A)
+        shapes[f"{q}.trunk.0.bias"] = (hd,)
+        shapes[f"{q}.trunk.2.weight"] = (hd, hd)
+        shapes[f"{q}.trunk.2.bias"] = (hd,)
+        shapes[f"{q}.trunk.4.weight"] = (1, hd)
+        shapes[f"{q}.trunk.4.bias"] = (1,)
+    return shapes
+
+
+def actor_shapes(obs_shape, A, hp):
+    cs = critic_shapes(obs_shape, A, hp)
+    shapes = {k: v for k, v in cs.items() if k.startswith("encoder.")}
+    pd, hd = hp["projection_dim"], hp["hidden_dim"]
+    shapes["mlp.0.weight"] = (hd, pd)
+    shapes["mlp.0.bias"] = (hd,)
+    shapes["mlp.2.weight"] = (hd, hd)
+    shapes["mlp.2.bias"] = (hd,)
+    shapes["mlp.4.weight"] = (2 * A, hd)
+    shapes["mlp.4.bias"] = (2 * A,)
+    return shapes
+
+
+def is_cnn(name):
+    return name.startswith("encoder.shared_cnn.") or name.startswith("encoder.head_cnn.")
+
+
+def synth_state(seed, shapes):
+    """Deterministic, box-independent weights (np.random.RandomState): He-like scale for weights,
+    small non-zero biases, LayerNorm weight near 1.  torch's own init is LAPACK-dependent."""
+    rs = np.random.RandomState(seed)
+    out = {}
+    for name in sorted(shapes):
+        shp = shapes[name]
+        if name.endswith("projection.1.weight"):
+            v = 1.0 + 0.1 * rs.standard_normal(shp)
+        elif name.endswith(".bias"):
+            v = 0.05 * rs.standard_normal(shp)
+        else:
+            fan_in = int(np.prod(shp[1:]))
+            v = rs.standard_normal(shp) * math.sqrt(2.0 / fan_in)
+        out[name] = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32))
+    return out
+
+
+# ------------------------------------------------------------------ networks (functional)
+def cnn_forward(p, x, hp):
+    h = x / 255.0
+    ids = conv_layer_ids(hp["num_shared_layers"])
+    for li, idx in enumerate(ids):
+        if li > 0:
+            h = torch.relu(h)
+        h = F.conv2d(h, p[f"encoder.shared_cnn.layers.{idx}.weight"], p[f"encoder.shared_cnn.layers.{idx}.bias"],
+                     stride=2 if li == 0 else 1)
+    for li in range(hp["num_head_layers"]):
+        h = torch.relu(h)
+        h = F.conv2d(h, p[f"encoder.head_cnn.layers.{2 * li + 1}.weight"], p[f"encoder.head_cnn.layers.{2 * li + 1}.bias"])
+    return h.flatten(1)
+
+
+def encode(p, x, hp, detach=False):
+    h = cnn_forward(p, x, hp)
+    if detach:
+        h = h.detach()
+    h = F.linear(h, p["encoder.projection.projection.0.weight"], p["encoder.projection.projection.0.bias"])
+    h = F.layer_norm(h, (h.shape[-1],), p["encoder.projection.projection.1.weight"],
+                     p["encoder.projection.projection.1.bias"], 1e-5)
+    return torch.tanh(h)
+
+
+def actor_forward(p, x, hp, noise=None, detach=False):
+    """returns mu, pi, log_pi, log_std (modules.py:216-244). noise=None => compute_pi=False."""
+    h = encode(p, x, hp, detach)
+    h = torch.relu(F.linear(h, p["mlp.0.weight"], p["mlp.0.bias"]))
+    h = torch.relu(F.linear(h, p["mlp.2.weight"], p["mlp.2.bias"]))
+    mu, log_std = F.linear(h, p["mlp.4.weight"], p["mlp.4.bias"]).chunk(2, dim=-1)
+    lo, hi = hp["actor_log_std_min"], hp["actor_log_std_max"]
+    log_std = lo + 0.5 * (hi - lo) * (torch.tanh(log_std) + 1)
+    if noise is None:
+        return torch.tanh(mu), None, None, log_std
+    pi = mu + noise * log_std.exp()
+    log_pi = (-0.5 * noise.pow(2) - log_std).sum(-1, keepdim=True) - 0.5 * np.log(2 * np.pi) * noise.size(-1)
+    mu, pi = torch.tanh(mu), torch.tanh(pi)
+    log_pi = log_pi - torch.log(F.relu(1 - pi.pow(2)) + 1e-6).sum(-1, keepdim=True)
+    return mu, pi, log_pi, log_std
+
+
+def q_forward(p, q, h, a):
+    z = torch.cat([h, a], dim=1)
+    z = torch.relu(F.linear(z, p[f"{q}.trunk.0.weight"], p[f"{q}.trunk.0.bias"]))
+    z = torch.relu(F.linear(z, p[f"{q}.trunk.2.weight"], p[f"{q}.trunk.2.bias"]))
+    return F.linear(z, p[f"{q}.trunk.4.weight"], p[f"{q}.trunk.4.bias"])
+
+
+def critic_forward(p, x, a, hp, detach=False):
+    h = encode(p, x, hp, detach)
+    return q_forward(p, "Q1", h, a), q_forward(p, "Q2", h, a)
+
+
+# ------------------------------------------------------------------ Adam (torch.optim.Adam, no amsgrad / wd)
+class Adam:
+    """One instance per reference optimizer; params is an ORDERED list of leaf tensors."""
+
+    def __init__(self, params, lr, beta1, beta2=0.999, eps=1e-8):
+        self.params, self.lr, self.b1, self.b2, self.eps = list(params), lr, beta1, beta2, eps
+        self.m = [torch.zeros_like(t) for t in self.params]
+        self.v = [torch.zeros_like(t) for t in self.params]
+        self.t = [0 for _ in self.params]
+
+    def zero_grad(self):
+        for t in self.params:
+            t.grad = None
+
+    def step(self):
+        with torch.no_grad():
+            for i, t in enumerate(self.params):
+                if t.grad is None:  # e.g. the shared CNN inside actor.parameters() (sac.py:119-133)
+                    continue
+                g = t.grad
+                self.t[i] += 1
+                k = self.t[i]
+                self.m[i].mul_(self.b1).add_(g, alpha=1 - self.b1)
+                self.v[i].mul_(self.b2).addcmul_(g, g, value=1 - self.b2)
+                bc1 = 1 - self.b1 ** k
+                bc2 = 1 - self.b2 ** k
+                denom = (self.v[i].sqrt() / math.sqrt(bc2)).add_(self.eps)
+                t.addcdiv_(self.m[i], denom, value=-(self.lr / bc1))
+
+
+def soft_update(src, dst, names, tau):
+    """utils.soft_update_params: target <- tau*p + (1-tau)*target (src/utils.py:76-78)."""
+    with torch.no_grad():
+        for n in names:
+            dst[n].copy_(tau * src[n] + (1 - tau) * dst[n])
+
+
+# ------------------------------------------------------------------ agent
+class OracleAgent:
+    """algo in {sac, rad, non_naive_rad, svea, drq, augcl}.  All randomness is passed in:
+    `aug(x)` callables for the augmentations and explicit actor noise tensors."""
+
+    def __init__(self, algo, obs_shape, A, actor_state, critic_state, hp=None):
+        self.algo = algo
+        self.hp = dict(DEFAULTS, **(hp or {}))
+        self.A = A
+        mk = lambda d: {k: v.clone().requires_grad_(True) for k, v in d.items()}  # noqa: E731
+        self.critic = mk(critic_state)
+        self.actor = mk({k: v for k, v in actor_state.items() if not is_cnn(k)})
+        for k in self.critic:  # actor and critic share the SAME CNN tensors (sac.py:17-32)
+            if is_cnn(k):
+                self.actor[k] = self.critic[k]
+        self.critic_target = {k: v.detach().clone() for k, v in self.critic.items()}  # deepcopy (sac.py:42)
+        self.log_alpha = torch.tensor(np.log(self.hp["init_temperature"]), dtype=torch.float64, requires_grad=True)
+        self.target_entropy = -float(A)
+        hp_ = self.hp
+        self.actor_names = list(actor_shapes(obs_shape, A, hp_).keys())  # nn.Module.parameters() order
+        self.critic_names = list(critic_shapes(obs_shape, A, hp_).keys())
+        self.actor_opt = Adam([self.actor[n] for n in self.actor_names], hp_["actor_lr"], hp_["actor_beta"])
+        self.critic_opt = Adam([self.critic[n] for n in self.critic_names], hp_["critic_lr"], hp_["critic_beta"])
+        self.alpha_opt = Adam([self.log_alpha], hp_["alpha_lr"], hp_["alpha_beta"])
+        if algo == "augcl":
+            # supported flow = curriculum hand-off (augcl.py:16-27): critic_weak is the previous agent's
+            # critic (with ITS optimizer), the strong critic/actor/target start as copies of it.
+            self.critic_weak = {k: v.detach().clone().requires_grad_(True) for k, v in self.critic.items()}
+            self.critic_weak_opt = Adam([self.critic_weak[n] for n in self.critic_names], hp_["critic_lr"],
+                                        hp_["critic_beta"])
+
+    @property
+    def alpha(self):
+        return self.log_alpha.exp()
+
+    # -- pieces -----------------------------------------------------------------------------
+    def target_q(self, next_obs, reward, not_done, noise):
+        with torch.no_grad():
+            _, pa, log_pi, _ = actor_forward(self.actor, next_obs, self.hp, noise)
+            q1, q2 = critic_forward(self.critic_target, next_obs, pa, self.hp)
+            v = torch.min(q1, q2) - self.alpha.detach() * log_pi
+            return reward + not_done * self.hp["discount"] * v
+
+    @staticmethod
+    def _mse2(q1, q2, y):
+        return F.mse_loss(q1, y) + F.mse_loss(q2, y)
+
+    def update_actor_and_alpha(self, obs, noise, log):
+        critic = self.critic
+        _, pi, log_pi, log_std = actor_forward(self.actor, obs, self.hp, noise, detach=True)
+        q1, q2 = critic_forward(critic, obs, pi, self.hp, detach=True)
+        actor_loss = (self.alpha.detach() * log_pi - torch.min(q1, q2)).mean()
+        ent = 0.5 * log_std.shape[1] * (1.0 + np.log(2 * np.pi)) + log_std.sum(dim=-1)
+        log["train_actor/loss"] = float(actor_loss.detach())
+        log["train_actor/mean_entropy"] = float(ent.mean().detach())
+        self.actor_opt.zero_grad()
+        for t in critic.values():
+            t.grad = None
+        actor_loss.backward()
+        # actor_optimizer only owns actor.parameters(); grads that landed on critic-only tensors are dropped
+        self.actor_opt.step()
+        self.alpha_opt.zero_grad()
+        alpha_loss = (self.alpha * (-log_pi - self.target_entropy).detach()).mean()
+        log["train_alpha/loss"] = float(alpha_loss.detach())
+        log["train_alpha/value"] = float(self.alpha.detach())
+        alpha_loss.backward()
+        self.alpha_opt.step()
+
+    def soft_update_target(self, src=None):
+        src = self.critic if src is None else src
+        q = [n for n in self.critic_names if n.startswith("Q1.") or n.startswith("Q2.")]
+        e = [n for n in self.critic_names if n.startswith("encoder.")]
+        soft_update(src, self.critic_target, q, self.hp["critic_tau"])
+        soft_update(src, self.critic_target, e, self.hp["encoder_tau"])
+
+    # -- update() ---------------------------------------------------------------------------
+    def update(self, batch, step, noise_target, noise_actor=None, aug=None, shift=None, shift2=None):
+        """batch = (obs, action, reward, next_obs, not_done) float32 tensors.
+        aug(x): the RAD chain; shift(x)/shift2(x): random_shift with the caller's offsets
+        (shift2 is DrQ's second draw for next_obs)."""
+        obs, action, reward, next_obs, not_done = batch
+        log = {}
+        algo = self.algo
+        if algo in ("sac", "rad", "non_naive_rad"):
+            if algo in ("rad", "non_naive_rad"):
+                obs = aug(obs)
+            if algo == "rad":
+                next_obs = aug(next_obs)
+            y = self.target_q(next_obs, reward, not_done, noise_target)
+            q1, q2 = critic_forward(self.critic, obs, action, self.hp)
+            loss = self._mse2(q1, q2, y)
+            log["train_critic/loss"] = float(loss.detach())
+            self.critic_opt.zero_grad()
+            loss.backward()
+            self.critic_opt.step()
+            actor_obs = obs
+        elif algo == "svea":
+            obs = shift(obs)
+            y = self.target_q(next_obs, reward, not_done, noise_target)
+            q1, q2 = critic_forward(self.critic, obs, action, self.hp)
+            l_shift = self.hp["svea_alpha"] * self._mse2(q1, q2, y)
+            obs_aug = aug(obs.clone())
+            q1a, q2a = critic_forward(self.critic, obs_aug, action, self.hp)
+            l_aug = self.hp["svea_beta"] * self._mse2(q1a, q2a, y)
+            loss = l_shift + l_aug
+            log.update({"train_critic/shift_loss": float(l_shift.detach()), "train_critic/aug_loss": float(l_aug.detach()),
+                        "train_critic/loss": float(loss.detach())})
+            self.critic_opt.zero_grad()
+            loss.backward()
+            self.critic_opt.step()
+            actor_obs = obs
+        elif algo == "drq":  # K = M = 1 (arguments.py:66-67)
+            obs = shift(obs)
+            next_obs = shift2(next_obs)
+            y = self.target_q(next_obs, reward, not_done, noise_target)
+            q1, q2 = critic_forward(self.critic, obs, action, self.hp)
+            loss = self._mse2(q1, q2, y)
+            log["train_critic/loss"] = float(loss.detach())
+            self.critic_opt.zero_grad()
+            loss.backward()
+            self.critic_opt.step()
+            actor_obs = obs
+        elif algo == "augcl":
+            obs_shift = shift(obs)
+            obs_aug = aug(obs)  # on the UN-shifted obs (augcl.py:72)
+            y = self.target_q(next_obs, reward, not_done, noise_target)
+            q1, q2 = critic_forward(self.critic_weak, obs_shift, action, self.hp)
+            l_weak = self._mse2(q1, q2, y)
+            q1, q2 = critic_forward(self.critic, obs_aug, action, self.hp)
+            l_strong = self._mse2(q1, q2, y)
+            log["train_critic_weak/loss"] = float(l_weak.detach())
+            log["train_critic_strong/loss"] = float(l_strong.detach())
+            self.critic_weak_opt.zero_grad()
+            l_weak.backward()
+            self.critic_weak_opt.step()
+            self.critic_opt.zero_grad()
+            l_strong.backward()
+            self.critic_opt.step()
+            actor_obs = obs_aug
+        else:
+            raise KeyError(algo)
+        if step % self.hp["actor_update_freq"] == 0:
+            self.update_actor_and_alpha(actor_obs, noise_actor, log)
+        if step % self.hp["critic_target_update_freq"] == 0:
+            self.soft_update_target(self.critic_weak if algo == "augcl" else None)
+        return log
+
+
+def checksum(params, names):
+    """Small per-parameter fingerprint (sum, abs-sum, first 4 values) for golden comparison."""
+    out = []
+    for n in names:
+        t = params[n].detach().double().flatten()
+        out.append([float(t.sum()), float(t.abs().sum())] + [float(v) for v in t[:4]] + [0.0] * max(0, 4 - t.numel()))
+    return np.array(out, dtype=np.float64)

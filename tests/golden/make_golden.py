@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Mint golden vectors from the UNMODIFIED reference (build container only).
 
-Run:  PYTHONDONTWRITEBYTECODE=1 python3 -O tests/golden/make_golden.py [aug|nets|update|all]
+Run:  PYTHONDONTWRITEBYTECODE=1 python3 -O tests/golden/make_golden.py
 
 The reference (/root/reference/src) is imported on CPU with empty placeholder
 modules for the third-party packages that are absent here (torchvision, kornia,
@@ -206,9 +206,4 @@ def make_aug():
 
 
 if __name__ == "__main__":
-    what = sys.argv[1] if len(sys.argv) > 1 else "all"
-    if what in ("aug", "all"):
-        make_aug()
-    if what in ("nets", "update", "all"):
-        import make_golden_sac
-        make_golden_sac.main(what)
+    make_aug()  # networks / update() goldens: make_golden_sac.py (separate process)
