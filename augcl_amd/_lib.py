@@ -64,8 +64,16 @@ _SIGS = {
     "augcl_color_jitter_f32": [_P, _I, _I, _I, _I, _P, _I, _P, _D, _D, _D, _F, _F, _P],
     "augcl_shift_conv_u8_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _U64, _U64, _I, _P],
     "augcl_shift_conv_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _U64, _U64, _I, _P],
+    "augcl_adam_f32": [_P, _P, _P, _P, _SZ, _D, _D, _D, _D, _c.c_int64, _D, _P],
+    "augcl_ema_f32": [_P, _P, _SZ, _D, _P],
+    "augcl_enc_conv_first_forward": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
+    "augcl_enc_conv32_forward": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "augcl_enc_conv32_backward_data": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "augcl_enc_wgrad_workspace_bytes": [_I],
+    "augcl_enc_conv32_backward_weights": [_P, _P, _P, _P, _P, _SZ, _I, _I, _I, _P],
+    "augcl_enc_conv_first_backward_weights": [_P, _P, _P, _P, _P, _SZ, _I, _I, _I, _I, _I, _F, _P],
 }
-_RESTYPE = {"augcl_last_error": _c.c_char_p}
+_RESTYPE = {"augcl_last_error": _c.c_char_p, "augcl_enc_wgrad_workspace_bytes": _SZ}
 
 _lib = None
 

@@ -1,0 +1,177 @@
+"""SAC base agent (drop-in for src/algorithms/sac.py:9-164).
+
+Same attribute surface as the reference (actor, critic, critic_target, log_alpha, alpha,
+*_optimizer, train/eval, select_action/sample_action, update(replay_buffer, L, step)), different
+engine room: parameters of each optimiser group live in one flat buffer (flat.FlatGroup), the
+optimiser step and the target EMA are single fused HIP launches, the shared CNN runs as one HIP
+autograd node, and gradients can be exchanged data-parallel through one all-reduce per group.
+"""
+from copy import deepcopy
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .. import dist as apdist
+from .. import flat
+from . import modules as m
+
+
+def _device():
+    if not torch.cuda.is_available():
+        raise RuntimeError("augcl_amd agents need an MI355X: there is no CPU path")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+class SAC(object):
+    def __init__(self, obs_shape, action_shape, args):
+        self.discount = args.discount
+        self.critic_tau = args.critic_tau
+        self.encoder_tau = args.encoder_tau
+        self.actor_update_freq = args.actor_update_freq
+        self.critic_target_update_freq = args.critic_target_update_freq
+        dev = self.device = _device()
+
+        shared_cnn = m.SharedCNN(obs_shape, args.num_shared_layers, args.num_filters)
+        head_cnn = m.HeadCNN(shared_cnn.out_shape, args.num_head_layers, args.num_filters)
+        actor_encoder = m.Encoder(shared_cnn, head_cnn, m.RLProjection(head_cnn.out_shape, args.projection_dim))
+        critic_encoder = m.Encoder(shared_cnn, head_cnn, m.RLProjection(head_cnn.out_shape, args.projection_dim))
+        self.actor = m.Actor(actor_encoder, action_shape, args.hidden_dim, args.actor_log_std_min,
+                             args.actor_log_std_max).to(dev)
+        self.critic = m.Critic(critic_encoder, action_shape, args.hidden_dim).to(dev)
+        self.critic_target = deepcopy(self.critic)
+
+        self.log_alpha = torch.tensor(np.log(args.init_temperature), device=dev)  # float64 scalar, as sac.py:44
+        self.log_alpha.requires_grad = True
+        self.target_entropy = -np.prod(action_shape)
+
+        self._hp = dict(actor_lr=args.actor_lr, actor_beta=args.actor_beta, critic_lr=args.critic_lr,
+                        critic_beta=args.critic_beta, alpha_lr=args.alpha_lr, alpha_beta=args.alpha_beta)
+        self._build_groups()
+        self.train()
+        self.critic_target.train()
+
+    # ---- flat groups / optimisers ------------------------------------------------------------
+    def _build_groups(self):
+        hp = self._hp
+        reducer = apdist.default_reducer()
+        # critic group: CNN + critic projection + Q1 + Q2, in nn.Module.parameters() order
+        self.critic_group = flat.FlatGroup(self.critic.named_parameters())
+        # actor group: what the actor owns exclusively.  The reference's actor optimiser also lists the shared
+        # CNN tensors, but they never receive a gradient there (detach=True, sac.py:120) so it never moves them.
+        shared = {id(p) for p in self.critic.parameters()}
+        self.actor_group = flat.FlatGroup([(n, p) for n, p in self.actor.named_parameters() if id(p) not in shared])
+        self.target_group = flat.FlatGroup(self.critic_target.named_parameters())
+        assert self.target_group.names == self.critic_group.names
+        self.critic_optimizer = flat.FlatAdam(self.critic_group, hp["critic_lr"], (hp["critic_beta"], 0.999), reducer=reducer)
+        self.actor_optimizer = flat.FlatAdam(self.actor_group, hp["actor_lr"], (hp["actor_beta"], 0.999), reducer=reducer)
+        self.log_alpha_optimizer = torch.optim.Adam([self.log_alpha], lr=hp["alpha_lr"], betas=(hp["alpha_beta"], 0.999))
+        self._reducer = reducer
+
+    def train(self, training=True):
+        self.training = training
+        self.actor.train(training)
+        self.critic.train(training)
+
+    def eval(self):
+        self.train(False)
+
+    @property
+    def alpha(self):
+        return self.log_alpha.exp()
+
+    # ---- acting ------------------------------------------------------------------------------
+    def _obs_to_input(self, obs):
+        _obs = np.array(obs) if not isinstance(obs, (np.ndarray, torch.Tensor)) else obs
+        _obs = torch.as_tensor(_obs).to(self.device, dtype=torch.float32)
+        return _obs.unsqueeze(0).contiguous()
+
+    def select_action(self, obs):
+        _obs = self._obs_to_input(obs)
+        with torch.no_grad():
+            mu, _, _, _ = self.actor(_obs, compute_pi=False, compute_log_pi=False)
+        return mu.cpu().data.numpy().flatten()
+
+    def sample_action(self, obs):
+        _obs = self._obs_to_input(obs)
+        with torch.no_grad():
+            mu, pi, _, _ = self.actor(_obs, compute_log_pi=False)
+        return pi.cpu().data.numpy().flatten()
+
+    # ---- learning ----------------------------------------------------------------------------
+    def calculate_target_Q(self, next_obs, reward, not_done):
+        """sac.py:94-101"""
+        with torch.no_grad():
+            _, policy_action, log_pi, _ = self.actor(next_obs)
+            target_Q1, target_Q2 = self.critic_target(next_obs, policy_action)
+            target_V = torch.min(target_Q1, target_Q2) - self.alpha.detach() * log_pi
+            return reward + (not_done * self.discount * target_V)
+
+    @staticmethod
+    def _q_loss(q1, q2, target_Q):
+        return F.mse_loss(q1, target_Q) + F.mse_loss(q2, target_Q)
+
+    def _log(self, L, key, value, step):
+        if L is not None:
+            if self._reducer is not None and torch.is_tensor(value):
+                value = self._reducer.mean_scalar(value)
+            L.log(key, value, step)
+
+    def update_critic(self, obs, action, reward, next_obs, not_done, L=None, step=None):
+        """sac.py:103-117"""
+        target_Q = self.calculate_target_Q(next_obs=next_obs, reward=reward, not_done=not_done)
+        current_Q1, current_Q2 = self.critic(obs, action)
+        critic_loss = self._q_loss(current_Q1, current_Q2, target_Q)
+        self._log(L, "train_critic/loss", critic_loss, step)
+        self.critic_optimizer.zero_grad()
+        critic_loss.backward()
+        self.critic_optimizer.step()
+
+    def update_actor_and_alpha(self, obs, L=None, step=None, update_alpha=True, critic=None):
+        """sac.py:119-146.  The actor's and the critic's encoders share the CNN and see the same obs
+        with detach=True, so the CNN runs once (the reference runs it twice to the same values)."""
+        critic = self.critic if critic is None else critic
+        with torch.no_grad():
+            feat = self.actor.encoder.features(obs)
+        same_cnn = critic.encoder.shared_cnn is self.actor.encoder.shared_cnn
+        _, pi, log_pi, log_std = self.actor(obs, detach=True, features=feat)
+        actor_Q1, actor_Q2 = critic(obs, pi, detach=True, features=feat if same_cnn else None)
+        actor_Q = torch.min(actor_Q1, actor_Q2)
+        actor_loss = (self.alpha.detach() * log_pi - actor_Q).mean()
+        if L is not None:
+            entropy = 0.5 * log_std.shape[1] * (1.0 + np.log(2 * np.pi)) + log_std.sum(dim=-1)
+            self._log(L, "train_actor/loss", actor_loss, step)
+            self._log(L, "train_actor/mean_entropy", entropy.mean(), step)
+        self.actor_optimizer.zero_grad()
+        actor_loss.backward()
+        self.actor_optimizer.step()
+        if update_alpha:
+            self.log_alpha_optimizer.zero_grad()
+            alpha_loss = (self.alpha * (-log_pi - self.target_entropy).detach()).mean()
+            self._log(L, "train_alpha/loss", alpha_loss, step)
+            self._log(L, "train_alpha/value", self.alpha, step)
+            alpha_loss.backward()
+            if self._reducer is not None:
+                self._reducer.allreduce_mean_(self.log_alpha.grad)
+            self.log_alpha_optimizer.step()
+
+    def _soft_update_from(self, src_group):
+        """sac.py:148-153: Q1,Q2 with critic_tau, encoder (CNN + projection) with encoder_tau -- two fused
+        launches over the flat segments instead of ~40 per-tensor updates."""
+        tg = self.target_group
+        ea, eb = tg.segment("encoder.")
+        qa, qb = tg.segment("Q")
+        flat.ema_(tg.param, src_group.param, ea, eb, self.encoder_tau)
+        flat.ema_(tg.param, src_group.param, qa, qb, self.critic_tau)
+
+    def soft_update_critic_target(self):
+        self._soft_update_from(self.critic_group)
+
+    def update(self, replay_buffer, L, step):
+        """sac.py:155-164"""
+        obs, action, reward, next_obs, not_done = replay_buffer.sample()
+        self.update_critic(obs, action, reward, next_obs, not_done, L, step)
+        if step % self.actor_update_freq == 0:
+            self.update_actor_and_alpha(obs, L, step)
+        if step % self.critic_target_update_freq == 0:
+            self.soft_update_critic_target()

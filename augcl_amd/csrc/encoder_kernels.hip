@@ -1,0 +1,706 @@
+// encoder_kernels.hip -- the shared conv encoder (src/algorithms/modules.py:145-165) on CDNA4 matrix cores.
+//
+// Every 3x3 convolution of the stack (forward, backward-data, backward-weights) is a dense
+// contraction on v_mfma_f32_32x32x2_f32: exact f32 products / f32 accumulation (bitwise a k-ordered
+// fmaf chain), so the stack meets the 1e-5 parity budget while running on the MFMA pipe and leaving
+// the VALU free for staging and epilogues.
+//
+//   forward (32->32):   D[co][m] = sum_k W[co][k] * X[k][m],   k = (ci,ky,kx), m = output pixel
+//     A operand = weights, held in 144 VGPRs per lane for the whole launch (lane l: row co = l&31,
+//     k-half h = l>>5 takes input channels 16h..16h+15);  B operand = pixels, one ds_read_b32 per MFMA
+//     out of an LDS tile [32 ci][RT+2 rows][Wv] staged once per (image, row-strip).  The accumulator
+//     comes out with PIXELS on the lanes, so each store instruction writes two 128-B runs of one
+//     channel row: coalesced NCHW stores, bias / ReLU / ReLU-mask fused in the epilogue.
+//   backward-data:      the same kernel on the zero-padded dZ with W'[ci][co][ky][kx] = W[co][ci][2-ky][2-kx]
+//     (gathered straight from the forward weights) and the ReLU mask (a_prev > 0) in the epilogue.
+//   backward-weights:   D_t[co][ci] = sum_p dZ[co][p] * A[ci][p + tap_t] for the 9 taps (144 accumulators),
+//     persistent workgroups accumulate over their share of (image, strip) items in registers, write
+//     one partial slab each; a second kernel sums the slabs in a FIXED order (no atomics: bitwise
+//     reproducible gradients, SURVEY.md section 7 "hard parts").
+//   first layer (C->32, stride 2, fused x/255): same scheme with the input channels split in two halves
+//     of ceil(C/2) (one zero plane pads an odd C).
+#include "augcl_common.h"
+
+namespace augcl {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float div255e(float x)
+{
+    const float r = 1.0f / 255.0f;
+    const float q = x * r;
+    return __builtin_fmaf(__builtin_fmaf(-q, 255.0f, x), r, q); // == x / 255.0f for every finite x (see aug_kernels)
+}
+
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// =========================================================================================
+// 32 -> 32 channel 3x3 conv, stride 1.   MODE 0: forward (valid conv, + bias, optional ReLU)
+//                                         MODE 1: backward-data (full conv of dZ, * (a_prev > 0))
+// in : (B,32,Hi,Wi)   out: (B,32,Ho,Wo) with Ho = Hi + 2P - 2, P = (MODE ? 2 : 0)
+// One workgroup (4 waves) per item = (image, strip of RT output rows); persistent over items.
+// =========================================================================================
+struct ConvArgs {
+    const float *in;     // forward: a_{l-1} (post-ReLU);  bwd-data: dZ_l
+    const float *w;      // (32,32,3,3) forward weights
+    const float *bias;   // (32) or null                       [MODE 0]
+    const float *mask;   // a_{l-1} (B,32,Ho,Wo) or null       [MODE 1]
+    float *out;
+    int B, Hi, Wi, Ho, Wo, RT, S; // S strips per image
+    int relu;                     // MODE 0: apply ReLU to the output
+    int n_items;                  // B * S
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void k_conv32(ConvArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[]; // [32][RT+2][Wv]
+    constexpr int P = MODE ? 2 : 0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int Wv = a.Wi + 2 * P;              // virtual (padded) input width = LDS row stride
+    const int plane = (a.RT + 2) * Wv;        // LDS words per channel
+
+    // ---- per-lane weights, resident for the whole launch: wreg[cil*9 + t] = Weff[row l31][col cil+16h][t]
+    float wreg[144];
+    {
+        if (MODE == 0) {
+            const float *wp = a.w + (size_t)l31 * 288 + h * 144; // contiguous 144 floats
+#pragma unroll
+            for (int k = 0; k < 144; k += 4) {
+                const float4 v = *reinterpret_cast<const float4 *>(wp + k);
+                wreg[k] = v.x; wreg[k + 1] = v.y; wreg[k + 2] = v.z; wreg[k + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int cil = 0; cil < 16; ++cil)
+#pragma unroll
+                for (int t = 0; t < 9; ++t) // W'[ci=l31][co=cil+16h][ky][kx] = W[co][ci][2-ky][2-kx]
+                    wreg[cil * 9 + t] = a.w[(size_t)(cil + 16 * h) * 288 + l31 * 9 + (8 - t)];
+        }
+    }
+    float bias_r[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bias_r[r] = (MODE == 0 && a.bias) ? a.bias[acc_row(r, h)] : 0.0f;
+
+    for (int item = blockIdx.x; item < a.n_items; item += gridDim.x) {
+        const int b = item / a.S, s = item - b * a.S;
+        const int y0 = s * a.RT;
+        const int rows = min(a.RT, a.Ho - y0); // output rows of this strip
+        const int npix = rows * a.Wo;
+        // ---- stage the input rows y0-P .. y0+rows+1-P of all 32 channels (zeros outside the image)
+        __syncthreads(); // previous item's readers are done with the tile
+        {
+            // division-free: wave w copies channels w, w+4, ...; a channel's rows are one contiguous run
+            const int nrow = rows + 2;
+            const float *src = a.in + (size_t)b * 32 * a.Hi * a.Wi;
+            if (MODE == 0) {
+                const int run = nrow * a.Wi; // Wv == Wi: the LDS plane mirrors memory
+                for (int ci = wave; ci < 32; ci += 4) {
+                    const float *g = src + ((size_t)ci * a.Hi + y0) * a.Wi;
+                    float *d = lds + ci * plane;
+                    for (int j = lane; j < run; j += 64) d[j] = g[j];
+                }
+            } else {
+                for (int j = tid; j < 32 * plane; j += 256) lds[j] = 0.0f; // zero padding (and halo outside dZ)
+                __syncthreads();
+                const int r_lo = max(0, P - y0), r_hi = min(nrow, a.Hi + P - y0); // rows with y0 + r - P inside dZ
+                for (int ci = wave; ci < 32; ci += 4)
+                    for (int r = r_lo; r < r_hi; ++r) {
+                        const float *g = src + ((size_t)ci * a.Hi + (y0 + r - P)) * a.Wi;
+                        float *d = lds + ci * plane + r * Wv + P;
+                        for (int x = lane; x < a.Wi; x += 64) d[x] = g[x];
+                    }
+            }
+        }
+        __syncthreads();
+        // ---- M-tiles of 32 consecutive strip pixels, round-robin over the 4 waves
+        const int ntiles = (npix + 31) >> 5;
+        for (int tile = wave; tile < ntiles; tile += 4) {
+            int m = tile * 32 + l31;
+            const bool valid = m < npix;
+            if (!valid) m = npix - 1; // read a real pixel, discard the result
+            const int yy = m / a.Wo, xx = m - yy * a.Wo;
+            const float *base = lds + (yy * Wv + xx) + h * 16 * plane;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = bias_r[r];
+#pragma unroll
+            for (int cil = 0; cil < 16; ++cil) {
+                const float *pc = base + cil * plane;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx)
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[cil * 9 + ky * 3 + kx], pc[ky * Wv + kx], acc,
+                                                                   0, 0, 0);
+            }
+            if (valid) {
+                const int y = y0 + yy;
+                const size_t o0 = ((size_t)b * 32 * a.Ho + y) * a.Wo + xx;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const size_t o = o0 + (size_t)acc_row(r, h) * a.Ho * a.Wo;
+                    float v = acc[r];
+                    if (MODE == 0) {
+                        if (a.relu) v = fmaxf(v, 0.0f);
+                    } else if (a.mask) {
+                        v = a.mask[o] > 0.0f ? v : 0.0f;
+                    }
+                    a.out[o] = v;
+                }
+            }
+        }
+    }
+}
+
+// =========================================================================================
+// first layer: C -> 32, 3x3, stride 2, input divided by `scale` (255) at staging.
+// channel halves: CH = ceil(C/2); lane half h takes channels h*CH .. h*CH+CH-1 (zero plane if >= C)
+// =========================================================================================
+struct Conv1Args {
+    const float *in; // (B,C,Hi,Wi) raw 0..255
+    const float *w;  // (32,C,3,3)
+    const float *bias;
+    float *out;      // (B,32,Ho,Wo)
+    int B, C, Hi, Wi, Ho, Wo, RT, S, relu, n_items, stride;
+    float scale;
+};
+
+template <int CH> // CH*9 MFMA steps
+__global__ __launch_bounds__(256, 2) void k_conv_first(Conv1Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[]; // [2*CH][rows_in][Wi]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int st = a.stride;
+    const int rows_in_max = st * (a.RT - 1) + 3;
+    const int plane = rows_in_max * a.Wi;
+    float wreg[CH * 9];
+#pragma unroll
+    for (int cil = 0; cil < CH; ++cil) {
+        const int c = cil + CH * h;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wreg[cil * 9 + t] = c < a.C ? a.w[((size_t)l31 * a.C + c) * 9 + t] : 0.0f;
+    }
+    float bias_r[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bias_r[r] = a.bias ? a.bias[acc_row(r, h)] : 0.0f;
+
+    for (int item = blockIdx.x; item < a.n_items; item += gridDim.x) {
+        const int b = item / a.S, s = item - b * a.S;
+        const int y0 = s * a.RT;
+        const int rows = min(a.RT, a.Ho - y0);
+        const int npix = rows * a.Wo;
+        const int rows_in = st * (rows - 1) + 3;
+        __syncthreads();
+        {
+            const int run = rows_in * a.Wi;
+            const float *src = a.in + (size_t)b * a.C * a.Hi * a.Wi;
+            const bool unit = a.scale == 1.0f, is255 = a.scale == 255.0f;
+            for (int c = wave; c < 2 * CH; c += 4) {
+                float *d = lds + c * plane;
+                if (c < a.C) {
+                    const float *g = src + ((size_t)c * a.Hi + st * y0) * a.Wi;
+                    for (int j = lane; j < run; j += 64) {
+                        const float v = g[j];
+                        d[j] = unit ? v : (is255 ? div255e(v) : v / a.scale);
+                    }
+                } else {
+                    for (int j = lane; j < run; j += 64) d[j] = 0.0f; // pad plane: finite zeros (0 * NaN would poison)
+                }
+            }
+        }
+        __syncthreads();
+        const int ntiles = (npix + 31) >> 5;
+        for (int tile = wave; tile < ntiles; tile += 4) {
+            int m = tile * 32 + l31;
+            const bool valid = m < npix;
+            if (!valid) m = npix - 1;
+            const int yy = m / a.Wo, xx = m - yy * a.Wo;
+            const float *base = lds + (st * yy * a.Wi + st * xx) + h * CH * plane;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = bias_r[r];
+#pragma unroll
+            for (int cil = 0; cil < CH; ++cil) {
+                const float *pc = base + cil * plane;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx)
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[cil * 9 + ky * 3 + kx], pc[ky * a.Wi + kx], acc,
+                                                                   0, 0, 0);
+            }
+            if (valid) {
+                const size_t o0 = ((size_t)b * 32 * a.Ho + (y0 + yy)) * a.Wo + xx;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[r];
+                    if (a.relu) v = fmaxf(v, 0.0f);
+                    a.out[o0 + (size_t)acc_row(r, h) * a.Ho * a.Wo] = v;
+                }
+            }
+        }
+    }
+}
+
+// =========================================================================================
+// backward-weights, 32 -> 32 layer:  dW[co][ci][t] = sum_{b,y,x} dZ[b,co,y,x] * A[b,ci,y+ky,x+kx]
+//                                     db[co]       = sum dZ[b,co,y,x]
+// LDS: A tile [32][RT+2][Wi] (plane stride odd: lanes = channels read one pixel -> conflict-free)
+//      Z tile [32][RT][Wo]    (plane stride odd)
+// each wave walks pixel PAIRS (lane half h = pixel p+h); 9 MFMAs per pair into 9 accumulator tiles.
+// =========================================================================================
+struct WgradArgs {
+    const float *act; // A = a_{l-1} (B,32,Hi,Wi)
+    const float *dz;  // (B,32,Ho,Wo)
+    float *partial;   // [gridDim.x][32*288 + 32]
+    int B, Hi, Wi, Ho, Wo, RT, S, n_items;
+};
+
+constexpr int WG_SLAB = 32 * 288 + 32;
+
+__global__ __launch_bounds__(256, 1) void k_wgrad32(WgradArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int planeA = ((a.RT + 2) * a.Wi) | 1;
+    const int planeZ = (a.RT * a.Wo) | 1;
+    float *ldsA = lds;
+    float *ldsZ = lds + 32 * planeA;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    float dbacc = 0.0f;
+
+    for (int item = blockIdx.x; item < a.n_items; item += gridDim.x) {
+        const int b = item / a.S, s = item - b * a.S;
+        const int y0 = s * a.RT;
+        const int rows = min(a.RT, a.Ho - y0);
+        const int npix = rows * a.Wo;
+        __syncthreads();
+        {
+            const int runA = (rows + 2) * a.Wi;
+            const float *src = a.act + (size_t)b * 32 * a.Hi * a.Wi;
+            const float *sz = a.dz + (size_t)b * 32 * a.Ho * a.Wo;
+            for (int c = wave; c < 32; c += 4) {
+                const float *g = src + ((size_t)c * a.Hi + y0) * a.Wi; // rows contiguous in NCHW
+                float *d = ldsA + c * planeA;
+                for (int j = lane; j < runA; j += 64) d[j] = g[j];
+                const float *gz = sz + ((size_t)c * a.Ho + y0) * a.Wo;
+                float *dzl = ldsZ + c * planeZ;
+                for (int j = lane; j < npix; j += 64) dzl[j] = gz[j];
+            }
+        }
+        __syncthreads();
+        const int npair = (npix + 1) >> 1;
+        for (int pr = wave; pr < npair; pr += 4) {
+            int p = 2 * pr + h;
+            const bool valid = p < npix;
+            if (!valid) p = npix - 1;
+            const int yy = p / a.Wo, xx = p - yy * a.Wo;
+            float z = ldsZ[l31 * planeZ + p];
+            if (!valid) z = 0.0f;
+            dbacc += z;
+            const float *pa = ldsA + l31 * planeA + yy * a.Wi + xx;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+                    acc[ky * 3 + kx] =
+                        __builtin_amdgcn_mfma_f32_32x32x2f32(z, pa[ky * a.Wi + kx], acc[ky * 3 + kx], 0, 0, 0);
+        }
+    }
+    // ---- fixed-order reduction over the 4 waves through LDS, then one slab per workgroup
+    // lane (ci = l31, h) holds dW[co = acc_row(r,h)][ci][t] in acc[t][r]
+    __syncthreads();
+    float *slab = a.partial + (size_t)blockIdx.x * WG_SLAB;
+    for (int w = 1; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) lds[(t * 16 + r) * 64 + lane] = acc[t][r];
+            lds[144 * 64 + lane] = dbacc;
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] += lds[(t * 16 + r) * 64 + lane];
+            dbacc += lds[144 * 64 + lane];
+        }
+        __syncthreads();
+    }
+    if (wave == 0) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) slab[(size_t)acc_row(r, h) * 288 + l31 * 9 + t] = acc[t][r];
+        // db: lanes (co = l31, h = 0/1) hold the sums over even / odd pixels
+        const float other = __shfl_xor(dbacc, 32, 64);
+        if (h == 0) slab[32 * 288 + l31] = dbacc + other;
+    }
+}
+
+// first layer: dW1[co][c][t] = sum dZ[co][p] * X[c][st*y+ky][st*x+kx]/scale ; n = c*9+t over NT n-tiles of 32
+struct Wgrad1Args {
+    const float *x;  // (B,C,Hi,Wi) raw
+    const float *dz; // (B,32,Ho,Wo)
+    float *partial;  // [gridDim.x][32*C*9 + 32]
+    int B, C, Hi, Wi, Ho, Wo, RT, S, n_items, stride;
+    float scale;
+};
+
+template <int NT>
+__global__ __launch_bounds__(256, 1) void k_wgrad_first(Wgrad1Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int st = a.stride;
+    const int rows_in_max = st * (a.RT - 1) + 3;
+    const int planeX = rows_in_max * a.Wi;
+    const int planeZ = (a.RT * a.Wo) | 1;
+    float *ldsX = lds;
+    float *ldsZ = lds + a.C * planeX;
+    const int K = a.C * 9;
+    int noff[NT]; // LDS offset of column n = l31 + 32 j: (c, ky, kx); invalid n -> offset 0 with weight masked
+    bool nval[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = l31 + 32 * j;
+        nval[j] = n < K;
+        const int nn = nval[j] ? n : 0;
+        const int c = nn / 9, t = nn - c * 9;
+        noff[j] = c * planeX + (t / 3) * a.Wi + (t % 3);
+    }
+    f32x16 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+    float dbacc = 0.0f;
+
+    for (int item = blockIdx.x; item < a.n_items; item += gridDim.x) {
+        const int b = item / a.S, s = item - b * a.S;
+        const int y0 = s * a.RT;
+        const int rows = min(a.RT, a.Ho - y0);
+        const int npix = rows * a.Wo;
+        const int rows_in = st * (rows - 1) + 3;
+        __syncthreads();
+        {
+            const int run = rows_in * a.Wi;
+            const float *src = a.x + (size_t)b * a.C * a.Hi * a.Wi;
+            const bool unit = a.scale == 1.0f, is255 = a.scale == 255.0f;
+            for (int c = wave; c < a.C; c += 4) {
+                const float *g = src + ((size_t)c * a.Hi + st * y0) * a.Wi;
+                float *d = ldsX + c * planeX;
+                for (int j = lane; j < run; j += 64) {
+                    const float v = g[j];
+                    d[j] = unit ? v : (is255 ? div255e(v) : v / a.scale);
+                }
+            }
+            const float *sz = a.dz + (size_t)b * 32 * a.Ho * a.Wo;
+            for (int c = wave; c < 32; c += 4) {
+                const float *gz = sz + ((size_t)c * a.Ho + y0) * a.Wo;
+                float *dzl = ldsZ + c * planeZ;
+                for (int j = lane; j < npix; j += 64) dzl[j] = gz[j];
+            }
+        }
+        __syncthreads();
+        const int npair = (npix + 1) >> 1;
+        for (int pr = wave; pr < npair; pr += 4) {
+            int p = 2 * pr + h;
+            const bool valid = p < npix;
+            if (!valid) p = npix - 1;
+            const int yy = p / a.Wo, xx = p - yy * a.Wo;
+            float z = ldsZ[l31 * planeZ + p];
+            if (!valid) z = 0.0f;
+            dbacc += z;
+            const float *px = ldsX + st * yy * a.Wi + st * xx;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const float xv = nval[j] ? px[noff[j]] : 0.0f;
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(z, xv, acc[j], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();
+    const int slab_sz = 32 * K + 32;
+    float *slab = a.partial + (size_t)blockIdx.x * slab_sz;
+    for (int w = 1; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) lds[(j * 16 + r) * 64 + lane] = acc[j][r];
+            lds[NT * 16 * 64 + lane] = dbacc;
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][r] += lds[(j * 16 + r) * 64 + lane];
+            dbacc += lds[NT * 16 * 64 + lane];
+        }
+        __syncthreads();
+    }
+    if (wave == 0) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = l31 + 32 * j;
+            if (n < K)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) slab[(size_t)acc_row(r, h) * K + n] = acc[j][r];
+        }
+        const float other = __shfl_xor(dbacc, 32, 64);
+        if (h == 0) slab[32 * K + l31] = dbacc + other;
+    }
+}
+
+// sum the per-workgroup slabs in a fixed order: out[i] = sum_g partial[g][i]  (i < n)
+__global__ __launch_bounds__(256) void k_reduce_slabs(const float *__restrict__ partial, int nslab, int n,
+                                                      float *__restrict__ out_w, int n_w, float *__restrict__ out_b)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int g = 0;
+    for (; g + 3 < nslab; g += 4) {
+        s0 += partial[(size_t)g * n + i];
+        s1 += partial[(size_t)(g + 1) * n + i];
+        s2 += partial[(size_t)(g + 2) * n + i];
+        s3 += partial[(size_t)(g + 3) * n + i];
+    }
+    for (; g < nslab; ++g) s0 += partial[(size_t)g * n + i];
+    const float s = (s0 + s1) + (s2 + s3);
+    if (i < n_w) out_w[i] = s;
+    else out_b[i - n_w] = s;
+}
+
+} // namespace augcl
+
+// =========================================================================================
+// C ABI
+// =========================================================================================
+using namespace augcl;
+
+namespace {
+
+constexpr int kMaxLds = 76 * 1024; // two workgroups per CU within the 160 KiB LDS
+
+int pick_rt(int Ho, int words_per_row_pair /* LDS words per output row (all planes) */, int extra_rows,
+            int max_lds_bytes, int *S)
+{
+    // largest RT with (RT + extra_rows) * words <= budget, then balance the strips
+    int rt = max_lds_bytes / 4 / words_per_row_pair - extra_rows;
+    if (rt < 1) return 0;
+    if (rt > Ho) rt = Ho;
+    const int s = (Ho + rt - 1) / rt;
+    rt = (Ho + s - 1) / s;
+    *S = s;
+    return rt;
+}
+
+template <typename K>
+int set_lds(K kern, size_t bytes, const char *name)
+{
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)bytes);
+    if (e != hipSuccess) return augcl::fail(AUGCL_E_LAUNCH, "%s: cannot set dynamic LDS %zu: %s", name, bytes,
+                                            hipGetErrorString(e));
+    return AUGCL_OK;
+}
+
+int grid_for(int n_items, int per_cu)
+{
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    const int g = cus * per_cu;
+    return n_items < g ? n_items : g;
+}
+
+} // namespace
+
+extern "C" {
+
+int augcl_enc_conv32_forward(const float *in, const float *w, const float *bias, float *out, int B, int Hi, int Wi,
+                             int relu, augcl_stream_t stream)
+{
+    const char *name = "augcl_enc_conv32_forward";
+    AUGCL_REQUIRE(B >= 0 && Hi >= 3 && Wi >= 3, "%s: bad shape", name);
+    if (B == 0) return AUGCL_OK;
+    AUGCL_REQUIRE(in && w && out, "%s: null tensor", name);
+    AUGCL_REQUIRE(aligned16(w), "%s: weights must be 16-byte aligned", name);
+    ConvArgs a{};
+    a.in = in; a.w = w; a.bias = bias; a.mask = nullptr; a.out = out;
+    a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ho = Hi - 2; a.Wo = Wi - 2; a.relu = relu;
+    a.RT = pick_rt(a.Ho, 32 * Wi, 2, kMaxLds, &a.S);
+    AUGCL_REQUIRE(a.RT > 0, "%s: image row too wide for LDS (W=%d)", name, Wi);
+    a.n_items = B * a.S;
+    const size_t lds = (size_t)32 * (a.RT + 2) * Wi * 4;
+    if (int rc = set_lds(k_conv32<0>, lds, name)) return rc;
+    hipLaunchKernelGGL(k_conv32<0>, dim3(grid_for(a.n_items, 2)), dim3(256), lds, as_stream(stream), a);
+    return augcl::check_launch(name);
+}
+
+int augcl_enc_conv32_backward_data(const float *dz, const float *w, const float *act_prev, float *dact, int B,
+                                   int Ho, int Wo, augcl_stream_t stream)
+{
+    const char *name = "augcl_enc_conv32_backward_data";
+    AUGCL_REQUIRE(B >= 0 && Ho >= 1 && Wo >= 1, "%s: bad shape", name);
+    if (B == 0) return AUGCL_OK;
+    AUGCL_REQUIRE(dz && w && dact, "%s: null tensor", name);
+    ConvArgs a{};
+    a.in = dz; a.w = w; a.bias = nullptr; a.mask = act_prev; a.out = dact;
+    a.B = B; a.Hi = Ho; a.Wi = Wo; a.Ho = Ho + 2; a.Wo = Wo + 2; a.relu = 0;
+    const int Wv = Wo + 4;
+    a.RT = pick_rt(a.Ho, 32 * Wv, 2, kMaxLds, &a.S);
+    AUGCL_REQUIRE(a.RT > 0, "%s: image row too wide for LDS (W=%d)", name, Wo);
+    a.n_items = B * a.S;
+    const size_t lds = (size_t)32 * (a.RT + 2) * Wv * 4;
+    if (int rc = set_lds(k_conv32<1>, lds, name)) return rc;
+    hipLaunchKernelGGL(k_conv32<1>, dim3(grid_for(a.n_items, 2)), dim3(256), lds, as_stream(stream), a);
+    return augcl::check_launch(name);
+}
+
+int augcl_enc_conv_first_forward(const float *in, const float *w, const float *bias, float *out, int B, int C, int Hi,
+                                 int Wi, int stride, float scale, int relu, augcl_stream_t stream)
+{
+    const char *name = "augcl_enc_conv_first_forward";
+    AUGCL_REQUIRE(B >= 0 && C >= 1 && Hi >= 3 && Wi >= 3 && (stride == 1 || stride == 2) && scale > 0.0f,
+                  "%s: bad shape", name);
+    if (B == 0) return AUGCL_OK;
+    AUGCL_REQUIRE(in && w && out, "%s: null tensor", name);
+    Conv1Args a{};
+    a.in = in; a.w = w; a.bias = bias; a.out = out;
+    a.B = B; a.C = C; a.Hi = Hi; a.Wi = Wi; a.stride = stride; a.scale = scale; a.relu = relu;
+    a.Ho = (Hi - 3) / stride + 1; a.Wo = (Wi - 3) / stride + 1;
+    const int CH = (C + 1) / 2;
+    // LDS rows per strip: stride*(RT-1)+3 for 2*CH planes
+    int rt = (kMaxLds / 4 / (2 * CH * Wi) - 3) / stride + 1;
+    AUGCL_REQUIRE(rt >= 1, "%s: image row too wide for LDS", name);
+    if (rt > a.Ho) rt = a.Ho;
+    a.S = (a.Ho + rt - 1) / rt;
+    a.RT = (a.Ho + a.S - 1) / a.S;
+    a.n_items = B * a.S;
+    const size_t lds = (size_t)2 * CH * (stride * (a.RT - 1) + 3) * Wi * 4;
+    hipStream_t s = as_stream(stream);
+#define LAUNCH_FIRST(CHV)                                                                     \
+    do {                                                                                      \
+        if (int rc = set_lds(k_conv_first<CHV>, lds, name)) return rc;                        \
+        hipLaunchKernelGGL(k_conv_first<CHV>, dim3(grid_for(a.n_items, 2)), dim3(256), lds, s, a); \
+    } while (0)
+    switch (CH) {
+    case 1: LAUNCH_FIRST(1); break;
+    case 2: LAUNCH_FIRST(2); break;
+    case 3: LAUNCH_FIRST(3); break;
+    case 5: LAUNCH_FIRST(5); break;
+    case 6: LAUNCH_FIRST(6); break;
+    case 8: LAUNCH_FIRST(8); break;
+    default:
+        return augcl::fail(AUGCL_E_UNSUPPORTED, "%s: %d input channels not instantiated (have 1-6, 9-12, 15-16)", name, C);
+    }
+#undef LAUNCH_FIRST
+    return augcl::check_launch(name);
+}
+
+size_t augcl_enc_wgrad_workspace_bytes(int C)
+{
+    // slabs for up to 256 CUs x 1 workgroup; C = input channels of the layer (32 for inner layers)
+    return (size_t)256 * ((size_t)32 * C * 9 + 32) * sizeof(float);
+}
+
+int augcl_enc_conv32_backward_weights(const float *act_prev, const float *dz, float *dw, float *db, float *workspace,
+                                      size_t workspace_bytes, int B, int Hi, int Wi, augcl_stream_t stream)
+{
+    const char *name = "augcl_enc_conv32_backward_weights";
+    AUGCL_REQUIRE(B >= 1 && Hi >= 3 && Wi >= 3, "%s: bad shape", name);
+    AUGCL_REQUIRE(act_prev && dz && dw && db && workspace, "%s: null tensor", name);
+    WgradArgs a{};
+    a.act = act_prev; a.dz = dz; a.partial = workspace;
+    a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ho = Hi - 2; a.Wo = Wi - 2;
+    // LDS words per output row: A rows (32*Wi) + Z rows (32*Wo); +2 halo rows of A; + slack for the odd strides
+    const int budget = 150 * 1024; // one workgroup per CU: 144 accumulators leave no room for a second
+    int rt = (budget / 4 - 64 * Wi - 64) / (32 * Wi + 32 * a.Wo);
+    AUGCL_REQUIRE(rt >= 1, "%s: image row too wide for LDS", name);
+    if (rt > a.Ho) rt = a.Ho;
+    a.S = (a.Ho + rt - 1) / rt;
+    a.RT = (a.Ho + a.S - 1) / a.S;
+    a.n_items = B * a.S;
+    const int planeA = ((a.RT + 2) * Wi) | 1, planeZ = (a.RT * a.Wo) | 1;
+    size_t lds = (size_t)(32 * planeA + 32 * planeZ) * 4;
+    const size_t red = (size_t)(145 * 64) * 4; // wave-reduction scratch reuses the tile
+    if (lds < red) lds = red;
+    const int grid = grid_for(a.n_items, 1);
+    AUGCL_REQUIRE(workspace_bytes >= (size_t)grid * WG_SLAB * 4, "%s: workspace too small (%zu < %zu)", name,
+                  workspace_bytes, (size_t)grid * WG_SLAB * 4);
+    if (int rc = set_lds(k_wgrad32, lds, name)) return rc;
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(k_wgrad32, dim3(grid), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(k_reduce_slabs, dim3((WG_SLAB + 255) / 256), dim3(256), 0, s, workspace, grid, WG_SLAB, dw,
+                       32 * 288, db);
+    return augcl::check_launch(name);
+}
+
+int augcl_enc_conv_first_backward_weights(const float *x, const float *dz, float *dw, float *db, float *workspace,
+                                          size_t workspace_bytes, int B, int C, int Hi, int Wi, int stride, float scale,
+                                          augcl_stream_t stream)
+{
+    const char *name = "augcl_enc_conv_first_backward_weights";
+    AUGCL_REQUIRE(B >= 1 && C >= 1 && Hi >= 3 && Wi >= 3 && (stride == 1 || stride == 2) && scale > 0.0f,
+                  "%s: bad shape", name);
+    AUGCL_REQUIRE(x && dz && dw && db && workspace, "%s: null tensor", name);
+    Wgrad1Args a{};
+    a.x = x; a.dz = dz; a.partial = workspace;
+    a.B = B; a.C = C; a.Hi = Hi; a.Wi = Wi; a.stride = stride; a.scale = scale;
+    a.Ho = (Hi - 3) / stride + 1; a.Wo = (Wi - 3) / stride + 1;
+    const int budget = 150 * 1024;
+    // words: X planes C*(stride*(RT-1)+3)*Wi + Z planes 32*(RT*Wo|1)
+    int rt = (budget / 4 - 3 * C * Wi - 64) / (C * stride * Wi + 32 * a.Wo);
+    AUGCL_REQUIRE(rt >= 1, "%s: image row too wide for LDS", name);
+    if (rt > a.Ho) rt = a.Ho;
+    a.S = (a.Ho + rt - 1) / rt;
+    a.RT = (a.Ho + a.S - 1) / a.S;
+    a.n_items = B * a.S;
+    const int K = C * 9;
+    const int NT = (K + 31) / 32;
+    const int planeX = (stride * (a.RT - 1) + 3) * Wi, planeZ = (a.RT * a.Wo) | 1;
+    size_t lds = (size_t)(C * planeX + 32 * planeZ) * 4;
+    const size_t red = (size_t)((NT * 16 + 1) * 64) * 4;
+    if (lds < red) lds = red;
+    const int grid = grid_for(a.n_items, 1);
+    const int slab = 32 * K + 32;
+    AUGCL_REQUIRE(workspace_bytes >= (size_t)grid * slab * 4, "%s: workspace too small", name);
+    hipStream_t s = as_stream(stream);
+#define LAUNCH_WG1(NTV)                                                      \
+    do {                                                                     \
+        if (int rc = set_lds(k_wgrad_first<NTV>, lds, name)) return rc;      \
+        hipLaunchKernelGGL(k_wgrad_first<NTV>, dim3(grid), dim3(256), lds, s, a); \
+    } while (0)
+    switch (NT) {
+    case 1: LAUNCH_WG1(1); break;
+    case 2: LAUNCH_WG1(2); break;
+    case 3: LAUNCH_WG1(3); break;
+    case 4: LAUNCH_WG1(4); break;
+    case 5: LAUNCH_WG1(5); break;
+    default:
+        return augcl::fail(AUGCL_E_UNSUPPORTED, "%s: %d input channels not supported (max 17)", name, C);
+    }
+#undef LAUNCH_WG1
+    hipLaunchKernelGGL(k_reduce_slabs, dim3((slab + 255) / 256), dim3(256), 0, s, workspace, grid, slab, dw, 32 * K, db);
+    return augcl::check_launch(name);
+}
+
+} // extern "C"

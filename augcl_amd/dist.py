@@ -1,0 +1,94 @@
+"""Data parallelism for the update(): one process per GPU, batch sharded over ranks, every rank a full
+replica; per optimiser step ONE sum all-reduce of the group's flat gradient bucket (RCCL over xGMI,
+`backend="nccl"` on ROCm), the 1/world_size folded into the fused Adam kernel.  No collective exists
+on the augmentation path (samples are independent; in-kernel Philox parameters are keyed by the GLOBAL
+sample index so results do not depend on the sharding).
+
+The reference has no distributed code at all: F.mse_loss / .mean() are batch means
+(src/algorithms/sac.py:109,124,139) and LayerNorm is per-sample, so equal shards + gradient averaging
+reproduce the full-batch gradient up to summation order.
+
+Works on any device torch.distributed supports: the CPU/gloo tests exercise exactly this code.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+_default = None
+
+
+class GradReducer:
+    def __init__(self, group=None):
+        assert dist.is_initialized(), "init torch.distributed first (dist.init_from_env)"
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self._scalars = None
+
+    def allreduce_sum_(self, flat_grad):
+        """In-place SUM over ranks of one flat bucket; returns the scale (1/world) the caller must apply."""
+        if self.world > 1:
+            dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+        return 1.0 / self.world
+
+    def allreduce_mean_(self, t):
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            t.div_(self.world)
+        return t
+
+    def mean_scalar(self, value):
+        """Mean over ranks of a logged scalar (each rank logs its shard's mean)."""
+        if self.world == 1:
+            return value
+        v = value.detach().clone().to(torch.float64).reshape(1)
+        dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group)
+        return (v / self.world).reshape(())
+
+    def shard(self, n):
+        """[begin, end) of this rank's slice of a global batch of n samples."""
+        per = n // self.world
+        assert per * self.world == n, f"global batch {n} not divisible by world size {self.world}"
+        return self.rank * per, (self.rank + 1) * per
+
+    def broadcast_(self, flat_param, src=0):
+        """Make replicas identical at start-up."""
+        if self.world > 1:
+            dist.broadcast(flat_param, src=src, group=self.group)
+
+    def __getstate__(self):  # agents are pickled whole (torch.save(agent), src/train.py:229)
+        return {}
+
+    def __setstate__(self, state):
+        self.group, self.world, self.rank, self._scalars = None, 1, 0, None
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun).  Returns the reducer
+    (None for a single process)."""
+    global _default
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        _default = None
+        return None
+    if not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kw = {}
+        if backend == "nccl":
+            dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+            torch.cuda.set_device(dev)
+            kw["device_id"] = dev
+        dist.init_process_group(backend, **kw)
+    _default = GradReducer()
+    return _default
+
+
+def set_default_reducer(r):
+    global _default
+    _default = r
+
+
+def default_reducer():
+    return _default

@@ -1,0 +1,44 @@
+"""conv_stack: the shared conv encoder (x/scale -> conv3x3(stride s) -> [ReLU -> conv3x3]*) as ONE op.
+
+Backends
+  "hip"   (default, the product): hand-written gfx950 kernels behind the C ABI
+          (augcl_enc_* in include/augcl.h): f32 MFMA implicit-GEMM forward / backward-data /
+          backward-weights with fused /255, bias, ReLU and ReLU-mask epilogues; one autograd node
+          for the whole stack, activations kept post-ReLU in a per-call workspace.
+  "torch" developer baseline for A/B timing only (ATen/MIOpen convs on the GPU); selected with
+          AUGCL_ENCODER=torch.  Never a fallback: if the HIP path is selected and the library or a
+          GPU is missing, the op raises.
+"""
+import os
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+
+BACKEND = os.environ.get("AUGCL_ENCODER", "hip")
+
+
+def set_backend(name):
+    global BACKEND
+    assert name in ("hip", "torch")
+    BACKEND = name
+
+
+def _conv_stack_torch(x, weights, biases, first_stride, input_scale, relu_first):
+    h = x / input_scale if input_scale != 1.0 else x
+    for i, (w, b) in enumerate(zip(weights, biases)):
+        if i > 0 or relu_first:
+            h = torch.relu(h)
+        h = F.conv2d(h, w, b, stride=first_stride if i == 0 else 1)
+    return h
+
+
+def conv_stack(x, weights, biases, first_stride=2, input_scale=255.0, relu_first=False):
+    """x: (B,C,H,W) f32 (0..255 when input_scale=255).  Returns the last conv's output (no final ReLU)."""
+    if BACKEND == "torch":
+        return _conv_stack_torch(x, weights, biases, first_stride, input_scale, relu_first)
+    _lib.require_cuda(x, "conv_stack input")
+    from . import encoder_hip
+    return encoder_hip.ConvStackFn.apply(x, first_stride, float(input_scale), bool(relu_first), len(weights),
+                                         *weights, *biases)

@@ -1,0 +1,101 @@
+"""Flat parameter groups: every optimiser group of an agent (critic, actor-only parameters)
+lives in ONE contiguous f32 buffer with a same-shaped gradient buffer.  nn.Parameters are views
+into it, so (a) the optimiser step is one fused HIP pass (augcl_adam_f32), (b) the target-network
+EMA is one pass per tau segment (augcl_ema_f32) and (c) the data-parallel gradient exchange is a
+single all-reduce of one bucket, with shared tensors (the CNN used by actor AND critic,
+src/algorithms/sac.py:17-32) appearing exactly once.
+"""
+import torch
+
+from . import _lib
+
+
+class FlatGroup:
+    """Owns flat param / grad buffers for an ordered list of (name, nn.Parameter)."""
+
+    def __init__(self, named_params, align=4):
+        named_params = list(named_params)
+        assert named_params, "empty parameter group"
+        dev = named_params[0][1].device
+        self.names, self.slices, self.shapes = [], {}, {}
+        off = 0
+        for n, p in named_params:
+            assert p.dtype == torch.float32 and p.device == dev
+            k = p.numel()
+            self.names.append(n)
+            self.slices[n] = (off, off + k)
+            self.shapes[n] = tuple(p.shape)
+            off = (off + k + align - 1) // align * align  # keep every tensor 16-byte aligned
+        self.numel = off
+        self.param = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.params = []
+        for n, p in named_params:
+            a, b = self.slices[n]
+            self.param[a:b].copy_(p.data.reshape(-1))
+            p.data = self.param[a:b].view(self.shapes[n])
+            p.grad = self.grad[a:b].view(self.shapes[n])
+            self.params.append(p)
+
+    def rebind(self):
+        """Re-point parameters at the flat buffers (after something replaced .data/.grad)."""
+        for n, p in zip(self.names, self.params):
+            a, b = self.slices[n]
+            if p.data.data_ptr() != self.param[a:b].data_ptr():
+                self.param[a:b].copy_(p.data.reshape(-1))
+                p.data = self.param[a:b].view(self.shapes[n])
+            p.grad = self.grad[a:b].view(self.shapes[n])
+
+    def segment(self, prefix):
+        """[begin, end) of the contiguous run of tensors whose name starts with prefix."""
+        idx = [i for i, n in enumerate(self.names) if n.startswith(prefix)]
+        assert idx and idx == list(range(idx[0], idx[-1] + 1)), f"{prefix}: not contiguous"
+        a = self.slices[self.names[idx[0]]][0]
+        b = self.slices[self.names[idx[-1]]][1] if idx[-1] == len(self.names) - 1 else self.slices[self.names[idx[-1] + 1]][0]
+        return a, (self.numel if idx[-1] == len(self.names) - 1 else b)
+
+
+class FlatAdam:
+    """torch.optim.Adam(params, lr, betas=(beta1, 0.999)) over a FlatGroup, one HIP launch per step.
+    zero_grad() zeroes the flat gradient buffer (grads stay allocated views: set_to_none=False)."""
+
+    def __init__(self, group, lr, betas=(0.9, 0.999), eps=1e-8, reducer=None):
+        self.group, self.lr, self.betas, self.eps = group, float(lr), (float(betas[0]), float(betas[1])), float(eps)
+        self.exp_avg = torch.zeros_like(group.param)
+        self.exp_avg_sq = torch.zeros_like(group.param)
+        self.step_count = 0
+        self.reducer = reducer  # data-parallel gradient exchange (dist.GradReducer) or None
+
+    def zero_grad(self, set_to_none=False):
+        self.group.grad.zero_()
+        for p in self.group.params:  # autograd may have replaced a .grad it found undefined
+            if p.grad is None or p.grad.data_ptr() == 0:
+                self.group.rebind()
+                break
+
+    def step(self):
+        g = self.group
+        scale = 1.0
+        if self.reducer is not None:
+            scale = self.reducer.allreduce_sum_(g.grad)  # returns 1/world_size
+        self.step_count += 1
+        _lib.call("augcl_adam_f32", g.param.data_ptr(), g.grad.data_ptr(), self.exp_avg.data_ptr(),
+                  self.exp_avg_sq.data_ptr(), g.numel, self.lr, self.betas[0], self.betas[1], self.eps,
+                  self.step_count, scale, _lib.current_stream(g.param.device))
+
+    def state_dict(self):
+        return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "lr": self.lr,
+                "betas": self.betas, "eps": self.eps}
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd["step"])
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+
+
+def ema_(target_flat, src_flat, begin, end, tau):
+    """target[begin:end] <- tau*src + (1-tau)*target (utils.soft_update_params on a flat segment)."""
+    if end <= begin:
+        return
+    _lib.call("augcl_ema_f32", target_flat.data_ptr() + 4 * begin, src_flat.data_ptr() + 4 * begin, end - begin,
+              float(tau), _lib.current_stream(target_flat.device))

@@ -112,6 +112,44 @@ int augcl_shift_conv_f32(const float *in, float *out_shift, float *out_aug,
                          const int32_t *oy, const int32_t *ox, const float *weights,
                          uint64_t seed, uint64_t offset, int sample0, augcl_stream_t stream);
 
+/* ---- fused optimiser step over a FLAT parameter group: torch.optim.Adam(betas=(b1,.999), eps=1e-8)
+ * as used at src/algorithms/sac.py:48-56 (math of torch/optim/adam.py, single-tensor form):
+ *   g *= grad_scale; m = b1*m+(1-b1)*g; v = b2*v+(1-b2)*g*g; p -= (lr/bc1) * m/(sqrt(v)/sqrt(bc2)+eps)
+ * bias corrections use `step` (1-based).  grad_scale folds the 1/world_size of a data-parallel
+ * SUM all-reduce into the same pass.  All four buffers hold n floats, 16-byte aligned. */
+int augcl_adam_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n,
+                   double lr, double beta1, double beta2, double eps, int64_t step, double grad_scale,
+                   augcl_stream_t stream);
+
+/* ---- target-network update: utils.soft_update_params (src/utils.py:76-78), called from
+ * SAC.soft_update_critic_target (src/algorithms/sac.py:148-153):
+ *   target[i] = tau*src[i] + (1-tau)*target[i]   (separate IEEE ops, bit-exact vs torch f32) */
+int augcl_ema_f32(float *target, const float *src, size_t n, double tau, augcl_stream_t stream);
+
+/* ---- shared conv encoder: SharedCNN / HeadCNN of src/algorithms/modules.py:145-181, i.e.
+ * NormalizeImg (x/255) -> Conv2d(C,32,3,stride=2) -> [ReLU -> Conv2d(32,32,3)]*, and its backward.
+ * All tensors f32 NCHW.  Forward kernels fuse the bias and (relu != 0) the ReLU that FOLLOWS the
+ * conv, so stored activations are post-ReLU; backward-data fuses the ReLU mask of the layer below
+ * (act_prev > 0; NULL = no mask).  f32 MFMA (v_mfma_f32_32x32x2_f32): exact f32 FMA chains.
+ * backward-weights needs a workspace of augcl_enc_wgrad_workspace_bytes(C_in) bytes; its reduction
+ * order is fixed (no atomics), so gradients are bitwise reproducible. */
+int augcl_enc_conv_first_forward(const float *in /* (B,C,Hi,Wi) */, const float *w /* (32,C,3,3) */,
+                                 const float *bias, float *out /* (B,32,Ho,Wo) */, int B, int C, int Hi, int Wi,
+                                 int stride, float scale /* input divided by this: 255 */, int relu,
+                                 augcl_stream_t stream);
+int augcl_enc_conv32_forward(const float *in /* (B,32,Hi,Wi) */, const float *w /* (32,32,3,3) */,
+                             const float *bias, float *out /* (B,32,Hi-2,Wi-2) */, int B, int Hi, int Wi, int relu,
+                             augcl_stream_t stream);
+int augcl_enc_conv32_backward_data(const float *dz /* (B,32,Ho,Wo) */, const float *w, const float *act_prev,
+                                   float *dact /* (B,32,Ho+2,Wo+2) */, int B, int Ho, int Wo, augcl_stream_t stream);
+size_t augcl_enc_wgrad_workspace_bytes(int C_in);
+int augcl_enc_conv32_backward_weights(const float *act_prev /* (B,32,Hi,Wi) */, const float *dz /* (B,32,Hi-2,Wi-2) */,
+                                      float *dw /* (32,32,3,3) */, float *db /* (32) */, float *workspace,
+                                      size_t workspace_bytes, int B, int Hi, int Wi, augcl_stream_t stream);
+int augcl_enc_conv_first_backward_weights(const float *x /* (B,C,Hi,Wi) raw */, const float *dz, float *dw /* (32,C,3,3) */,
+                                          float *db, float *workspace, size_t workspace_bytes, int B, int C, int Hi,
+                                          int Wi, int stride, float scale, augcl_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

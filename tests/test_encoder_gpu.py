@@ -1,0 +1,104 @@
+"""GPU parity: hand-written HIP encoder kernels (f32 MFMA implicit GEMM: forward, backward-data,
+backward-weights) vs a plain fp32 reference of the same op (torch conv2d on the CPU = what the
+oracle's cnn_forward runs) and vs the golden vectors minted from the reference's SharedCNN."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import inputs as gi
+from augcl_amd import _lib, encoder_ops
+from oracle import sac_oracle as so
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def ref_stack(x, ws, bs, stride, scale):
+    h = x / scale
+    for i, (w, b) in enumerate(zip(ws, bs)):
+        if i:
+            h = torch.relu(h)
+        h = F.conv2d(h, w, b, stride=stride if i == 0 else 1)
+    return h
+
+
+def rel_err(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("B,C,H,n_layers,stride", [(3, 9, 84, 11, 2), (2, 9, 84, 4, 2), (5, 3, 40, 3, 2),
+                                                   (2, 12, 50, 2, 1), (1, 9, 84, 1, 2), (7, 9, 36, 5, 2)])
+def test_conv_stack_forward_backward(cuda, B, C, H, n_layers, stride):
+    rs = np.random.RandomState(B * 100 + H)
+    x = torch.from_numpy(rs.randint(0, 256, (B, C, H, H)).astype(np.float32))
+    ws = [torch.from_numpy((rs.standard_normal((32, C if i == 0 else 32, 3, 3)) * np.sqrt(2.0 / (9 * (C if i == 0 else 32)))).astype(np.float32)) for i in range(n_layers)]
+    bs = [torch.from_numpy((0.05 * rs.standard_normal(32)).astype(np.float32)) for _ in range(n_layers)]
+    wr = [w.clone().requires_grad_(True) for w in ws]
+    br = [b.clone().requires_grad_(True) for b in bs]
+    ref = ref_stack(x, wr, br, stride, 255.0)
+    gout = torch.from_numpy(rs.standard_normal(tuple(ref.shape)).astype(np.float32))
+    (ref * gout).sum().backward()
+
+    wg = [w.clone().to(cuda).requires_grad_(True) for w in ws]
+    bg = [b.clone().to(cuda).requires_grad_(True) for b in bs]
+    encoder_ops.set_backend("hip")
+    out = encoder_ops.conv_stack(x.to(cuda), wg, bg, first_stride=stride, input_scale=255.0)
+    (out * gout.to(cuda)).sum().backward()
+    torch.cuda.synchronize()
+    assert out.shape == ref.shape
+    assert rel_err(out.cpu(), ref.detach()) <= 1e-5
+    for i in range(n_layers):
+        assert rel_err(wg[i].grad.cpu(), wr[i].grad) <= 2e-5, f"dW layer {i}"
+        assert rel_err(bg[i].grad.cpu(), br[i].grad) <= 2e-5, f"db layer {i}"
+
+
+def test_no_grad_path_and_determinism(cuda):
+    rs = np.random.RandomState(0)
+    x = torch.from_numpy(rs.randint(0, 256, (4, 9, 84, 84)).astype(np.float32)).to(cuda)
+    hp = dict(so.DEFAULTS)
+    st = so.synth_state(5, so.critic_shapes((9, 84, 84), 6, hp))
+    ids = so.conv_layer_ids(11)
+    ws = [st[f"encoder.shared_cnn.layers.{i}.weight"].to(cuda).requires_grad_(True) for i in ids]
+    bs = [st[f"encoder.shared_cnn.layers.{i}.bias"].to(cuda).requires_grad_(True) for i in ids]
+    with torch.no_grad():
+        a = encoder_ops.conv_stack(x, ws, bs)
+    b = encoder_ops.conv_stack(x, ws, bs)
+    assert torch.equal(a, b)
+    b.square().sum().backward()
+    g1 = [w.grad.clone() for w in ws]
+    for w in ws:
+        w.grad = None
+    encoder_ops.conv_stack(x, ws, bs).square().sum().backward()
+    for g, w in zip(g1, ws):
+        assert torch.equal(g, w.grad)  # fixed-order slab reduction: bitwise reproducible gradients
+
+
+def test_shared_cnn_matches_reference_golden(cuda):
+    """Same synthetic weights / batch as tests/golden/make_golden_sac.py's nets block."""
+    G = np.load(os.path.join(ROOT, "tests", "golden", "sac_golden.npz"))
+    hp = dict(so.DEFAULTS)
+    cs = so.synth_state(31, so.critic_shapes((9, 84, 84), 6, hp))
+    ob, _, _, _, _ = gi.transition_batch(33, 3, 6)
+    ids = so.conv_layer_ids(11)
+    ws = [cs[f"encoder.shared_cnn.layers.{i}.weight"].to(cuda) for i in ids]
+    bs = [cs[f"encoder.shared_cnn.layers.{i}.bias"].to(cuda) for i in ids]
+    out = encoder_ops.conv_stack(torch.from_numpy(ob.astype(np.float32)).to(cuda), ws, bs)
+    want = torch.from_numpy(G["nets/cnn_out"])
+    assert rel_err(out.cpu(), want) <= 1e-5
+
+
+def test_full_batch_linearity_property(cuda):
+    """config-2 size (B=256): conv stack of a batch == stack of its halves (size-independent property)."""
+    rs = np.random.RandomState(1)
+    x = torch.from_numpy(rs.randint(0, 256, (256, 9, 84, 84)).astype(np.float32)).to(cuda)
+    ws = [torch.from_numpy((rs.standard_normal((32, 9 if i == 0 else 32, 3, 3)) * 0.08).astype(np.float32)).to(cuda) for i in range(11)]
+    bs = [torch.zeros(32, device=cuda) for _ in range(11)]
+    with torch.no_grad():
+        full = encoder_ops.conv_stack(x, ws, bs)
+        halves = torch.cat([encoder_ops.conv_stack(x[:100].contiguous(), ws, bs), encoder_ops.conv_stack(x[100:].contiguous(), ws, bs)])
+    assert full.shape == (256, 32, 21, 21)
+    assert torch.equal(full, halves)
