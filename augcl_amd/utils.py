@@ -45,7 +45,7 @@ class LazyFrames(object):
     def __init__(self, frames):
         self._frames = frames
 
-    def __array__(self, dtype=None):
+    def __array__(self, dtype=None, copy=None):
         import numpy as np
         out = np.concatenate(self._frames, axis=0)
         return out.astype(dtype) if dtype is not None else out

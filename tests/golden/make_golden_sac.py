@@ -30,7 +30,8 @@ from oracle import sac_oracle as so  # noqa: E402
 OBS = (9, 84, 84)
 K_STEPS = 3
 FIRST_STEP = 2
-B = 4
+B = 2
+N_SEEDS = 10  # candidate scenario seeds per case; the one with the widest ReLU gate margin is kept (see run_case)
 CASES = [  # (name, algorithm, data_aug, action_dim)
     ("sac_cartpole", "sac", "identity", 1),            # config 1 (no aug)
     ("nnrad_shift_cartpole", "non_naive_rad", "shift", 1),  # config 1: SAC + random_shift
@@ -67,10 +68,35 @@ def main(_what="all"):
 
     real_randn_like = torch.randn_like
     out = {}
-    for ci, (name, algo, data_aug, A) in enumerate(CASES):
+
+    class GateMargin:
+        """min |pre-activation| over every ReLU input seen during a run.  ReLU is continuous in value but its
+        GRADIENT is not: an input within f32 rounding (~1e-8..1e-7 here) of zero can gate differently under another
+        summation order (MFMA vs MKL-DNN), which perturbs that update by ~1e-3 relative -- for ANY independent
+        implementation, the reference on a GPU included.  Scenarios are therefore chosen (among N_SEEDS seeded
+        candidates) to keep every gate clear of zero, and the margin is stored with the vectors."""
+
+        def __init__(self):
+            self.m = float("inf")
+            self.handles = []
+
+        def watch(self, *modules):
+            for mod in modules:
+                for sub in mod.modules():
+                    if isinstance(sub, torch.nn.ReLU):
+                        self.handles.append(sub.register_forward_hook(self._hook))
+
+        def _hook(self, mod, inp, outp):
+            self.m = min(self.m, float(inp[0].detach().abs().min()))
+
+        def close(self):
+            for h in self.handles:
+                h.remove()
+
+    def run_case(ci, name, algo, data_aug, A, seed):
+        res = {}
         hp = dict(so.DEFAULTS)
         args = ref_utils.dotdict(algorithm=algo, data_aug=data_aug, aug_params=None, **hp)
-        seed = 100 + ci
         actor_state = so.synth_state(seed, so.actor_shapes(OBS, A, hp))
         critic_state = so.synth_state(seed + 1000, so.critic_shapes(OBS, A, hp))
         for k in critic_state:  # shared CNN: actor sees the critic's tensors
@@ -91,6 +117,8 @@ def main(_what="all"):
             agent.load_pretrained_agent(prev)
         else:
             agent = build(algo)
+        gm = GateMargin()
+        gm.watch(agent.actor, agent.critic, agent.critic_target, *( [agent.critic_weak] if algo == "augcl" else []))
 
         ob, ac, rw, nob, nd = gi.transition_batch(seed + 7, B, A)
         batch = tuple(torch.from_numpy(v.astype(np.float32)) for v in (ob, ac, rw, nob, nd))
@@ -130,33 +158,48 @@ def main(_what="all"):
                     cw = torch.stack([torch.randn(3, 3, 3, 3) for _ in range(B)]).numpy()
                 oys.append(oy); oxs.append(ox); oys2.append(oy2); oxs2.append(ox2); cws.append(cw)
                 used_noise.append(n_before - len(queue))
+                margin = gm.m  # the probe below is not part of the scenario
                 with torch.no_grad():
                     q1, q2 = agent.critic(batch[0], batch[1])
+                gm.m = margin
                 qs.append(np.stack([q1.numpy().ravel(), q2.numpy().ravel()]))
         finally:
             torch.randn_like = real_randn_like
+            gm.close()
         keys = sorted({k for (_, k) in L.rows})
         logs = np.full((K_STEPS, len(keys)), np.nan)
         for (st, k), v in L.rows.items():
             logs[st - FIRST_STEP, keys.index(k)] = v
         pre = name + "/"
-        out[pre + "log_keys"] = np.array(keys)
-        out[pre + "logs"] = logs
-        out[pre + "noise_used"] = np.array(used_noise)
-        out[pre + "oy"], out[pre + "ox"] = np.stack(oys), np.stack(oxs)
-        out[pre + "oy2"], out[pre + "ox2"] = np.stack(oys2), np.stack(oxs2)
+        res[pre + "seed"] = np.array([seed])
+        res[pre + "gate_margin"] = np.array([gm.m])
+        res[pre + "log_keys"] = np.array(keys)
+        res[pre + "logs"] = logs
+        res[pre + "noise_used"] = np.array(used_noise)
+        res[pre + "oy"], res[pre + "ox"] = np.stack(oys), np.stack(oxs)
+        res[pre + "oy2"], res[pre + "ox2"] = np.stack(oys2), np.stack(oxs2)
         if data_aug == "conv":
-            out[pre + "conv_w"] = np.stack(cws)
-        out[pre + "q_after"] = np.stack(qs)
+            res[pre + "conv_w"] = np.stack(cws)
+        res[pre + "q_after"] = np.stack(qs)
         cn = list(so.critic_shapes(OBS, A, hp).keys())
         an = list(so.actor_shapes(OBS, A, hp).keys())
-        out[pre + "critic_ck"] = so.checksum(dict(agent.critic.named_parameters()), cn)
-        out[pre + "actor_ck"] = so.checksum(dict(agent.actor.named_parameters()), an)
-        out[pre + "target_ck"] = so.checksum(dict(agent.critic_target.named_parameters()), cn)
+        res[pre + "critic_ck"] = so.checksum(dict(agent.critic.named_parameters()), cn)
+        res[pre + "actor_ck"] = so.checksum(dict(agent.actor.named_parameters()), an)
+        res[pre + "target_ck"] = so.checksum(dict(agent.critic_target.named_parameters()), cn)
         if algo == "augcl":
-            out[pre + "weak_ck"] = so.checksum(dict(agent.critic_weak.named_parameters()), cn)
-        out[pre + "log_alpha"] = np.array([agent.log_alpha.item()], dtype=np.float64)
-        print(name, {k: np.round(logs[:, i], 5).tolist() for i, k in enumerate(keys)})
+            res[pre + "weak_ck"] = so.checksum(dict(agent.critic_weak.named_parameters()), cn)
+        res[pre + "log_alpha"] = np.array([agent.log_alpha.item()], dtype=np.float64)
+        return res, gm.m, {k: np.round(logs[:, i], 5).tolist() for i, k in enumerate(keys)}
+
+    for ci, (name, algo, data_aug, A) in enumerate(CASES):
+        best = None
+        for trial in range(N_SEEDS):
+            seed = 100 + ci + 37 * trial
+            res, margin, summary = run_case(ci, name, algo, data_aug, A, seed)
+            if best is None or margin > best[1]:
+                best = (res, margin, summary, seed)
+        out.update(best[0])
+        print(name, "seed", best[3], "gate margin %.2e" % best[1], best[2])
 
     # module-level golden: forward values + input/parameter gradients of encoder, actor, critic (A=6)
     A, hp = 6, dict(so.DEFAULTS)

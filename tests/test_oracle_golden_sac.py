@@ -35,17 +35,21 @@ def t(a):
     return torch.from_numpy(np.ascontiguousarray(a))
 
 
+GB = 2  # scenario batch size (tests/golden/make_golden_sac.py)
+
+
 def make_case(name, algo, data_aug, A, ci):
-    """Rebuild the golden scenario: returns (states, batch, noises, overlay images)."""
+    """Rebuild the golden scenario: returns (states, batch, noises, overlay images).  The scenario seed is the
+    one the generator kept for its wide ReLU gate margin (stored in the golden file)."""
     hp = dict(so.DEFAULTS)
-    seed = 100 + ci
+    seed = int(np.load(os.path.join(ROOT, "tests", "golden", "sac_golden.npz"))[f"{name}/seed"][0])
     actor_state = so.synth_state(seed, so.actor_shapes(OBS, A, hp))
     critic_state = so.synth_state(seed + 1000, so.critic_shapes(OBS, A, hp))
-    ob, ac, rw, nob, nd = gi.transition_batch(seed + 7, 4, A)
+    ob, ac, rw, nob, nd = gi.transition_batch(seed + 7, GB, A)
     batch = tuple(t(v.astype(np.float32)) for v in (ob, ac, rw, nob, nd))
     rs = np.random.RandomState(seed + 3)
-    noises = [t(rs.standard_normal((4, A)).astype(np.float32)) for _ in range(6)]
-    ov = gi.overlay_imgs(seed + 9, 4)
+    noises = [t(rs.standard_normal((GB, A)).astype(np.float32)) for _ in range(6)]
+    ov = gi.overlay_imgs(seed + 9, GB)
     return actor_state, critic_state, batch, noises, ov
 
 

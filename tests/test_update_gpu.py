@@ -1,0 +1,178 @@
+"""GPU parity of update(): augcl_amd agents (HIP augmentations + HIP encoder + fused Adam/EMA)
+vs the golden vectors minted from the reference's own agents and vs the CPU oracle, on the same
+seeded batch with the same injected noise and augmentation parameters."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import test_oracle_golden_sac as T
+from augcl_amd import augmentations as aug
+from augcl_amd import utils as au
+from augcl_amd.algorithms import make_agent
+from oracle import sac_oracle as so
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RTOL0 = 1e-5     # first update from identical state (north_star)
+RTOL_TRAJ = 1e-4  # later steps: chaotic amplification of f32 rounding (see test_oracle_golden_sac.py)
+
+
+class RecLogger:
+    def __init__(self):
+        self.rows = {}
+
+    def log(self, key, value, step, n=1):
+        self.rows[(step, key)] = float(value.item() if torch.is_tensor(value) else value)
+
+
+class FakeBuffer:
+    def __init__(self, batch):
+        self.batch = batch
+
+    def sample(self, n=None, idxs=None):
+        return tuple(t.clone() for t in self.batch)
+
+
+def build_agent(algo, data_aug, A, actor_state, critic_state, cuda):
+    args = au.dotdict(algorithm=algo, data_aug=data_aug, aug_params=None, **so.DEFAULTS)
+
+    def load(agent):
+        cs = {k: v.to(cuda) for k, v in critic_state.items()}
+        as_ = {k: (cs[k] if so.is_cnn(k) else v.to(cuda)) for k, v in actor_state.items()}
+        agent.critic.load_state_dict(cs)
+        agent.actor.load_state_dict(as_)
+        agent.critic_target.load_state_dict(cs)
+        return agent
+
+    if algo == "augcl":
+        prev = load(make_agent(T.OBS, (A,), au.dotdict(dict(args, algorithm="non_naive_rad"))))
+        agent = make_agent(T.OBS, (A,), args)
+        agent.load_pretrained_agent(prev)
+        return agent
+    return load(make_agent(T.OBS, (A,), args))
+
+
+@pytest.mark.parametrize("name,algo,data_aug,A,ci", T.CASES)
+def test_update_matches_reference_golden(cuda, monkeypatch, name, algo, data_aug, A, ci):
+    G = np.load(os.path.join(ROOT, "tests", "golden", "sac_golden.npz"))
+    actor_state, critic_state, batch, noises, ov = T.make_case(name, algo, data_aug, A, ci)
+    agent = build_agent(algo, data_aug, A, actor_state, critic_state, cuda)
+    agent.fuse_front_end = False  # explicit parameters go through the un-fused ops (fused == chain is tested elsewhere)
+    dbatch = tuple(t.to(cuda) for t in batch)
+    buf, L = FakeBuffer(dbatch), RecLogger()
+    queue = [n.to(cuda) for n in noises]
+    monkeypatch.setattr(torch, "randn_like", lambda t, *a, **k: queue.pop(0).clone())
+    keys = [str(k) for k in G[f"{name}/log_keys"]]
+    want = G[f"{name}/logs"]
+    state = {"s": 0, "shift_calls": 0}
+    real_shift, real_conv, real_overlay = aug.random_shift, aug.random_conv, aug.random_overlay
+
+    def shift_explicit(x, pad=4, **kw):
+        s = state["s"]
+        second = state["shift_calls"] == 1 and (algo == "drq" or (algo == "rad" and data_aug == "shift"))
+        state["shift_calls"] += 1
+        oy = G[f"{name}/oy2" if second else f"{name}/oy"][s]
+        ox = G[f"{name}/ox2" if second else f"{name}/ox"][s]
+        return real_shift(x, pad, oy=oy, ox=ox)
+
+    def conv_explicit(x, **kw):
+        return real_conv(x, weights=G[f"{name}/conv_w"][state["s"]])
+
+    def overlay_explicit(x, **kw):
+        return real_overlay(x, imgs=torch.from_numpy(ov).to(cuda))
+
+    import augcl_amd.algorithms.augcl as m_augcl
+    import augcl_amd.algorithms.drq as m_drq
+    import augcl_amd.algorithms.svea as m_svea
+    for mod in (m_svea, m_drq, m_augcl):
+        monkeypatch.setattr(mod.augmentations, "random_shift", shift_explicit)
+    if hasattr(agent, "aug_funcs"):
+        for k, fn in (("shift", shift_explicit), ("conv", conv_explicit), ("overlay", overlay_explicit)):
+            if k in agent.aug_funcs:
+                agent.aug_funcs[k]["func"] = fn
+
+    for s in range(3):
+        state["s"], state["shift_calls"] = s, 0
+        step = 2 + s
+        agent.update(buf, L, step)
+        tol = RTOL0 if s == 0 else RTOL_TRAJ
+        for j, k in enumerate(keys):
+            if np.isnan(want[s, j]) or "variance" in k:
+                continue
+            got = L.rows[(step, k)]
+            atol = tol * (T.ENT_CONST(A) + abs(want[s, j])) if k.endswith("mean_entropy") else tol
+            assert got == pytest.approx(want[s, j], rel=tol, abs=atol), (s, k)
+        with torch.no_grad():
+            q1, q2 = agent.critic(dbatch[0], dbatch[1])
+        got = np.stack([q1.cpu().numpy().ravel(), q2.cpu().numpy().ravel()])
+        np.testing.assert_allclose(got, G[f"{name}/q_after"][s], rtol=tol, atol=tol)
+    assert not queue or len(queue) == len(noises) - int(G[f"{name}/noise_used"].sum())
+    cn = list(so.critic_shapes(T.OBS, A, so.DEFAULTS).keys())
+    for ck, net in (("critic_ck", agent.critic), ("target_ck", agent.critic_target)):
+        got = so.checksum({k: v.detach().cpu() for k, v in net.named_parameters()}, cn)
+        np.testing.assert_allclose(got[:, 1], G[f"{name}/{ck}"][:, 1], rtol=2e-5)
+    assert float(agent.log_alpha) == pytest.approx(float(G[f"{name}/log_alpha"][0]), rel=1e-7)
+
+
+def test_adam_and_ema_kernels_match_torch(cuda):
+    from augcl_amd import flat
+    rs = np.random.RandomState(0)
+    n = 100003  # not a multiple of 4: exercises the tail kernel
+    p0 = torch.from_numpy(rs.standard_normal(n).astype(np.float32))
+    grads = [torch.from_numpy((rs.standard_normal(n) * 10.0 ** rs.uniform(-6, 1, n)).astype(np.float32)) for _ in range(4)]
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=1e-3, betas=(0.9, 0.999), foreach=False)
+    par = torch.nn.Parameter(p0.clone().to(cuda))
+    grp = flat.FlatGroup([("p", par)])
+    fopt = flat.FlatAdam(grp, 1e-3, (0.9, 0.999))
+    for g in grads:
+        ref.grad = g.clone()
+        opt.step()
+        fopt.zero_grad()
+        par.grad.copy_(g.to(cuda))
+        fopt.step()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(par.detach().cpu().numpy(), ref.detach().numpy(), rtol=2e-6, atol=2e-8)
+    # EMA: bit-exact with the reference expression
+    t0 = torch.from_numpy(rs.standard_normal(n).astype(np.float32))
+    want = 0.05 * p0 + (1 - 0.05) * t0
+    tg = t0.clone().to(cuda)
+    flat.ema_(tg, p0.to(cuda), 0, n, 0.05)
+    assert torch.equal(tg.cpu(), want)
+    tg = t0.clone().to(cuda)
+    flat.ema_(tg, p0.to(cuda), 1, n, 0.01)  # unaligned segment start
+    assert torch.equal(tg.cpu()[1:], (0.01 * p0 + (1 - 0.01) * t0)[1:]) and tg.cpu()[0] == t0[0]
+
+
+def test_agent_surface_and_actions(cuda):
+    args = au.dotdict(algorithm="svea", data_aug="conv", aug_params=None, **so.DEFAULTS)
+    agent = make_agent(T.OBS, (6,), args)
+    assert agent.actor.encoder.shared_cnn is agent.critic.encoder.shared_cnn  # shared CNN object (sac.py:17-32)
+    assert agent.critic_target.encoder.shared_cnn is not agent.critic.encoder.shared_cnn
+    assert agent.log_alpha.dtype == torch.float64 and agent.training
+    n_c = sum(p.numel() for p in agent.critic.parameters())
+    n_a = sum(p.numel() for p in agent.actor.parameters())
+    assert (n_c, n_a) == (3826990, 2671928)
+    obs = np.random.RandomState(0).randint(0, 256, (9, 84, 84)).astype(np.uint8)
+    a1 = agent.select_action(obs)
+    a2 = agent.sample_action(au.LazyFrames([obs[:3], obs[3:6], obs[6:]]))
+    assert a1.shape == (6,) and a2.shape == (6,) and np.all(np.abs(a1) <= 1) and np.all(np.abs(a2) <= 1)
+    with au.eval_mode(agent):
+        assert not agent.training
+    assert agent.training
+    # a full default-path update (fused u8 front end, in-kernel Philox parameters) runs and changes the nets
+    B = 16
+    g = torch.Generator(device=cuda).manual_seed(0)
+    batch = (torch.randint(0, 256, (B, 9, 84, 84), device=cuda, generator=g).float(), torch.rand(B, 6, device=cuda) * 2 - 1,
+             torch.rand(B, 1, device=cuda), torch.randint(0, 256, (B, 9, 84, 84), device=cuda, generator=g).float(),
+             torch.ones(B, 1, device=cuda))
+    before = agent.critic_group.param.clone()
+    L = RecLogger()
+    for step in (0, 1):
+        agent.update(FakeBuffer(batch), L, step)
+    assert not torch.equal(before, agent.critic_group.param)
+    assert all(np.isfinite(v) for v in L.rows.values())
+    assert {k for _, k in L.rows} >= {"train_critic/loss", "train_critic/shift_loss", "train_critic/aug_loss",
+                                      "train_actor/loss", "train_alpha/value"}
