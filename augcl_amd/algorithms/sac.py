@@ -67,6 +67,9 @@ class SAC(object):
         self.actor_optimizer = flat.FlatAdam(self.actor_group, hp["actor_lr"], (hp["actor_beta"], 0.999), reducer=reducer)
         self.log_alpha_optimizer = torch.optim.Adam([self.log_alpha], lr=hp["alpha_lr"], betas=(hp["alpha_beta"], 0.999))
         self._reducer = reducer
+        if reducer is not None:  # replicas must start identical
+            for g in (self.critic_group, self.actor_group, self.target_group):
+                reducer.broadcast_(g.param)
 
     def train(self, training=True):
         self.training = training

@@ -1,0 +1,75 @@
+"""SAC grad-steps/s leg of bench.py: full SVEA update() calls (config 2: walker_walk, A=6, random_shift +
+random_conv, B=256 per GPU, f32) on a pre-staged synthetic replay batch -- critic every step, actor+alpha
+and target EMA every 2nd -- timed like the headline metric (barrier + synchronize, max over ranks)."""
+import time
+
+import torch
+
+
+class _SyntheticReplay:
+    """Device-resident ring of uint8->f32 batches in the 5-tuple layout of ReplayBuffer.sample()
+    (src/utils.py:272-280)."""
+
+    def __init__(self, dev, B, A, ring=4, seed=0):
+        g = torch.Generator(device=dev)
+        g.manual_seed(seed)
+        self.items = []
+        for _ in range(ring):
+            obs = torch.randint(0, 256, (B, 9, 84, 84), device=dev, generator=g, dtype=torch.uint8).float()
+            nobs = torch.randint(0, 256, (B, 9, 84, 84), device=dev, generator=g, dtype=torch.uint8).float()
+            act = torch.rand((B, A), device=dev, generator=g) * 2 - 1
+            rew = torch.rand((B, 1), device=dev, generator=g) * 4
+            self.items.append((obs, act, rew, nobs, torch.ones((B, 1), device=dev)))
+        self.i = 0
+
+    def sample(self, n=None, idxs=None):
+        self.i += 1
+        return self.items[self.i % len(self.items)]
+
+
+class _NullLogger:
+    def log(self, key, value, step, n=1):
+        pass
+
+
+def run(dev, dist, world, rank, steps=20, warmup=4, B=256, A=6, algo="svea", data_aug="conv", backend=None):
+    from . import dist as apdist
+    from . import encoder_ops
+    from . import utils as au
+    from .algorithms import make_agent
+
+    if backend:
+        encoder_ops.set_backend(backend)
+    hp = dict(discount=0.99, critic_tau=0.01, encoder_tau=0.05, actor_update_freq=2, critic_target_update_freq=2,
+              num_shared_layers=11, num_head_layers=0, num_filters=32, projection_dim=100, hidden_dim=1024,
+              actor_log_std_min=-10.0, actor_log_std_max=2.0, init_temperature=0.1, actor_lr=1e-3, actor_beta=0.9,
+              critic_lr=1e-3, critic_beta=0.9, alpha_lr=1e-4, alpha_beta=0.5, svea_alpha=0.5, svea_beta=0.5, drq_k=1,
+              drq_m=1)
+    if dist is not None and apdist.default_reducer() is None:
+        apdist.set_default_reducer(apdist.GradReducer())
+    torch.manual_seed(0)  # identical replicas
+    agent = make_agent((9, 84, 84), (A,), au.dotdict(algorithm=algo, data_aug=data_aug, aug_params=None, **hp))
+    buf = _SyntheticReplay(dev, B, A, seed=100 + rank)
+    L = None  # no logging inside the timed region (the reference's Logger syncs per scalar)
+    for s in range(warmup):
+        agent.update(buf, L, s)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(steps):
+        agent.update(buf, L, s)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([wall], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    flops = 432e9 * (B / 256)  # ~1.69 GFLOP per sample per (average) step
+    return {"grad_steps_per_s": steps / wall, "ms_per_update": wall / steps * 1e3, "samples_per_s": world * B * steps / wall,
+            "algo": f"{algo}+{data_aug}", "batch_per_gpu": B, "steps": steps, "dtype": "f32",
+            "approx_TFLOP/s_per_gpu": flops * steps / wall / 1e12, "encoder_backend": encoder_ops.BACKEND}

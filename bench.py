@@ -171,8 +171,9 @@ def main():
     if os.path.exists(prof):
         try:
             t = json.load(open(prof)).get("k_random_conv", {})
-            if t.get("batch") == B:
+            if t.get("batch") == B:  # measured offline with rocprofv3 --pmc (profiles/, tools/summarize_profiles.py)
                 res["roofline"]["traffic"] = t.get("hbm_bytes_per_launch")
+                res["roofline"]["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
         except Exception:
             pass
 
