@@ -456,38 +456,144 @@ __device__ __forceinline__ float blend(float a, float b, float ratio, float inv,
 
 __device__ __forceinline__ void hue_shift(float &r, float &g, float &b, float hue)
 {
+    // torchvision _rgb2hsv -> h = (h + hue) % 1 -> _hsv2rgb.  The three (maxc - c) / cr quotients share one
+    // IEEE reciprocal (<= 1 ulp from the separate divisions; HSV->RGB is continuous across sector boundaries, so
+    // a last-bit difference cannot jump), and fmod(x, 1) is written as x - trunc(x), which is exact.
     const float maxc = fmaxf(r, fmaxf(g, b)), minc = fminf(r, fminf(g, b));
     const bool eqc = (maxc == minc);
     const float cr = maxc - minc;
     const float sat = cr / (eqc ? 1.0f : maxc);
-    const float dv = eqc ? 1.0f : cr;
-    const float rc = (maxc - r) / dv, gc = (maxc - g) / dv, bc = (maxc - b) / dv;
+    const float inv = 1.0f / (eqc ? 1.0f : cr);
+    const float rc = (maxc - r) * inv, gc = (maxc - g) * inv, bc = (maxc - b) * inv;
     const float hr = (maxc == r) ? (bc - gc) : 0.0f;
     const float hg = ((maxc == g) && (maxc != r)) ? (2.0f + rc - bc) : 0.0f;
     const float hb = ((maxc != g) && (maxc != r)) ? (4.0f + gc - rc) : 0.0f;
     float h = (hr + hg) + hb;
-    h = fmodf(h / 6.0f + 1.0f, 1.0f);
-    float hh = fmodf(h + hue, 1.0f);
-    if (hh != 0.0f && hh < 0.0f) hh += 1.0f;
+    h = h / 6.0f + 1.0f;
+    h = h - truncf(h); // fmod(h, 1), h > 0
+    float hh = h + hue;
+    hh = hh - truncf(hh); // fmod(hh, 1): keeps the sign of hh
+    if (hh != 0.0f && hh < 0.0f) hh += 1.0f; // python-style remainder
     const float v = maxc;
     const float h6 = hh * 6.0f;
     const float fl = floorf(h6);
     const float f = h6 - fl;
-    int i = ((int)fl) % 6;
-    if (i < 0) i += 6;
+    int i = (int)fl;
+    i = i >= 6 ? i - 6 : i; // hh in [0, 1] => fl in {0..6}
     const float p = clampf(v * (1.0f - sat), 0.0f, 1.0f);
     const float q = clampf(v * (1.0f - sat * f), 0.0f, 1.0f);
     const float t = clampf(v * (1.0f - sat * (1.0f - f)), 0.0f, 1.0f);
-    switch (i) {
-    case 0: r = v; g = t; b = p; break;
-    case 1: r = q; g = v; b = p; break;
-    case 2: r = p; g = v; b = t; break;
-    case 3: r = p; g = q; b = v; break;
-    case 4: r = t; g = p; b = v; break;
-    default: r = v; g = p; b = q; break;
+    const float r0 = (i == 0 || i == 5) ? v : (i == 1) ? q : (i == 4) ? t : p;
+    const float g0 = (i == 1 || i == 2) ? v : (i == 0) ? t : (i == 3) ? q : p;
+    const float b0 = (i == 3 || i == 4) ? v : (i == 2) ? t : (i == 5) ? q : p;
+    r = r0; g = g0; b = b0;
+}
+
+// Register-resident variant (the product path for 84x84 / 100x100 frames): NT threads own the whole RGB
+// frame, NQ quads of 4 pixels per thread and channel (<= 60 data VGPRs), so the only LDS traffic is the
+// NT/64 partial sums of the contrast mean.  Every load of a thread is issued up front (3*NQ dwordx4 in
+// flight), several workgroups fit per CU, and HBM sees one read and one write per element.
+template <int NT, int NQ, int WPS>
+__global__ __launch_bounds__(NT, WPS) void k_color_jitter_reg(float *__restrict__ inout, int n /* H*W, %4==0 */,
+                                                         const int32_t *__restrict__ idx, int n_idx, JitterParams p)
+{
+    __shared__ double red[NT / 64];
+    const int frame = blockIdx.x;
+    const int tid = threadIdx.x;
+    if (idx != nullptr) {
+        int hit = 0;
+        for (int k = tid; k < n_idx; k += NT) hit |= (idx[k] == frame);
+        if (!__syncthreads_or(hit)) return;
+    }
+    float4 *__restrict__ g = reinterpret_cast<float4 *>(inout + (size_t)frame * 3 * n);
+    const int n4 = n / 4;
+    float4 px[3][NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        const int q = tid + j * NT;
+        if (q < n4) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) px[c][j] = g[c * n4 + q];
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) px[c][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    if (p.scale != 1.0f) {
+        const bool is255 = p.scale == 255.0f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                float *v = &px[c][j].x;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = is255 ? div255(v[e]) : v[e] / p.scale;
+            }
+    }
+    for (int s = 0; s < 4; ++s) {
+        const int op = p.order[s];
+        if (op == 1) {
+            double acc = 0.0; // fixed order: own pixels, wave tree, waves in order => deterministic
+#pragma unroll
+            for (int j = 0; j < NQ; ++j)
+                if (tid + j * NT < n4) {
+                    const float *r = &px[0][j].x, *gg = &px[1][j].x, *b = &px[2][j].x;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc += (double)gray(r[e], gg[e], b[e]);
+                }
+            for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+            __syncthreads(); // red[] may still be read from an earlier contrast pass
+            if ((tid & 63) == 0) red[tid >> 6] = acc;
+            __syncthreads();
+            double tot = 0.0;
+            for (int w = 0; w < NT / 64; ++w) tot += red[w];
+            const float mean = (float)(tot / (double)n);
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int j = 0; j < NQ; ++j) {
+                    float *v = &px[c][j].x;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = blend(v[e], mean, p.c_r, p.c_inv, p.bound);
+                }
+        } else if (op == 2) {
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                float *r = &px[0][j].x, *gg = &px[1][j].x, *b = &px[2][j].x;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float gy = gray(r[e], gg[e], b[e]);
+                    r[e] = blend(r[e], gy, p.s_r, p.s_inv, p.bound);
+                    gg[e] = blend(gg[e], gy, p.s_r, p.s_inv, p.bound);
+                    b[e] = blend(b[e], gy, p.s_r, p.s_inv, p.bound);
+                }
+            }
+        } else if (op == 3) {
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                float *r = &px[0][j].x, *gg = &px[1][j].x, *b = &px[2][j].x;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) hue_shift(r[e], gg[e], b[e], p.hue);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        const int q = tid + j * NT;
+        if (q < n4) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float4 v = px[c][j];
+                if (p.scale != 1.0f) {
+                    v.x = v.x * p.scale; v.y = v.y * p.scale; v.z = v.z * p.scale; v.w = v.w * p.scale;
+                }
+                g[c * n4 + q] = v;
+            }
+        }
     }
 }
 
+// LDS-resident variant for other frame sizes (whole frame in LDS, up to 160 KiB)
 template <int NT>
 __global__ __launch_bounds__(NT) void k_color_jitter(float *__restrict__ inout, int n /* H*W, %4==0 */,
                                                      const int32_t *__restrict__ idx, int n_idx, JitterParams p)
@@ -775,6 +881,16 @@ int augcl_color_jitter_f32(float *inout, int B, int frames, int H, int W, const 
         return augcl::fail(AUGCL_E_UNSUPPORTED, "%s: a %dx%d RGB frame (%zu B) exceeds the 160 KiB LDS of a CU", name, H,
                            W, smem);
     if (B == 0 || (idx != nullptr && n_idx == 0)) return AUGCL_OK;
+    if (n / 4 <= 1024 * 2) { // 84x84 (1764 quads): register-resident, two 16-wave workgroups per CU
+        hipLaunchKernelGGL((k_color_jitter_reg<1024, 2, 4>), dim3(B * frames), dim3(1024), 0, as_stream(stream), inout, n,
+                           idx, n_idx, p);
+        LAUNCH_CHECK(name);
+    }
+    if (n / 4 <= 1024 * 3) { // 100x100 (2500 quads)
+        hipLaunchKernelGGL((k_color_jitter_reg<1024, 3, 4>), dim3(B * frames), dim3(1024), 0, as_stream(stream), inout, n,
+                           idx, n_idx, p);
+        LAUNCH_CHECK(name);
+    }
     static size_t attr_max = 48 * 1024; // idempotent; a benign race at worst repeats the call
     if (smem > attr_max) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_color_jitter<NT>),

@@ -51,15 +51,80 @@ struct ConvArgs {
     int n_items;                  // B * S
 };
 
+// ---- global -> LDS staging of contiguous runs ------------------------------------------------------
+// A wave copies `run` floats (4-byte aligned in global, 16-byte aligned in LDS) of TWO channels at once:
+// up to 2*UN unaligned dwordx4 loads per lane are issued before the first LDS write, so one batch covers
+// 2 x 256*UN floats with a single exposed memory latency (the naive `d[j] = g[j]` loop paid one latency
+// per 64 floats and made the MFMA kernels staging-bound).
+typedef float f32x4ua __attribute__((ext_vector_type(4), aligned(4)));
+
+template <int UN, bool VECST = true, typename XF>
+__device__ __forceinline__ void wave_copy_runs2(const float *__restrict__ g0, const float *__restrict__ g1,
+                                                float *__restrict__ d0, float *__restrict__ d1, int run, int lane,
+                                                XF xf)
+{
+    const int nfull = run >> 2;
+    for (int c0 = 0; c0 < nfull; c0 += 64 * UN) {
+        f32x4ua v0[UN], v1[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int c = c0 + u * 64 + lane;
+            if (c < nfull) {
+                v0[u] = *reinterpret_cast<const f32x4ua *>(g0 + 4 * c);
+                v1[u] = *reinterpret_cast<const f32x4ua *>(g1 + 4 * c);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int c = c0 + u * 64 + lane;
+            if (c < nfull) {
+                if (VECST) { // destination 16-byte aligned: one ds_write_b128
+                    *reinterpret_cast<float4 *>(d0 + 4 * c) = make_float4(xf(v0[u].x), xf(v0[u].y), xf(v0[u].z), xf(v0[u].w));
+                    *reinterpret_cast<float4 *>(d1 + 4 * c) = make_float4(xf(v1[u].x), xf(v1[u].y), xf(v1[u].z), xf(v1[u].w));
+                } else { // odd plane strides (bank-conflict-free column reads): dword stores
+                    d0[4 * c] = xf(v0[u].x); d0[4 * c + 1] = xf(v0[u].y); d0[4 * c + 2] = xf(v0[u].z); d0[4 * c + 3] = xf(v0[u].w);
+                    d1[4 * c] = xf(v1[u].x); d1[4 * c + 1] = xf(v1[u].y); d1[4 * c + 2] = xf(v1[u].z); d1[4 * c + 3] = xf(v1[u].w);
+                }
+            }
+        }
+    }
+    const int t = (nfull << 2) + lane; // < 4 leftover floats
+    if (t < run) {
+        d0[t] = xf(g0[t]);
+        d1[t] = xf(g1[t]);
+    }
+}
+
+struct XfScale { // x / scale with the exact 3-op path for 255
+    float scale;
+    __device__ __forceinline__ float operator()(float v) const
+    {
+        return scale == 1.0f ? v : (scale == 255.0f ? div255e(v) : v / scale);
+    }
+};
+
+struct XfId {
+    __device__ __forceinline__ float operator()(float v) const { return v; }
+};
+
+__device__ __forceinline__ int round4(int v) { return (v + 3) & ~3; }
+
+// LDS image of k_conv32: [guard G][32 planes of `plane` words][guard G][32 bias]; a plane mirrors the
+// channel's memory rows (row stride Wi).  MODE 1 (backward-data) keeps NO padding in LDS: taps that fall
+// outside dZ are zeroed with a per-lane select in front of the MFMA (9 masks per tile), the guards only
+// keep those discarded reads inside the allocation.
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void k_conv32(ConvArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) float lds[]; // [32][RT+2][Wv]
+    extern __shared__ __attribute__((aligned(16))) float lds_raw[];
     constexpr int P = MODE ? 2 : 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
-    const int Wv = a.Wi + 2 * P;              // virtual (padded) input width = LDS row stride
-    const int plane = (a.RT + 2) * Wv;        // LDS words per channel
+    const int Wi = a.Wi;
+    const int plane = round4((a.RT + 2) * Wi);
+    const int G = MODE ? round4(2 * Wi + 4) : 0;
+    float *lds = lds_raw + G;
+    float *lbias = lds_raw + 2 * G + 32 * plane;
 
     // ---- per-lane weights, resident for the whole launch: wreg[cil*9 + t] = Weff[row l31][col cil+16h][t]
     float wreg[144];
@@ -79,39 +144,24 @@ __global__ __launch_bounds__(256, 2) void k_conv32(ConvArgs a)
                     wreg[cil * 9 + t] = a.w[(size_t)(cil + 16 * h) * 288 + l31 * 9 + (8 - t)];
         }
     }
-    float bias_r[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) bias_r[r] = (MODE == 0 && a.bias) ? a.bias[acc_row(r, h)] : 0.0f;
+    if (tid < 32) lbias[tid] = (MODE == 0 && a.bias) ? a.bias[tid] : 0.0f;
 
     for (int item = blockIdx.x; item < a.n_items; item += gridDim.x) {
         const int b = item / a.S, s = item - b * a.S;
         const int y0 = s * a.RT;
         const int rows = min(a.RT, a.Ho - y0); // output rows of this strip
         const int npix = rows * a.Wo;
-        // ---- stage the input rows y0-P .. y0+rows+1-P of all 32 channels (zeros outside the image)
+        // input rows [r0, r1) feed this strip (MODE 1: clipped to dZ; taps outside are masked to zero)
+        const int r0 = MODE ? max(0, y0 - P) : y0;
+        const int r1 = MODE ? min(a.Hi, y0 + rows) : y0 + rows + 2;
         __syncthreads(); // previous item's readers are done with the tile
         {
-            // division-free: wave w copies channels w, w+4, ...; a channel's rows are one contiguous run
-            const int nrow = rows + 2;
-            const float *src = a.in + (size_t)b * 32 * a.Hi * a.Wi;
-            if (MODE == 0) {
-                const int run = nrow * a.Wi; // Wv == Wi: the LDS plane mirrors memory
-                for (int ci = wave; ci < 32; ci += 4) {
-                    const float *g = src + ((size_t)ci * a.Hi + y0) * a.Wi;
-                    float *d = lds + ci * plane;
-                    for (int j = lane; j < run; j += 64) d[j] = g[j];
-                }
-            } else {
-                for (int j = tid; j < 32 * plane; j += 256) lds[j] = 0.0f; // zero padding (and halo outside dZ)
-                __syncthreads();
-                const int r_lo = max(0, P - y0), r_hi = min(nrow, a.Hi + P - y0); // rows with y0 + r - P inside dZ
-                for (int ci = wave; ci < 32; ci += 4)
-                    for (int r = r_lo; r < r_hi; ++r) {
-                        const float *g = src + ((size_t)ci * a.Hi + (y0 + r - P)) * a.Wi;
-                        float *d = lds + ci * plane + r * Wv + P;
-                        for (int x = lane; x < a.Wi; x += 64) d[x] = g[x];
-                    }
-            }
+            const int run = (r1 - r0) * Wi;
+            const float *src = a.in + ((size_t)b * 32 * a.Hi + r0) * Wi;
+            const size_t cs = (size_t)a.Hi * Wi;
+            for (int ci = wave * 2; ci < 32; ci += 8) // wave w: channel pairs (2w,2w+1), (2w+8,2w+9), ...
+                wave_copy_runs2<3>(src + ci * cs, src + (ci + 1) * cs, lds + ci * plane, lds + (ci + 1) * plane, run,
+                                   lane, XfId());
         }
         __syncthreads();
         // ---- M-tiles of 32 consecutive strip pixels, round-robin over the 4 waves
@@ -121,19 +171,28 @@ __global__ __launch_bounds__(256, 2) void k_conv32(ConvArgs a)
             const bool valid = m < npix;
             if (!valid) m = npix - 1; // read a real pixel, discard the result
             const int yy = m / a.Wo, xx = m - yy * a.Wo;
-            const float *base = lds + (yy * Wv + xx) + h * 16 * plane;
+            // top-left tap of this pixel inside the staged rows (may lie in the guard for MODE 1)
+            const float *base = lds + ((y0 + yy - P - r0) * Wi + (xx - P)) + h * 16 * plane;
+            bool rowok[3], colok[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                rowok[k] = MODE == 0 || ((unsigned)(y0 + yy + k - P) < (unsigned)a.Hi);
+                colok[k] = MODE == 0 || ((unsigned)(xx + k - P) < (unsigned)Wi);
+            }
             f32x16 acc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = bias_r[r];
+            for (int r = 0; r < 16; ++r) acc[r] = lbias[acc_row(r, h)];
 #pragma unroll
             for (int cil = 0; cil < 16; ++cil) {
                 const float *pc = base + cil * plane;
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                    for (int kx = 0; kx < 3; ++kx)
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[cil * 9 + ky * 3 + kx], pc[ky * Wv + kx], acc,
-                                                                   0, 0, 0);
+                    for (int kx = 0; kx < 3; ++kx) {
+                        float xv = pc[ky * Wi + kx];
+                        if (MODE == 1) xv = (rowok[ky] && colok[kx]) ? xv : 0.0f;
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[cil * 9 + ky * 3 + kx], xv, acc, 0, 0, 0);
+                    }
             }
             if (valid) {
                 const int y = y0 + yy;
@@ -197,19 +256,16 @@ __global__ __launch_bounds__(256, 2) void k_conv_first(Conv1Args a)
         {
             const int run = rows_in * a.Wi;
             const float *src = a.in + (size_t)b * a.C * a.Hi * a.Wi;
-            const bool unit = a.scale == 1.0f, is255 = a.scale == 255.0f;
-            for (int c = wave; c < 2 * CH; c += 4) {
-                float *d = lds + c * plane;
-                if (c < a.C) {
-                    const float *g = src + ((size_t)c * a.Hi + st * y0) * a.Wi;
-                    for (int j = lane; j < run; j += 64) {
-                        const float v = g[j];
-                        d[j] = unit ? v : (is255 ? div255e(v) : v / a.scale);
-                    }
-                } else {
-                    for (int j = lane; j < run; j += 64) d[j] = 0.0f; // pad plane: finite zeros (0 * NaN would poison)
-                }
+            const size_t cs = (size_t)a.Hi * a.Wi;
+            const XfScale xf{a.scale};
+            for (int c = wave * 2; c < 2 * CH; c += 8) { // channel pairs; planes >= C are zero planes
+                const int ca = min(c, a.C - 1), cb = min(c + 1, a.C - 1);
+                wave_copy_runs2<2, false>(src + ca * cs + (size_t)st * y0 * a.Wi, src + cb * cs + (size_t)st * y0 * a.Wi,
+                                          lds + c * plane, lds + (c + 1) * plane, run, lane, xf);
             }
+            __syncthreads();
+            for (int c = a.C + wave; c < 2 * CH; c += 4) // pad planes: finite zeros (0 * NaN would poison the MFMA)
+                for (int j = lane; j < run; j += 64) lds[c * plane + j] = 0.0f;
         }
         __syncthreads();
         const int ntiles = (npix + 31) >> 5;
@@ -286,15 +342,14 @@ __global__ __launch_bounds__(256, 1) void k_wgrad32(WgradArgs a)
         __syncthreads();
         {
             const int runA = (rows + 2) * a.Wi;
-            const float *src = a.act + (size_t)b * 32 * a.Hi * a.Wi;
-            const float *sz = a.dz + (size_t)b * 32 * a.Ho * a.Wo;
-            for (int c = wave; c < 32; c += 4) {
-                const float *g = src + ((size_t)c * a.Hi + y0) * a.Wi; // rows contiguous in NCHW
-                float *d = ldsA + c * planeA;
-                for (int j = lane; j < runA; j += 64) d[j] = g[j];
-                const float *gz = sz + ((size_t)c * a.Ho + y0) * a.Wo;
-                float *dzl = ldsZ + c * planeZ;
-                for (int j = lane; j < npix; j += 64) dzl[j] = gz[j];
+            const float *src = a.act + ((size_t)b * 32 * a.Hi + y0) * a.Wi; // rows contiguous in NCHW
+            const float *sz = a.dz + ((size_t)b * 32 * a.Ho + y0) * a.Wo;
+            const size_t csA = (size_t)a.Hi * a.Wi, csZ = (size_t)a.Ho * a.Wo;
+            for (int c = wave * 2; c < 32; c += 8) {
+                wave_copy_runs2<3, false>(src + c * csA, src + (c + 1) * csA, ldsA + c * planeA, ldsA + (c + 1) * planeA,
+                                          runA, lane, XfId());
+                wave_copy_runs2<3, false>(sz + c * csZ, sz + (c + 1) * csZ, ldsZ + c * planeZ, ldsZ + (c + 1) * planeZ,
+                                          npix, lane, XfId());
             }
         }
         __syncthreads();
@@ -397,22 +452,18 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_first(Wgrad1Args a)
         __syncthreads();
         {
             const int run = rows_in * a.Wi;
-            const float *src = a.x + (size_t)b * a.C * a.Hi * a.Wi;
-            const bool unit = a.scale == 1.0f, is255 = a.scale == 255.0f;
-            for (int c = wave; c < a.C; c += 4) {
-                const float *g = src + ((size_t)c * a.Hi + st * y0) * a.Wi;
-                float *d = ldsX + c * planeX;
-                for (int j = lane; j < run; j += 64) {
-                    const float v = g[j];
-                    d[j] = unit ? v : (is255 ? div255e(v) : v / a.scale);
-                }
+            const float *src = a.x + (size_t)b * a.C * a.Hi * a.Wi + (size_t)st * y0 * a.Wi;
+            const size_t cs = (size_t)a.Hi * a.Wi;
+            const XfScale xf{a.scale};
+            for (int c = wave * 2; c < a.C; c += 8) {
+                const int cb = min(c + 1, a.C - 1); // odd C: the last pair copies the last channel twice (same bytes)
+                wave_copy_runs2<2, false>(src + c * cs, src + cb * cs, ldsX + c * planeX, ldsX + cb * planeX, run, lane, xf);
             }
-            const float *sz = a.dz + (size_t)b * 32 * a.Ho * a.Wo;
-            for (int c = wave; c < 32; c += 4) {
-                const float *gz = sz + ((size_t)c * a.Ho + y0) * a.Wo;
-                float *dzl = ldsZ + c * planeZ;
-                for (int j = lane; j < npix; j += 64) dzl[j] = gz[j];
-            }
+            const float *sz = a.dz + ((size_t)b * 32 * a.Ho + y0) * a.Wo;
+            const size_t csZ = (size_t)a.Ho * a.Wo;
+            for (int c = wave * 2; c < 32; c += 8)
+                wave_copy_runs2<3, false>(sz + c * csZ, sz + (c + 1) * csZ, ldsZ + c * planeZ, ldsZ + (c + 1) * planeZ,
+                                          npix, lane, XfId());
         }
         __syncthreads();
         const int npair = (npix + 1) >> 1;
@@ -466,22 +517,37 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_first(Wgrad1Args a)
     }
 }
 
-// sum the per-workgroup slabs in a fixed order: out[i] = sum_g partial[g][i]  (i < n)
-__global__ __launch_bounds__(256) void k_reduce_slabs(const float *__restrict__ partial, int nslab, int n,
-                                                      float *__restrict__ out_w, int n_w, float *__restrict__ out_b)
+// sum the per-workgroup slabs in a FIXED order, two levels so the 9.4 MB of slabs are read by ~300 workgroups:
+//   level 1: workgroup (x, y) sums slabs y*nslab/RG .. for outputs x*256..; level 2 adds the RG partial rows.
+constexpr int RG = 8;
+
+__global__ __launch_bounds__(256) void k_reduce_slabs_l1(const float *__restrict__ partial, int nslab, int n,
+                                                         float *__restrict__ part2 /* [RG][n] */)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    const int per = (nslab + RG - 1) / RG;
+    const int g0 = blockIdx.y * per, g1 = min(nslab, g0 + per);
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int g = 0;
-    for (; g + 3 < nslab; g += 4) {
+    int g = g0;
+    for (; g + 3 < g1; g += 4) {
         s0 += partial[(size_t)g * n + i];
         s1 += partial[(size_t)(g + 1) * n + i];
         s2 += partial[(size_t)(g + 2) * n + i];
         s3 += partial[(size_t)(g + 3) * n + i];
     }
-    for (; g < nslab; ++g) s0 += partial[(size_t)g * n + i];
-    const float s = (s0 + s1) + (s2 + s3);
+    for (; g < g1; ++g) s0 += partial[(size_t)g * n + i];
+    part2[(size_t)blockIdx.y * n + i] = (s0 + s1) + (s2 + s3);
+}
+
+__global__ __launch_bounds__(256) void k_reduce_slabs_l2(const float *__restrict__ part2, int n,
+                                                         float *__restrict__ out_w, int n_w, float *__restrict__ out_b)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+#pragma unroll
+    for (int y = 0; y < RG; ++y) s += part2[(size_t)y * n + i];
     if (i < n_w) out_w[i] = s;
     else out_b[i - n_w] = s;
 }
@@ -546,10 +612,10 @@ int augcl_enc_conv32_forward(const float *in, const float *w, const float *bias,
     ConvArgs a{};
     a.in = in; a.w = w; a.bias = bias; a.mask = nullptr; a.out = out;
     a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ho = Hi - 2; a.Wo = Wi - 2; a.relu = relu;
-    a.RT = pick_rt(a.Ho, 32 * Wi, 2, kMaxLds, &a.S);
+    a.RT = pick_rt(a.Ho, 32 * Wi, 2, kMaxLds - 1024, &a.S);
     AUGCL_REQUIRE(a.RT > 0, "%s: image row too wide for LDS (W=%d)", name, Wi);
     a.n_items = B * a.S;
-    const size_t lds = (size_t)32 * (a.RT + 2) * Wi * 4;
+    const size_t lds = ((size_t)32 * (((a.RT + 2) * Wi + 3) & ~3) + 32) * 4;
     if (int rc = set_lds(k_conv32<0>, lds, name)) return rc;
     hipLaunchKernelGGL(k_conv32<0>, dim3(grid_for(a.n_items, 2)), dim3(256), lds, as_stream(stream), a);
     return augcl::check_launch(name);
@@ -565,11 +631,11 @@ int augcl_enc_conv32_backward_data(const float *dz, const float *w, const float 
     ConvArgs a{};
     a.in = dz; a.w = w; a.bias = nullptr; a.mask = act_prev; a.out = dact;
     a.B = B; a.Hi = Ho; a.Wi = Wo; a.Ho = Ho + 2; a.Wo = Wo + 2; a.relu = 0;
-    const int Wv = Wo + 4;
-    a.RT = pick_rt(a.Ho, 32 * Wv, 2, kMaxLds, &a.S);
+    const int G = (2 * Wo + 4 + 3) & ~3;
+    a.RT = pick_rt(a.Ho, 32 * Wo, 2, kMaxLds - 1024 - 8 * G, &a.S);
     AUGCL_REQUIRE(a.RT > 0, "%s: image row too wide for LDS (W=%d)", name, Wo);
     a.n_items = B * a.S;
-    const size_t lds = (size_t)32 * (a.RT + 2) * Wv * 4;
+    const size_t lds = ((size_t)32 * (((a.RT + 2) * Wo + 3) & ~3) + 2 * G + 32) * 4;
     if (int rc = set_lds(k_conv32<1>, lds, name)) return rc;
     hipLaunchKernelGGL(k_conv32<1>, dim3(grid_for(a.n_items, 2)), dim3(256), lds, as_stream(stream), a);
     return augcl::check_launch(name);
@@ -618,8 +684,8 @@ int augcl_enc_conv_first_forward(const float *in, const float *w, const float *b
 
 size_t augcl_enc_wgrad_workspace_bytes(int C)
 {
-    // slabs for up to 256 CUs x 1 workgroup; C = input channels of the layer (32 for inner layers)
-    return (size_t)256 * ((size_t)32 * C * 9 + 32) * sizeof(float);
+    // slabs for up to 256 CUs x 1 workgroup + RG rows of the two-level reduction; C = input channels of the layer
+    return (size_t)(256 + 8) * ((size_t)32 * C * 9 + 32) * sizeof(float);
 }
 
 int augcl_enc_conv32_backward_weights(const float *act_prev, const float *dz, float *dw, float *db, float *workspace,
@@ -644,13 +710,16 @@ int augcl_enc_conv32_backward_weights(const float *act_prev, const float *dz, fl
     const size_t red = (size_t)(145 * 64) * 4; // wave-reduction scratch reuses the tile
     if (lds < red) lds = red;
     const int grid = grid_for(a.n_items, 1);
-    AUGCL_REQUIRE(workspace_bytes >= (size_t)grid * WG_SLAB * 4, "%s: workspace too small (%zu < %zu)", name,
-                  workspace_bytes, (size_t)grid * WG_SLAB * 4);
+    AUGCL_REQUIRE(workspace_bytes >= (size_t)(grid + RG) * WG_SLAB * 4, "%s: workspace too small (%zu < %zu)", name,
+                  workspace_bytes, (size_t)(grid + RG) * WG_SLAB * 4);
     if (int rc = set_lds(k_wgrad32, lds, name)) return rc;
     hipStream_t s = as_stream(stream);
     hipLaunchKernelGGL(k_wgrad32, dim3(grid), dim3(256), lds, s, a);
-    hipLaunchKernelGGL(k_reduce_slabs, dim3((WG_SLAB + 255) / 256), dim3(256), 0, s, workspace, grid, WG_SLAB, dw,
-                       32 * 288, db);
+    float *part2 = workspace + (size_t)grid * WG_SLAB;
+    hipLaunchKernelGGL(k_reduce_slabs_l1, dim3((WG_SLAB + 255) / 256, RG), dim3(256), 0, s, workspace, grid, WG_SLAB,
+                       part2);
+    hipLaunchKernelGGL(k_reduce_slabs_l2, dim3((WG_SLAB + 255) / 256), dim3(256), 0, s, part2, WG_SLAB, dw, 32 * 288,
+                       db);
     return augcl::check_launch(name);
 }
 
@@ -682,7 +751,7 @@ int augcl_enc_conv_first_backward_weights(const float *x, const float *dz, float
     if (lds < red) lds = red;
     const int grid = grid_for(a.n_items, 1);
     const int slab = 32 * K + 32;
-    AUGCL_REQUIRE(workspace_bytes >= (size_t)grid * slab * 4, "%s: workspace too small", name);
+    AUGCL_REQUIRE(workspace_bytes >= (size_t)(grid + RG) * slab * 4, "%s: workspace too small", name);
     hipStream_t s = as_stream(stream);
 #define LAUNCH_WG1(NTV)                                                      \
     do {                                                                     \
@@ -699,7 +768,9 @@ int augcl_enc_conv_first_backward_weights(const float *x, const float *dz, float
         return augcl::fail(AUGCL_E_UNSUPPORTED, "%s: %d input channels not supported (max 17)", name, C);
     }
 #undef LAUNCH_WG1
-    hipLaunchKernelGGL(k_reduce_slabs, dim3((slab + 255) / 256), dim3(256), 0, s, workspace, grid, slab, dw, 32 * K, db);
+    float *part2 = workspace + (size_t)grid * slab;
+    hipLaunchKernelGGL(k_reduce_slabs_l1, dim3((slab + 255) / 256, RG), dim3(256), 0, s, workspace, grid, slab, part2);
+    hipLaunchKernelGGL(k_reduce_slabs_l2, dim3((slab + 255) / 256), dim3(256), 0, s, part2, slab, dw, 32 * K, db);
     return augcl::check_launch(name);
 }
 

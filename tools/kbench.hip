@@ -87,6 +87,17 @@ int main(int argc, char **argv)
     vs.push_back({"conv ABL1 no sigmoid", f2f, [&](int k) { hipLaunchKernelGGL((k_conv<84, 84, 12, 256, float, false, 1>), dim3(B * 3 * 7), dim3(256), 0, 0, fin[k], (float *)nullptr, fout[k], B * 3, 3, 0, (const int32_t *)nullptr, (const int32_t *)nullptr, w, 0, 0, 0); }});
     vs.push_back({"conv ABL2 1/3 fma", f2f, [&](int k) { hipLaunchKernelGGL((k_conv<84, 84, 12, 256, float, false, 2>), dim3(B * 3 * 7), dim3(256), 0, 0, fin[k], (float *)nullptr, fout[k], B * 3, 3, 0, (const int32_t *)nullptr, (const int32_t *)nullptr, w, 0, 0, 0); }});
     vs.push_back({"conv ABL3 stage+copy only", f2f, [&](int k) { hipLaunchKernelGGL((k_conv<84, 84, 12, 256, float, false, 3>), dim3(B * 3 * 7), dim3(256), 0, 0, fin[k], (float *)nullptr, fout[k], B * 3, 3, 0, (const int32_t *)nullptr, (const int32_t *)nullptr, w, 0, 0, 0); }});
+    {
+        static JitterParams jp; jp.order[0] = 1; jp.order[1] = 2; jp.order[2] = 3; jp.order[3] = 0;
+        jp.c_r = 1.2f; jp.c_inv = -0.2f; jp.s_r = 0.8f; jp.s_inv = 0.2f; jp.hue = 0.1f; jp.bound = 1.0f; jp.scale = 255.0f;
+        const int n = 84 * 84;
+        vs.push_back({"jitter product", f2f, [&](int k) { static int32_t ord[4] = {1, 2, 3, 0}; augcl_color_jitter_f32(fout[k], B, 3, 84, 84, nullptr, 0, ord, 1.2, 0.8, 0.1, 1.0f, 255.0f, 0); }});
+        vs.push_back({"jitter reg<1024,2,4>", f2f, [&, n](int k) { hipLaunchKernelGGL((k_color_jitter_reg<1024, 2, 4>), dim3(B * 3), dim3(1024), 0, 0, fout[k], n, (const int32_t *)nullptr, 0, jp); }});
+        vs.push_back({"jitter reg<1024,2,8> (spills)", f2f, [&, n](int k) { hipLaunchKernelGGL((k_color_jitter_reg<1024, 2, 8>), dim3(B * 3), dim3(1024), 0, 0, fout[k], n, (const int32_t *)nullptr, 0, jp); }});
+        vs.push_back({"jitter reg<512,4,2>", f2f, [&, n](int k) { hipLaunchKernelGGL((k_color_jitter_reg<512, 4, 2>), dim3(B * 3), dim3(512), 0, 0, fout[k], n, (const int32_t *)nullptr, 0, jp); }});
+        vs.push_back({"jitter reg<256,7,1>", f2f, [&, n](int k) { hipLaunchKernelGGL((k_color_jitter_reg<256, 7, 1>), dim3(B * 3), dim3(256), 0, 0, fout[k], n, (const int32_t *)nullptr, 0, jp); }});
+        vs.push_back({"jitter reg<256,7,2>", f2f, [&, n](int k) { hipLaunchKernelGGL((k_color_jitter_reg<256, 7, 2>), dim3(B * 3), dim3(256), 0, 0, fout[k], n, (const int32_t *)nullptr, 0, jp); }});
+    }
     vs.push_back({"copy parts=1", f2f, [&](int k) { hipLaunchKernelGGL((k_copy_parts<84, 84, 1>), dim3(B * 9), dim3(256), 0, 0, fin[k], fout[k]); }});
     vs.push_back({"copy parts=3", f2f, [&](int k) { hipLaunchKernelGGL((k_copy_parts<84, 84, 3>), dim3(B * 9 * 3), dim3(256), 0, 0, fin[k], fout[k]); }});
     vs.push_back({"copy parts=7", f2f, [&](int k) { hipLaunchKernelGGL((k_copy_parts<84, 84, 7>), dim3(B * 9 * 7), dim3(256), 0, 0, fin[k], fout[k]); }});
