@@ -21,6 +21,8 @@
 //     of ceil(C/2) (one zero plane pads an odd C).
 #include "augcl_common.h"
 
+#include <algorithm>
+
 namespace augcl {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -67,17 +69,15 @@ __device__ __forceinline__ void wave_copy_runs2(const float *__restrict__ g0, co
     for (int c0 = 0; c0 < nfull; c0 += 64 * UN) {
         f32x4ua v0[UN], v1[UN];
 #pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const int c = c0 + u * 64 + lane;
-            if (c < nfull) {
-                v0[u] = *reinterpret_cast<const f32x4ua *>(g0 + 4 * c);
-                v1[u] = *reinterpret_cast<const f32x4ua *>(g1 + 4 * c);
-            }
+        for (int u = 0; u < UN; ++u) { // branch-free: chunks past the end are clamped to the last one (idempotent)
+            const int c = min(c0 + u * 64 + lane, nfull - 1);
+            v0[u] = *reinterpret_cast<const f32x4ua *>(g0 + 4 * c);
+            v1[u] = *reinterpret_cast<const f32x4ua *>(g1 + 4 * c);
         }
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-            const int c = c0 + u * 64 + lane;
-            if (c < nfull) {
+            const int c = min(c0 + u * 64 + lane, nfull - 1);
+            {
                 if (VECST) { // destination 16-byte aligned: one ds_write_b128
                     *reinterpret_cast<float4 *>(d0 + 4 * c) = make_float4(xf(v0[u].x), xf(v0[u].y), xf(v0[u].z), xf(v0[u].w));
                     *reinterpret_cast<float4 *>(d1 + 4 * c) = make_float4(xf(v1[u].x), xf(v1[u].y), xf(v1[u].z), xf(v1[u].w));
@@ -109,26 +109,34 @@ struct XfId {
 
 __device__ __forceinline__ int round4(int v) { return (v + 3) & ~3; }
 
-// LDS image of k_conv32: [guard G][32 planes of `plane` words][guard G][32 bias]; a plane mirrors the
-// channel's memory rows (row stride Wi).  MODE 1 (backward-data) keeps NO padding in LDS: taps that fall
-// outside dZ are zeroed with a per-lane select in front of the MFMA (9 masks per tile), the guards only
-// keep those discarded reads inside the allocation.
-template <int MODE>
-__global__ __launch_bounds__(256, 2) void k_conv32(ConvArgs a)
+// k_conv32: 512 threads = 4 COMPUTE waves (one per SIMD: they own the MFMA pipe and keep the 144 weights
+// in registers) + 4 LOADER waves that stage the NEXT item's tile into the other half of a double-buffered
+// LDS image while the compute waves run the current one.  One workgroup per CU, one barrier per item.
+// (Two independent 256-thread workgroups per CU ran in lockstep -- same program, same start -- so their
+// staging and MFMA phases never overlapped: ablation showed t = t_mfma + t_rest, not max.)
+// LDS image per buffer: [guard G][32 planes of `plane` words][guard G]; a plane mirrors the channel's
+// memory rows (row stride Wi).  MODE 1 (backward-data) keeps NO padding in LDS: taps that fall outside dZ
+// are zeroed with a per-lane select in front of the MFMA, the guards only keep those discarded reads
+// inside the allocation.
+template <int MODE, int ABL = 0> // ABL: developer ablation switch (tools/ebench), 0 = product
+__global__ __launch_bounds__(512, 2) void k_conv32(ConvArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];
     constexpr int P = MODE ? 2 : 0;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // scalar: role / loop control on the SALU
+    const bool loader = wave >= 4;
+    const int cw = wave & 3; // index inside the role
     const int l31 = lane & 31, h = lane >> 5;
     const int Wi = a.Wi;
     const int plane = round4((a.RT + 2) * Wi);
     const int G = MODE ? round4(2 * Wi + 4) : 0;
-    float *lds = lds_raw + G;
-    float *lbias = lds_raw + 2 * G + 32 * plane;
+    const int mwords = MODE ? round4(a.RT * a.Wo) : 0; // backward-data: ReLU gate bits, one word per strip pixel
+    const int bufw = 2 * G + 32 * plane + mwords;        // words per buffer
+    float *lbias = lds_raw + 2 * bufw;
 
-    // ---- per-lane weights, resident for the whole launch: wreg[cil*9 + t] = Weff[row l31][col cil+16h][t]
     float wreg[144];
-    {
+    if (!loader) {
         if (MODE == 0) {
             const float *wp = a.w + (size_t)l31 * 288 + h * 144; // contiguous 144 floats
 #pragma unroll
@@ -146,70 +154,133 @@ __global__ __launch_bounds__(256, 2) void k_conv32(ConvArgs a)
     }
     if (tid < 32) lbias[tid] = (MODE == 0 && a.bias) ? a.bias[tid] : 0.0f;
 
-    for (int item = blockIdx.x; item < a.n_items; item += gridDim.x) {
+    // stage item `it` into buffer `bi` (loader waves only): wave cw copies channels 8cw .. 8cw+7, four
+    // channel pairs back to back => 24 dwordx4 per lane in flight, one exposed latency per item
+    auto stage = [&](int item, int bi) {
         const int b = item / a.S, s = item - b * a.S;
         const int y0 = s * a.RT;
-        const int rows = min(a.RT, a.Ho - y0); // output rows of this strip
-        const int npix = rows * a.Wo;
-        // input rows [r0, r1) feed this strip (MODE 1: clipped to dZ; taps outside are masked to zero)
+        const int rows = min(a.RT, a.Ho - y0);
         const int r0 = MODE ? max(0, y0 - P) : y0;
         const int r1 = MODE ? min(a.Hi, y0 + rows) : y0 + rows + 2;
-        __syncthreads(); // previous item's readers are done with the tile
-        {
-            const int run = (r1 - r0) * Wi;
-            const float *src = a.in + ((size_t)b * 32 * a.Hi + r0) * Wi;
-            const size_t cs = (size_t)a.Hi * Wi;
-            for (int ci = wave * 2; ci < 32; ci += 8) // wave w: channel pairs (2w,2w+1), (2w+8,2w+9), ...
-                wave_copy_runs2<3>(src + ci * cs, src + (ci + 1) * cs, lds + ci * plane, lds + (ci + 1) * plane, run,
-                                   lane, XfId());
+        const int run = (r1 - r0) * Wi;
+        const float *src = a.in + ((size_t)b * 32 * a.Hi + r0) * Wi;
+        const size_t cs = (size_t)a.Hi * Wi;
+        float *dst = lds_raw + bi * bufw + G;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ci = 8 * cw + 2 * k;
+            wave_copy_runs2<3>(src + ci * cs, src + (ci + 1) * cs, dst + ci * plane, dst + (ci + 1) * plane, run, lane,
+                               XfId());
         }
-        __syncthreads();
-        // ---- M-tiles of 32 consecutive strip pixels, round-robin over the 4 waves
-        const int ntiles = (npix + 31) >> 5;
-        for (int tile = wave; tile < ntiles; tile += 4) {
-            int m = tile * 32 + l31;
-            const bool valid = m < npix;
-            if (!valid) m = npix - 1; // read a real pixel, discard the result
-            const int yy = m / a.Wo, xx = m - yy * a.Wo;
-            // top-left tap of this pixel inside the staged rows (may lie in the guard for MODE 1)
-            const float *base = lds + ((y0 + yy - P - r0) * Wi + (xx - P)) + h * 16 * plane;
-            bool rowok[3], colok[3];
+        if (MODE == 1 && a.mask != nullptr) {
+            // ReLU gate of the layer below, packed by the LOADER waves: word[m] bit co = (a_prev[b,co,y0*Wo+m] > 0).
+            // 32 coalesced loads in flight per lane; the compute waves' epilogue then needs one ds_read instead
+            // of 16 dependent global loads per tile (which exposed ~2 us of latency per tile).
+            uint32_t *mw = reinterpret_cast<uint32_t *>(lds_raw + bi * bufw + 2 * G + 32 * plane);
+            const int npix = rows * a.Wo;
+            const int chw = a.Ho * a.Wo;
+            const float *mp = a.mask + (size_t)b * 32 * chw + (size_t)y0 * a.Wo;
+            for (int m = cw * 64 + lane; m < npix; m += 256) {
+                uint32_t w = 0;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                rowok[k] = MODE == 0 || ((unsigned)(y0 + yy + k - P) < (unsigned)a.Hi);
-                colok[k] = MODE == 0 || ((unsigned)(xx + k - P) < (unsigned)Wi);
+                for (int half = 0; half < 2; ++half) {
+                    float v[16];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) v[k] = mp[(size_t)(16 * half + k) * chw + m];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) w |= (v[k] > 0.0f ? 1u : 0u) << (16 * half + k);
+                }
+                mw[m] = w;
             }
-            f32x16 acc;
+        }
+    };
+
+    int it = 0;
+    const int first = blockIdx.x;
+    if (loader && first < a.n_items && ABL != 1) stage(first, 0);
+    __syncthreads();
+    for (int item = first; item < a.n_items; item += gridDim.x, ++it) {
+        const int next = item + gridDim.x;
+        if (loader) {
+            if (next < a.n_items && ABL != 1) stage(next, (it + 1) & 1);
+        } else {
+            const int b = item / a.S, s = item - b * a.S;
+            const int y0 = s * a.RT;
+            const int rows = min(a.RT, a.Ho - y0); // output rows of this strip
+            const int npix = rows * a.Wo;
+            const int r0 = MODE ? max(0, y0 - P) : y0;
+            const float *lds = lds_raw + (it & 1) * bufw + G;
+            const uint32_t *maskw = reinterpret_cast<const uint32_t *>(lds_raw + (it & 1) * bufw + 2 * G + 32 * plane);
+            // ---- M-tiles of 32 consecutive strip pixels, round-robin over the 4 compute waves
+            const int ntiles = (npix + 31) >> 5;
+            for (int tile = cw; tile < ntiles; tile += 4) {
+                int m = tile * 32 + l31;
+                const bool valid = m < npix;
+                if (!valid) m = npix - 1; // read a real pixel, discard the result
+                const int yy = m / a.Wo, xx = m - yy * a.Wo;
+                // top-left tap of this pixel inside the staged rows (may lie in the guard for MODE 1)
+                const float *base = lds + ((y0 + yy - P - r0) * Wi + (xx - P)) + h * 16 * plane;
+                bool rowok[3], colok[3];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = lbias[acc_row(r, h)];
+                for (int k = 0; k < 3; ++k) {
+                    rowok[k] = MODE == 0 || ((unsigned)(y0 + yy + k - P) < (unsigned)a.Hi);
+                    colok[k] = MODE == 0 || ((unsigned)(xx + k - P) < (unsigned)Wi);
+                }
+                f32x16 acc;
 #pragma unroll
-            for (int cil = 0; cil < 16; ++cil) {
-                const float *pc = base + cil * plane;
+                for (int r = 0; r < 16; ++r) acc[r] = lbias[acc_row(r, h)];
+                // explicit software pipeline: the 9 taps of channel cil+1 are in flight while the 9 MFMAs of
+                // channel cil issue (one wave per SIMD must never wait on a just-issued ds_read)
+                float xa[9], xb[9];
+                constexpr int NC = (ABL == 2 ? 2 : 16);
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
+                for (int t = 0; t < 9; ++t) xa[t] = base[(t / 3) * Wi + (t % 3)];
 #pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        float xv = pc[ky * Wi + kx];
-                        if (MODE == 1) xv = (rowok[ky] && colok[kx]) ? xv : 0.0f;
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[cil * 9 + ky * 3 + kx], xv, acc, 0, 0, 0);
+                for (int cil = 0; cil < NC; cil += 2) {
+                    const float *p1 = base + (cil + 1) * plane;
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) xb[t] = p1[(t / 3) * Wi + (t % 3)];
+                    __builtin_amdgcn_sched_barrier(0); // keep the 9 reads AHEAD of the MFMA group (hipcc sinks them)
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {
+                        float xv = xa[t];
+                        if (MODE == 1) xv = (rowok[t / 3] && colok[t % 3]) ? xv : 0.0f;
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[cil * 9 + t], xv, acc, 0, 0, 0);
                     }
-            }
-            if (valid) {
-                const int y = y0 + yy;
-                const size_t o0 = ((size_t)b * 32 * a.Ho + y) * a.Wo + xx;
+                    if (cil + 2 < NC) {
+                        const float *p2 = base + (cil + 2) * plane;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const size_t o = o0 + (size_t)acc_row(r, h) * a.Ho * a.Wo;
-                    float v = acc[r];
-                    if (MODE == 0) {
-                        if (a.relu) v = fmaxf(v, 0.0f);
-                    } else if (a.mask) {
-                        v = a.mask[o] > 0.0f ? v : 0.0f;
+                        for (int t = 0; t < 9; ++t) xa[t] = p2[(t / 3) * Wi + (t % 3)];
                     }
-                    a.out[o] = v;
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {
+                        float xv = xb[t];
+                        if (MODE == 1) xv = (rowok[t / 3] && colok[t % 3]) ? xv : 0.0f;
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[(cil + 1) * 9 + t], xv, acc, 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (valid && (ABL != 3 || acc[0] == 12345.678f)) {
+                    const int y = y0 + yy;
+                    const int chw = a.Ho * a.Wo; // 32-bit offsets: the host checks B*32*Ho*Wo < 2^31
+                    const int o0 = (b * 32 * a.Ho + y) * a.Wo + xx + 4 * h * chw;
+                    const uint32_t gate = (MODE == 1 && a.mask) ? (maskw[m] >> (4 * h)) : 0xffffffffu;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int o = o0 + ((r & 3) + 8 * (r >> 2)) * chw;
+                        float v = acc[r];
+                        if (MODE == 0) {
+                            if (a.relu) v = fmaxf(v, 0.0f);
+                        } else {
+                            v = ((gate >> ((r & 3) + 8 * (r >> 2))) & 1u) ? v : 0.0f;
+                        }
+                        a.out[o] = v;
+                    }
                 }
             }
         }
+        __syncthreads(); // next tile landed AND current tile's readers are done
     }
 }
 
@@ -317,15 +388,25 @@ struct WgradArgs {
 
 constexpr int WG_SLAB = 32 * 288 + 32;
 
+// One 256-thread workgroup per CU (the 144 accumulators + operands need the whole 512-register budget, so
+// there is no room for loader waves as in k_conv32).  Staging is REGISTER double-buffered instead: the global
+// loads of item i+1 (<= 24 dwordx4 + 16 tail dwords per lane) are issued before the MFMA loop of item i, land
+// while it runs, and are written to the other LDS buffer afterwards -- one barrier per item.
+// The host picks RT so that a channel's A run fits 2 and its dZ run 1 dwordx4 per lane (see the launcher).
+struct WgPrefetch { // lane-contiguous dwords: conflict-free ds_write_b32 into the odd-stride planes
+    float a[8][8], z[8][4];
+};
+
+template <int ABL = 0>
 __global__ __launch_bounds__(256, 1) void k_wgrad32(WgradArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // scalar: loop bounds stay on the SALU
     const int l31 = lane & 31, h = lane >> 5;
     const int planeA = ((a.RT + 2) * a.Wi) | 1;
     const int planeZ = (a.RT * a.Wo) | 1;
-    float *ldsA = lds;
-    float *ldsZ = lds + 32 * planeA;
+    const int bufw = 32 * planeA + 32 * planeZ;
 
     f32x16 acc[9];
 #pragma unroll
@@ -334,46 +415,108 @@ __global__ __launch_bounds__(256, 1) void k_wgrad32(WgradArgs a)
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
     float dbacc = 0.0f;
 
-    for (int item = blockIdx.x; item < a.n_items; item += gridDim.x) {
+    // wave w owns channels 8w .. 8w+7 of both tiles
+    auto issue = [&](int item, WgPrefetch &pf) {
         const int b = item / a.S, s = item - b * a.S;
         const int y0 = s * a.RT;
         const int rows = min(a.RT, a.Ho - y0);
-        const int npix = rows * a.Wo;
-        __syncthreads();
+        const int runA = (rows + 2) * a.Wi, runZ = rows * a.Wo;
+        const float *src = a.act + ((size_t)b * 32 * a.Hi + y0) * a.Wi; // rows contiguous in NCHW
+        const float *sz = a.dz + ((size_t)b * 32 * a.Ho + y0) * a.Wo;
+        const size_t csA = (size_t)a.Hi * a.Wi, csZ = (size_t)a.Ho * a.Wo;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float *ga = src + (8 * wave + k) * csA, *gz = sz + (8 * wave + k) * csZ;
+            // branch-free: indices past the run are clamped to its last element (a duplicate load / store of
+            // the same value to the same address) -- predicated loads compile to one exec-masked block each
+#pragma unroll
+            for (int u = 0; u < 8; ++u) pf.a[k][u] = ga[min(lane + 64 * u, runA - 1)];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) pf.z[k][u] = gz[min(lane + 64 * u, runZ - 1)];
+        }
+    };
+    auto commit = [&](int item, int bi, const WgPrefetch &pf) {
+        const int s = item % a.S;
+        const int rows = min(a.RT, a.Ho - s * a.RT);
+        const int runA = (rows + 2) * a.Wi, runZ = rows * a.Wo;
+        float *ldsA = lds + bi * bufw, *ldsZ = ldsA + 32 * planeA;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float *da = ldsA + (8 * wave + k) * planeA, *dz = ldsZ + (8 * wave + k) * planeZ;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) da[min(lane + 64 * u, runA - 1)] = pf.a[k][u];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) dz[min(lane + 64 * u, runZ - 1)] = pf.z[k][u];
+        }
+    };
+
+    WgPrefetch pf;
+    int it = 0;
+    const int first = blockIdx.x;
+    if (first < a.n_items) {
+        issue(first, pf);
+        commit(first, 0, pf);
+    }
+    __syncthreads();
+    for (int item = first; item < a.n_items; item += gridDim.x, ++it) {
+        const int next = item + gridDim.x;
+        if (next < a.n_items && ABL != 1) issue(next, pf);
+        __builtin_amdgcn_sched_barrier(0);
         {
-            const int runA = (rows + 2) * a.Wi;
-            const float *src = a.act + ((size_t)b * 32 * a.Hi + y0) * a.Wi; // rows contiguous in NCHW
-            const float *sz = a.dz + ((size_t)b * 32 * a.Ho + y0) * a.Wo;
-            const size_t csA = (size_t)a.Hi * a.Wi, csZ = (size_t)a.Ho * a.Wo;
-            for (int c = wave * 2; c < 32; c += 8) {
-                wave_copy_runs2<3, false>(src + c * csA, src + (c + 1) * csA, ldsA + c * planeA, ldsA + (c + 1) * planeA,
-                                          runA, lane, XfId());
-                wave_copy_runs2<3, false>(sz + c * csZ, sz + (c + 1) * csZ, ldsZ + c * planeZ, ldsZ + (c + 1) * planeZ,
-                                          npix, lane, XfId());
+            const int s = item % a.S;
+            const int y0 = s * a.RT;
+            const int rows = min(a.RT, a.Ho - y0);
+            const int npix = rows * a.Wo;
+            const float *ldsA = lds + (it & 1) * bufw, *ldsZ = ldsA + 32 * planeA;
+            const int npair = (npix + 1) >> 1;
+            // operands of pixel pair pr: z = dZ[co=l31][p], xv[t] = A[ci=l31][p + tap t]  (p = 2 pr + h).
+            // Each wave walks p, p+8, p+16, ...: (yy,xx) advance incrementally (no division in the loop).
+            int pn = 2 * wave + h, yn = pn / a.Wo, xn = pn - yn * a.Wo; // NEXT pair to be loaded
+            const int ylast = (npix - 1) / a.Wo, xlast = (npix - 1) - ylast * a.Wo;
+            auto ldnext = [&](float &z, float (&xv)[9], bool &valid) {
+                valid = pn < npix; // the odd tail pixel: read real data, zero dZ at USE time (no wait on the load here)
+                const int p = valid ? pn : npix - 1;
+                const int yy = valid ? yn : ylast, xx = valid ? xn : xlast;
+                z = ldsZ[l31 * planeZ + p];
+                const float *pa = ldsA + l31 * planeA + yy * a.Wi + xx;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) xv[t] = pa[(t / 3) * a.Wi + (t % 3)];
+                pn += 8;
+                xn += 8;
+                if (xn >= a.Wo) { // Wo >= 8 is guaranteed by the launcher => at most one wrap
+                    xn -= a.Wo;
+                    ++yn;
+                }
+            };
+            float z0, z1, x0[9], x1[9];
+            bool v0 = true, v1 = true;
+            int pr = wave;
+            if (pr < npair) ldnext(z0, x0, v0);
+            for (; pr < npair; pr += 8) { // two pairs per trip: the next pair's 10 LDS reads fly under 9 MFMAs
+                if (pr + 4 < npair) ldnext(z1, x1, v1);
+                __builtin_amdgcn_sched_barrier(0);
+                z0 = v0 ? z0 : 0.0f;
+                dbacc += z0;
+#pragma unroll
+                for (int t = 0; t < (ABL == 2 ? 1 : 9); ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(z0, x0[t], acc[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (pr + 8 < npair) ldnext(z0, x0, v0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (pr + 4 < npair) {
+                    z1 = v1 ? z1 : 0.0f;
+                    dbacc += z1;
+#pragma unroll
+                    for (int t = 0; t < (ABL == 2 ? 1 : 9); ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(z1, x1[t], acc[t], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
+        if (next < a.n_items && ABL != 1) commit(next, (it + 1) & 1, pf);
         __syncthreads();
-        const int npair = (npix + 1) >> 1;
-        for (int pr = wave; pr < npair; pr += 4) {
-            int p = 2 * pr + h;
-            const bool valid = p < npix;
-            if (!valid) p = npix - 1;
-            const int yy = p / a.Wo, xx = p - yy * a.Wo;
-            float z = ldsZ[l31 * planeZ + p];
-            if (!valid) z = 0.0f;
-            dbacc += z;
-            const float *pa = ldsA + l31 * planeA + yy * a.Wi + xx;
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx)
-                    acc[ky * 3 + kx] =
-                        __builtin_amdgcn_mfma_f32_32x32x2f32(z, pa[ky * a.Wi + kx], acc[ky * 3 + kx], 0, 0, 0);
-        }
     }
     // ---- fixed-order reduction over the 4 waves through LDS, then one slab per workgroup
     // lane (ci = l31, h) holds dW[co = acc_row(r,h)][ci][t] in acc[t][r]
-    __syncthreads();
     float *slab = a.partial + (size_t)blockIdx.x * WG_SLAB;
     for (int w = 1; w < 4; ++w) {
         if (wave == w) {
@@ -562,6 +705,7 @@ using namespace augcl;
 namespace {
 
 constexpr int kMaxLds = 76 * 1024; // two workgroups per CU within the 160 KiB LDS
+constexpr int kBufLds = 78 * 1024; // one of the two tile buffers of a double-buffered, one-per-CU workgroup
 
 int pick_rt(int Ho, int words_per_row_pair /* LDS words per output row (all planes) */, int extra_rows,
             int max_lds_bytes, int *S)
@@ -609,15 +753,16 @@ int augcl_enc_conv32_forward(const float *in, const float *w, const float *bias,
     if (B == 0) return AUGCL_OK;
     AUGCL_REQUIRE(in && w && out, "%s: null tensor", name);
     AUGCL_REQUIRE(aligned16(w), "%s: weights must be 16-byte aligned", name);
+    AUGCL_REQUIRE((size_t)B * 32 * Hi * Wi < ((size_t)1 << 31), "%s: tensor too large for 32-bit offsets", name);
     ConvArgs a{};
     a.in = in; a.w = w; a.bias = bias; a.mask = nullptr; a.out = out;
     a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ho = Hi - 2; a.Wo = Wi - 2; a.relu = relu;
-    a.RT = pick_rt(a.Ho, 32 * Wi, 2, kMaxLds - 1024, &a.S);
+    a.RT = pick_rt(a.Ho, 32 * Wi, 2, kBufLds, &a.S);
     AUGCL_REQUIRE(a.RT > 0, "%s: image row too wide for LDS (W=%d)", name, Wi);
     a.n_items = B * a.S;
-    const size_t lds = ((size_t)32 * (((a.RT + 2) * Wi + 3) & ~3) + 32) * 4;
+    const size_t lds = (2 * (size_t)32 * (((a.RT + 2) * Wi + 3) & ~3) + 32) * 4;
     if (int rc = set_lds(k_conv32<0>, lds, name)) return rc;
-    hipLaunchKernelGGL(k_conv32<0>, dim3(grid_for(a.n_items, 2)), dim3(256), lds, as_stream(stream), a);
+    hipLaunchKernelGGL(k_conv32<0>, dim3(grid_for(a.n_items, 1)), dim3(512), lds, as_stream(stream), a);
     return augcl::check_launch(name);
 }
 
@@ -628,16 +773,17 @@ int augcl_enc_conv32_backward_data(const float *dz, const float *w, const float 
     AUGCL_REQUIRE(B >= 0 && Ho >= 1 && Wo >= 1, "%s: bad shape", name);
     if (B == 0) return AUGCL_OK;
     AUGCL_REQUIRE(dz && w && dact, "%s: null tensor", name);
+    AUGCL_REQUIRE((size_t)B * 32 * (Ho + 2) * (Wo + 2) < ((size_t)1 << 31), "%s: tensor too large for 32-bit offsets", name);
     ConvArgs a{};
     a.in = dz; a.w = w; a.bias = nullptr; a.mask = act_prev; a.out = dact;
     a.B = B; a.Hi = Ho; a.Wi = Wo; a.Ho = Ho + 2; a.Wo = Wo + 2; a.relu = 0;
     const int G = (2 * Wo + 4 + 3) & ~3;
-    a.RT = pick_rt(a.Ho, 32 * Wo, 2, kMaxLds - 1024 - 8 * G, &a.S);
+    a.RT = pick_rt(a.Ho, 32 * Wo + a.Wo, 2, kBufLds - 8 * G - 64, &a.S);
     AUGCL_REQUIRE(a.RT > 0, "%s: image row too wide for LDS (W=%d)", name, Wo);
     a.n_items = B * a.S;
-    const size_t lds = ((size_t)32 * (((a.RT + 2) * Wo + 3) & ~3) + 2 * G + 32) * 4;
+    const size_t lds = (2 * ((size_t)32 * (((a.RT + 2) * Wo + 3) & ~3) + 2 * G + ((a.RT * a.Wo + 3) & ~3)) + 32) * 4;
     if (int rc = set_lds(k_conv32<1>, lds, name)) return rc;
-    hipLaunchKernelGGL(k_conv32<1>, dim3(grid_for(a.n_items, 2)), dim3(256), lds, as_stream(stream), a);
+    hipLaunchKernelGGL(k_conv32<1>, dim3(grid_for(a.n_items, 1)), dim3(512), lds, as_stream(stream), a);
     return augcl::check_launch(name);
 }
 
@@ -698,23 +844,25 @@ int augcl_enc_conv32_backward_weights(const float *act_prev, const float *dz, fl
     a.act = act_prev; a.dz = dz; a.partial = workspace;
     a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ho = Hi - 2; a.Wo = Wi - 2;
     // LDS words per output row: A rows (32*Wi) + Z rows (32*Wo); +2 halo rows of A; + slack for the odd strides
-    const int budget = 150 * 1024; // one workgroup per CU: 144 accumulators leave no room for a second
+    const int budget = kBufLds; // per buffer of the double-buffered {A, dZ} tile pair (one workgroup per CU)
     int rt = (budget / 4 - 64 * Wi - 64) / (32 * Wi + 32 * a.Wo);
-    AUGCL_REQUIRE(rt >= 1, "%s: image row too wide for LDS", name);
+    // register prefetch geometry: an A run (rt+2 rows) fits 8, a dZ run (rt rows) 4 dwords per lane
+    rt = std::min(rt, std::min(512 / Wi - 2, 256 / a.Wo));
+    AUGCL_REQUIRE(rt >= 1 && a.Wo >= 8, "%s: unsupported width %d (need 10 <= W <= 170)", name, Wi);
     if (rt > a.Ho) rt = a.Ho;
     a.S = (a.Ho + rt - 1) / rt;
     a.RT = (a.Ho + a.S - 1) / a.S;
     a.n_items = B * a.S;
     const int planeA = ((a.RT + 2) * Wi) | 1, planeZ = (a.RT * a.Wo) | 1;
-    size_t lds = (size_t)(32 * planeA + 32 * planeZ) * 4;
-    const size_t red = (size_t)(145 * 64) * 4; // wave-reduction scratch reuses the tile
+    size_t lds = 2 * (size_t)(32 * planeA + 32 * planeZ) * 4;
+    const size_t red = (size_t)(145 * 64) * 4; // wave-reduction scratch reuses the tiles
     if (lds < red) lds = red;
     const int grid = grid_for(a.n_items, 1);
     AUGCL_REQUIRE(workspace_bytes >= (size_t)(grid + RG) * WG_SLAB * 4, "%s: workspace too small (%zu < %zu)", name,
                   workspace_bytes, (size_t)(grid + RG) * WG_SLAB * 4);
-    if (int rc = set_lds(k_wgrad32, lds, name)) return rc;
+    if (int rc = set_lds(k_wgrad32<0>, lds, name)) return rc;
     hipStream_t s = as_stream(stream);
-    hipLaunchKernelGGL(k_wgrad32, dim3(grid), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(k_wgrad32<0>, dim3(grid), dim3(256), lds, s, a);
     float *part2 = workspace + (size_t)grid * WG_SLAB;
     hipLaunchKernelGGL(k_reduce_slabs_l1, dim3((WG_SLAB + 255) / 256, RG), dim3(256), 0, s, workspace, grid, WG_SLAB,
                        part2);

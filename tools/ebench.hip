@@ -1,0 +1,80 @@
+// tools/ebench.hip -- developer microbenchmark for the encoder kernels (not part of the product).
+#include "../augcl_amd/csrc/encoder_kernels.hip"
+#include <algorithm>
+#include <functional>
+#include <string>
+#include <vector>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
+using namespace augcl;
+struct V { std::string name; double flop; std::function<void()> run; };
+// register-only f32 MFMA loop: the practical MFMA ceiling (clock under load) on this chip
+__global__ __launch_bounds__(256, 1) void k_mfma_peak(float *out, int iters, float a0)
+{
+    f32x16 acc[4];
+    for (int t = 0; t < 4; ++t) for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float a = a0 + threadIdx.x * 1e-3f, b = 1.0f + threadIdx.x * 1e-4f;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int t = 0; t < 4; ++t) for (int r = 0; r < 16; ++r) s += acc[t][r];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+template <int MODE, int ABL>
+static void launch_conv(const float *in, const float *w, const float *bias, const float *mask, float *out, int B, int Hi, int Wi, int per_cu = 1)
+{
+    ConvArgs a{}; a.in = in; a.w = w; a.bias = bias; a.mask = mask; a.out = out; a.B = B; a.Hi = Hi; a.Wi = Wi; a.relu = 1;
+    size_t lds;
+    if (MODE == 0) { a.Ho = Hi - 2; a.Wo = Wi - 2; a.RT = pick_rt(a.Ho, 32 * Wi, 2, kBufLds, &a.S); lds = (2 * (size_t)32 * (((a.RT + 2) * Wi + 3) & ~3) + 32) * 4; }
+    else { a.Ho = Hi + 2; a.Wo = Wi + 2; const int G = (2 * Wi + 4 + 3) & ~3; a.RT = pick_rt(a.Ho, 32 * Wi + a.Wo, 2, kBufLds - 8 * G - 64, &a.S); lds = (2 * ((size_t)32 * (((a.RT + 2) * Wi + 3) & ~3) + 2 * G + ((a.RT * a.Wo + 3) & ~3)) + 32) * 4; }
+    a.n_items = B * a.S;
+    set_lds(k_conv32<MODE, ABL>, lds, "x");
+    hipLaunchKernelGGL((k_conv32<MODE, ABL>), dim3(grid_for(a.n_items, per_cu)), dim3(512), lds, 0, a);
+}
+int main(int argc, char **argv)
+{
+    const int B = argc > 1 ? atoi(argv[1]) : 256;
+    const int H = argc > 2 ? atoi(argv[2]) : 41;
+    const size_t nin = (size_t)B * 32 * H * H, nout = (size_t)B * 32 * (H + 2) * (H + 2);
+    float *in, *out, *w, *bias, *mask, *ws, *dw, *db;
+    CK(hipMalloc(&in, nout * 4)); CK(hipMalloc(&out, nout * 4)); CK(hipMalloc(&mask, nout * 4));
+    CK(hipMalloc(&w, 9216 * 4)); CK(hipMalloc(&bias, 128)); CK(hipMalloc(&dw, 9216 * 4)); CK(hipMalloc(&db, 128));
+    const size_t wsb = augcl_enc_wgrad_workspace_bytes(32); CK(hipMalloc(&ws, wsb));
+    std::vector<float> h(nout); for (size_t i = 0; i < nout; ++i) h[i] = (float)((i * 2654435761u >> 9) & 1023) / 512.f - 0.7f;
+    CK(hipMemcpy(in, h.data(), nout * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(mask, h.data(), nout * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(w, h.data(), 9216 * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(bias, h.data(), 128, hipMemcpyHostToDevice));
+    const double f_fwd = 2.0 * 288 * 32 * B * (H - 2) * (H - 2), f_bwd = 2.0 * 288 * 32 * B * (double)(H + 2) * (H + 2);
+    std::vector<V> vs;
+    vs.push_back({"fwd product", f_fwd, [&] { launch_conv<0, 0>(in, w, bias, nullptr, out, B, H, H); }});
+    vs.push_back({"fwd no staging", f_fwd, [&] { launch_conv<0, 1>(in, w, bias, nullptr, out, B, H, H); }});
+    vs.push_back({"fwd 1/16 mfma", f_fwd, [&] { launch_conv<0, 2>(in, w, bias, nullptr, out, B, H, H); }});
+    vs.push_back({"fwd no store", f_fwd, [&] { launch_conv<0, 3>(in, w, bias, nullptr, out, B, H, H); }});
+    vs.push_back({"bwd-data product", f_bwd, [&] { launch_conv<1, 0>(in, w, nullptr, mask, out, B, H, H); }});
+    vs.push_back({"bwd-data no staging", f_bwd, [&] { launch_conv<1, 1>(in, w, nullptr, mask, out, B, H, H); }});
+    vs.push_back({"bwd-data 1/16 mfma", f_bwd, [&] { launch_conv<1, 2>(in, w, nullptr, mask, out, B, H, H); }});
+    vs.push_back({"wgrad product", f_fwd, [&] { augcl_enc_conv32_backward_weights(in, out, dw, db, ws, wsb, B, H, H, 0); }});
+    auto wg = [&](auto kern) {
+        WgradArgs a{}; a.act = in; a.dz = out; a.partial = ws; a.B = B; a.Hi = H; a.Wi = H; a.Ho = H - 2; a.Wo = H - 2;
+        int rt = (kBufLds / 4 - 64 * H - 64) / (32 * H + 32 * a.Wo); rt = std::min(rt, std::min(512 / H - 2, 256 / a.Wo)); if (rt > a.Ho) rt = a.Ho;
+        a.S = (a.Ho + rt - 1) / rt; a.RT = (a.Ho + a.S - 1) / a.S; a.n_items = B * a.S;
+        const int planeA = ((a.RT + 2) * H) | 1, planeZ = (a.RT * a.Wo) | 1; size_t lds = 2 * (size_t)(32 * planeA + 32 * planeZ) * 4;
+        set_lds(kern, lds, "x"); hipLaunchKernelGGL(kern, dim3(grid_for(a.n_items, 1)), dim3(256), lds, 0, a);
+    };
+    vs.push_back({"wgrad kernel only", f_fwd, [&] { wg(k_wgrad32<0>); }});
+    vs.push_back({"wgrad no staging", f_fwd, [&] { wg(k_wgrad32<1>); }});
+    vs.push_back({"wgrad 1/9 mfma", f_fwd, [&] { wg(k_wgrad32<2>); }});
+    vs.push_back({"mfma f32 peak (regs only)", 2.0 * 32 * 32 * 2 * 16 * 4000.0 * 4 * 256, [&] { hipLaunchKernelGGL(k_mfma_peak, dim3(256), dim3(256), 0, 0, out, 4000, 0.5f); }});
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    printf("B=%d H=%d\n%-26s %9s %9s\n", B, H, "variant", "med us", "TFLOP/s");
+    std::vector<std::vector<double>> us(vs.size());
+    for (int r = 0; r < 5; ++r) for (size_t v = 0; v < vs.size(); ++v) {
+        for (int i = 0; i < 3; ++i) vs[v].run();
+        CK(hipEventRecord(e0, 0)); for (int i = 0; i < 20; ++i) vs[v].run(); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipGetLastError());
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); us[v].push_back(ms * 1000.0 / 20);
+    }
+    for (size_t v = 0; v < vs.size(); ++v) { std::sort(us[v].begin(), us[v].end()); const double m = us[v][2]; printf("%-26s %9.1f %9.1f\n", vs[v].name.c_str(), m, vs[v].flop / m / 1e6); }
+    return 0;
+}
