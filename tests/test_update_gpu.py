@@ -176,3 +176,44 @@ def test_agent_surface_and_actions(cuda):
     assert all(np.isfinite(v) for v in L.rows.values())
     assert {k for _, k in L.rows} >= {"train_critic/loss", "train_critic/shift_loss", "train_critic/aug_loss",
                                       "train_actor/loss", "train_alpha/value"}
+
+
+def test_agent_pickle_roundtrip_and_state_dict_names(cuda, tmp_path):
+    """train.py:229 saves the whole agent with torch.save; eval.py reloads it.  Flat-buffer views must survive."""
+    args = au.dotdict(algorithm="svea", data_aug="conv", aug_params=None, **so.DEFAULTS)
+    agent = make_agent(T.OBS, (6,), args)
+    want_keys = list(so.critic_shapes(T.OBS, 6, so.DEFAULTS).keys())
+    assert list(agent.critic.state_dict().keys()) == want_keys  # the reference's state-dict names, in order
+    assert list(agent.actor.state_dict().keys()) == list(so.actor_shapes(T.OBS, 6, so.DEFAULTS).keys())
+    path = tmp_path / "agent.pt"
+    torch.save(agent, path)
+    loaded = torch.load(path, weights_only=False)  # our own file
+    obs = np.random.RandomState(1).randint(0, 256, (9, 84, 84)).astype(np.uint8)
+    assert np.array_equal(agent.select_action(obs), loaded.select_action(obs))
+    # the reloaded agent still trains through the flat groups
+    B = 8
+    g = torch.Generator(device=cuda).manual_seed(1)
+    batch = (torch.randint(0, 256, (B, 9, 84, 84), device=cuda, generator=g).float(), torch.rand(B, 6, device=cuda) * 2 - 1,
+             torch.rand(B, 1, device=cuda), torch.randint(0, 256, (B, 9, 84, 84), device=cuda, generator=g).float(),
+             torch.ones(B, 1, device=cuda))
+    before = loaded.critic.Q1.trunk[0].weight.detach().clone()
+    loaded.update(FakeBuffer(batch), None, 0)
+    assert not torch.equal(before, loaded.critic.Q1.trunk[0].weight)
+    assert loaded.critic.Q1.trunk[0].weight.data_ptr() >= loaded.critic_group.param.data_ptr()
+
+
+def test_full_batch_update_runs_all_algorithms(cuda):
+    """BASELINE configs' batch sizes through the default (RNG-internal, fused) paths: finite losses, nets move."""
+    for algo, data_aug, A, B in (("svea", "conv", 6, 256), ("drq", "identity", 2, 512), ("non_naive_rad", "shift", 1, 128)):
+        args = au.dotdict(algorithm=algo, data_aug=data_aug, aug_params=None, **so.DEFAULTS)
+        agent = make_agent(T.OBS, (A,), args)
+        g = torch.Generator(device=cuda).manual_seed(2)
+        batch = (torch.randint(0, 256, (B, 9, 84, 84), device=cuda, generator=g).float(), torch.rand(B, A, device=cuda) * 2 - 1,
+                 torch.rand(B, 1, device=cuda), torch.randint(0, 256, (B, 9, 84, 84), device=cuda, generator=g).float(),
+                 torch.ones(B, 1, device=cuda))
+        L = RecLogger()
+        before = agent.critic_group.param.clone()
+        for step in (0, 1):
+            agent.update(FakeBuffer(batch), L, step)
+        assert all(np.isfinite(v) for v in L.rows.values()), (algo, L.rows)
+        assert not torch.equal(before, agent.critic_group.param)
