@@ -1,0 +1,55 @@
+// replay_kernels.hip -- device-resident replay sampling.
+//
+// The reference keeps observations as Python lists of LazyFrames and, per sample(), walks B indices on the host,
+// np.concatenate()s 2*B frame stacks and pushes 2 x B x 63.5 KB through PCIe (src/utils.py:206-214, 234-240,
+// 283-322).  Here every RGB frame lives ONCE in a uint8 ring in HBM and a batch is materialised by a gather:
+// out[b, 3k:3k+3] = frames[idx[b][k]].  One dword (4 pixels) per thread, float4 / dword stores: pure HBM copy
+// work -- (1 + 4) bytes per pixel for the f32 batch the agents consume, 2 for a uint8 batch.
+#include "augcl_common.h"
+
+namespace augcl {
+
+template <typename TOut>
+__global__ __launch_bounds__(256) void k_replay_gather(const uint8_t *__restrict__ frames,
+                                                       const int32_t *__restrict__ slots /* [B][stack] */,
+                                                       TOut *__restrict__ out /* [B][stack*fq*4] */, int stack,
+                                                       int fq /* dwords per RGB frame */, size_t total)
+{
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (size_t)gridDim.x * 256) {
+        const size_t fi = q / fq; // = b*stack + k
+        const int off = (int)(q - fi * fq);
+        const int slot = slots[fi];
+        const uint32_t v = reinterpret_cast<const uint32_t *>(frames)[(size_t)slot * fq + off];
+        if constexpr (sizeof(TOut) == 1)
+            reinterpret_cast<uint32_t *>(out)[q] = v;
+        else
+            reinterpret_cast<float4 *>(out)[q] =
+                make_float4((float)(v & 0xffu), (float)((v >> 8) & 0xffu), (float)((v >> 16) & 0xffu), (float)(v >> 24));
+    }
+}
+
+} // namespace augcl
+
+using namespace augcl;
+
+extern "C" int augcl_replay_gather(const uint8_t *frames, const int32_t *slots, void *out, int B, int stack,
+                                   int frame_bytes, int out_f32, augcl_stream_t stream)
+{
+    const char *name = "augcl_replay_gather";
+    AUGCL_REQUIRE(B >= 0 && stack > 0 && frame_bytes > 0 && (frame_bytes & 3) == 0, "%s: bad shape", name);
+    if (B == 0) return AUGCL_OK;
+    AUGCL_REQUIRE(frames && slots && out, "%s: null buffer", name);
+    AUGCL_REQUIRE(aligned16(frames) && aligned16(out), "%s: buffers must be 16-byte aligned", name);
+    const int fq = frame_bytes / 4;
+    const size_t total = (size_t)B * stack * fq;
+    const size_t blocks = (total + 255) / 256;
+    const unsigned grid = (unsigned)(blocks < 16384 ? blocks : 16384);
+    hipStream_t s = as_stream(stream);
+    if (out_f32)
+        hipLaunchKernelGGL(k_replay_gather<float>, dim3(grid), dim3(256), 0, s, frames, slots, (float *)out, stack, fq,
+                           total);
+    else
+        hipLaunchKernelGGL(k_replay_gather<uint8_t>, dim3(grid), dim3(256), 0, s, frames, slots, (uint8_t *)out, stack,
+                           fq, total);
+    return augcl::check_launch(name);
+}

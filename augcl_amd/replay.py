@@ -1,0 +1,176 @@
+"""Device-resident replay buffer: drop-in for the sampling side of
+`utils.ReplayBuffer` (src/utils.py:136-280) and `LazyFrames` (src/utils.py:283-322).
+
+Same constructor / `add` / `sample` surface and the SAME index stream (`np.random.randint(0, capacity if full
+else idx, size=n)` on numpy's global generator, src/utils.py:229-232), so a run seeded like the reference samples
+the same transitions.  Different storage: every RGB frame is kept ONCE in a uint8 ring in HBM (frame stacks of
+consecutive steps share frames exactly like the reference's LazyFrames share numpy arrays); `add` uploads only
+frames it has not seen (normally one 21 KB frame per environment step) and `sample` is one gather launch per
+tensor that writes the stacked (B, 3*stack, H, W) batch -- float32 like `tensor_buffer_samples`' `.float()`, or
+uint8 for the fused uint8 front end (`augmentations.shift_conv`) -- straight into HBM.  No per-sample host loop,
+no 2 x B x 63.5 KB PCIe transfer per update.
+
+save/load of the reference's pickled "{start}_{end}.tar" chunks (src/utils.py:156-204) is host bookkeeping
+outside the accelerated path; `state_dict()/load_state_dict()` carry the ring instead.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+
+
+class LazyFrames(object):
+    """Frame stack that shares its frames with its neighbours (src/utils.py:283-322)."""
+
+    def __init__(self, frames, extremely_lazy=True):
+        self._frames = list(frames)
+
+    @property
+    def frames(self):
+        return self._frames
+
+    def __array__(self, dtype=None, copy=None):
+        out = np.concatenate(self._frames, axis=0)
+        return out.astype(dtype) if dtype is not None else out
+
+    def __len__(self):
+        return len(self._frames)
+
+    def __getitem__(self, i):
+        return np.concatenate(self._frames, axis=0)[i]
+
+
+class ReplayBuffer(object):
+    def __init__(self, obs_shape, action_shape, capacity, batch_size, prefill=True, device=None, frame_slack=None,
+                 sample_dtype=torch.float32):
+        c, h, w = obs_shape
+        assert c % 3 == 0, "observations are stacks of RGB frames"
+        if device is None:
+            if not torch.cuda.is_available():
+                raise _lib.AugclError("augcl_amd.replay.ReplayBuffer keeps its frames in HBM: a GPU is required")
+            device = torch.device("cuda", torch.cuda.current_device())
+        self.device = torch.device(device)
+        self.capacity, self.batch_size = int(capacity), int(batch_size)
+        self.stack, self.h, self.w = c // 3, h, w
+        self.frame_bytes = 3 * h * w
+        assert self.frame_bytes % 16 == 0, "frame size must keep the ring 16-byte aligned"
+        # one new frame per step plus a fresh stack per episode: capacity + slack slots keep every frame referenced
+        # by a live transition resident (checked at sample time)
+        self.n_slots = self.capacity + (frame_slack if frame_slack is not None else self.capacity // 50 + 4 * self.stack + 16)
+        self.frames = torch.empty((self.n_slots, self.frame_bytes), dtype=torch.uint8, device=self.device)
+        self.frame_seq = 0  # frames ever stored; slot = seq % n_slots
+        self._ids = {}      # id(frame ndarray) -> (seq, weakref-free strong ref to keep the id unique)
+        self._ids_order = []
+        self.obs_seq = np.zeros((self.capacity, self.stack), dtype=np.int64)
+        self.next_seq = np.zeros((self.capacity, self.stack), dtype=np.int64)
+        self.actions = torch.empty((self.capacity, *action_shape), dtype=torch.float32, device=self.device)
+        self.rewards = torch.empty((self.capacity, 1), dtype=torch.float32, device=self.device)
+        self.not_dones = torch.empty((self.capacity, 1), dtype=torch.float32, device=self.device)
+        self._scal = torch.empty((1, int(np.prod(action_shape)) + 2), dtype=torch.float32).pin_memory() \
+            if self.device.type == "cuda" else torch.empty((1, int(np.prod(action_shape)) + 2))
+        self.sample_dtype = sample_dtype
+        self.idx = 0
+        self.full = False
+
+    # ---- storing --------------------------------------------------------------------------------
+    def _frames_of(self, obs):
+        if hasattr(obs, "frames"):
+            fr = [np.asarray(f) for f in obs.frames]
+        else:
+            a = np.asarray(obs)
+            fr = [a[3 * k:3 * k + 3] for k in range(self.stack)]  # views: identity is lost, content is compared
+        assert len(fr) == self.stack and all(f.shape == (3, self.h, self.w) for f in fr), "unexpected observation shape"
+        return fr
+
+    def _store_frame(self, f, allow_content_match):
+        key = id(f)
+        hit = self._ids.get(key)
+        if hit is not None and hit[1] is f:
+            return hit[0]
+        if allow_content_match:  # ndarray observations: the previous step's frames are the only candidates
+            for k2 in self._ids_order[-2 * self.stack:]:
+                seq, ref = self._ids[k2]
+                if ref.shape == f.shape and np.array_equal(ref, f):
+                    return seq
+        seq = self.frame_seq
+        self.frame_seq += 1
+        src = torch.from_numpy(np.ascontiguousarray(f, dtype=np.uint8).reshape(-1))
+        self.frames[seq % self.n_slots].copy_(src, non_blocking=False)
+        keep = f if not allow_content_match else np.array(f, copy=True)
+        self._ids[id(keep) if allow_content_match else key] = (seq, keep)
+        self._ids_order.append(id(keep) if allow_content_match else key)
+        if len(self._ids_order) > 8 * self.stack:  # only recent frames can recur
+            old = self._ids_order.pop(0)
+            self._ids.pop(old, None)
+        return seq
+
+    def add(self, obs, action, reward, next_obs, done):
+        """src/utils.py:216-227"""
+        by_content = not hasattr(obs, "frames")
+        self.obs_seq[self.idx] = [self._store_frame(f, by_content) for f in self._frames_of(obs)]
+        self.next_seq[self.idx] = [self._store_frame(f, by_content) for f in self._frames_of(next_obs)]
+        a = np.asarray(action, dtype=np.float32).reshape(-1)
+        self._scal[0, :a.size] = torch.from_numpy(a)
+        self._scal[0, a.size] = float(reward)
+        self._scal[0, a.size + 1] = float(not done)
+        row = self._scal.to(self.device, non_blocking=False)
+        self.actions[self.idx] = row[0, :a.size].view(self.actions.shape[1:])
+        self.rewards[self.idx] = row[0, a.size]
+        self.not_dones[self.idx] = row[0, a.size + 1]
+        self.idx = (self.idx + 1) % self.capacity
+        self.full = self.full or self.idx == 0
+
+    # ---- sampling -------------------------------------------------------------------------------
+    def _get_idxs(self, n=None):
+        """src/utils.py:229-232 (numpy's GLOBAL generator, like the reference)"""
+        if n is None:
+            n = self.batch_size
+        return np.random.randint(0, self.capacity if self.full else self.idx, size=n)
+
+    def _gather(self, seqs, dtype):
+        live = self.frame_seq - self.n_slots
+        if seqs.min() < live:
+            raise _lib.AugclError("replay frame ring too small: a sampled transition's frame was overwritten "
+                                  f"(slots={self.n_slots}); raise frame_slack")
+        B = seqs.shape[0]
+        slots = torch.from_numpy((seqs % self.n_slots).astype(np.int32)).to(self.device)
+        out = torch.empty((B, 3 * self.stack, self.h, self.w), dtype=dtype, device=self.device)
+        _lib.call("augcl_replay_gather", self.frames.data_ptr(), slots.data_ptr(), out.data_ptr(), B, self.stack,
+                  self.frame_bytes, 1 if dtype == torch.float32 else 0, _lib.current_stream(self.device))
+        return out
+
+    def sample(self, n=None, idxs=None, dtype=None):
+        """src/utils.py:272-280: returns (obs, actions, rewards, next_obs, not_dones) on the device."""
+        if idxs is None:
+            idxs = self._get_idxs(n)
+        idxs = np.asarray(idxs)
+        dtype = dtype or self.sample_dtype
+        obs = self._gather(self.obs_seq[idxs], dtype)
+        next_obs = self._gather(self.next_seq[idxs], dtype)
+        it = torch.from_numpy(idxs.astype(np.int64)).to(self.device)
+        return obs, self.actions[it], self.rewards[it], next_obs, self.not_dones[it]
+
+    def sample_obs(self, n=None):
+        return self._gather(self.obs_seq[self._get_idxs(n)], torch.float32)
+
+    def sample_drq(self, n=None, pad=4):
+        """src/utils.py:258-270"""
+        from . import augmentations
+        obs, actions, rewards, next_obs, not_dones = self.sample(n)
+        return augmentations.random_shift(obs, pad), actions, rewards, augmentations.random_shift(next_obs, pad), not_dones
+
+    # ---- persistence ----------------------------------------------------------------------------
+    def state_dict(self):
+        return dict(frames=self.frames.cpu(), frame_seq=self.frame_seq, obs_seq=self.obs_seq.copy(),
+                    next_seq=self.next_seq.copy(), actions=self.actions.cpu(), rewards=self.rewards.cpu(),
+                    not_dones=self.not_dones.cpu(), idx=self.idx, full=self.full)
+
+    def load_state_dict(self, sd):
+        self.frames.copy_(sd["frames"])
+        self.frame_seq, self.idx, self.full = int(sd["frame_seq"]), int(sd["idx"]), bool(sd["full"])
+        self.obs_seq[:], self.next_seq[:] = sd["obs_seq"], sd["next_seq"]
+        self.actions.copy_(sd["actions"])
+        self.rewards.copy_(sd["rewards"])
+        self.not_dones.copy_(sd["not_dones"])
+        self._ids.clear()
+        self._ids_order.clear()

@@ -198,6 +198,18 @@ def main():
         order_p = _lib.ctypes.cast(order, _lib.ctypes.c_void_p)
         rate("color_jitter_f32", lambda i: call("augcl_color_jitter_f32", p(outs[i % R]), B, 3, 84, 84, None, 0, order_p,
                                                 1.2, 0.8, 0.1, 1.0, 255.0, stream))
+        # device-resident replay sampling: gather obs + next_obs (f32) of B transitions from a
+        # 20k-frame uint8 ring; algorithmic bytes per sampled transition = 2 x 63504 x (1 + 4)
+        from augcl_amd.replay import ReplayBuffer
+        import numpy as np
+        rb = ReplayBuffer((9, 84, 84), (6,), capacity=20000, batch_size=B, device=dev)
+        rb.frames.random_(0, 256, generator=g)
+        rb.frame_seq = rb.n_slots
+        rb.obs_seq[:] = (np.arange(20000)[:, None] + np.arange(3)[None, :]) % rb.n_slots
+        rb.next_seq[:] = (rb.obs_seq + 1) % rb.n_slots
+        rb.idx, rb.full = 0, True
+        BYTES_PER_OBS["replay_sample_f32"] = 2 * OBS_ELEMS * 5
+        rate("replay_sample_f32", lambda i: rb.sample())
         res["extras"] = extras
         try:
             from augcl_amd import bench_update

@@ -150,6 +150,13 @@ int augcl_enc_conv_first_backward_weights(const float *x /* (B,C,Hi,Wi) raw */, 
                                           float *db, float *workspace, size_t workspace_bytes, int B, int C, int Hi,
                                           int Wi, int stride, float scale, augcl_stream_t stream);
 
+/* ---- device-resident replay sampling: ReplayBuffer.sample -> tensor_buffer_samples / _encode_obses /
+ * LazyFrames._force (src/utils.py:206-214, 234-240, 272-280, 293-299).  `frames` is a uint8 ring of RGB frames
+ * (frame_bytes = 3*H*W each) in HBM; slots[b*stack + k] names the k-th frame of sample b's stack.
+ * out[b, 3k:3k+3, :, :] = frames[slot]; out is uint8 (out_f32 = 0) or float32 (the `.float()` of utils.py:208). */
+int augcl_replay_gather(const uint8_t *frames, const int32_t *slots, void *out, int B, int stack, int frame_bytes,
+                        int out_f32, augcl_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -59,3 +59,23 @@ def smooth_obs_u8(seed, B, C=C, H=H, W=W):
     out[:, 1::3, 6:12, :6] = 0
     out[:, 2::3, 6:12, :6] = 0
     return out
+
+
+def replay_stream(seed, n, A, ep_len=7, stack=3, H=H, W=W):
+    """Yield n transitions (obs_frames, action, reward, next_frames, done) of an episodic stream with the frame
+    sharing of src/env/wrappers.py:177-206 (FrameStack): a reset replicates the first frame `stack` times, every
+    step appends ONE new (3,H,W) uint8 frame; consecutive stacks share their frame arrays (identity)."""
+    rs = np.random.RandomState(seed)
+    new = lambda: rs.randint(0, 256, size=(3, H, W)).astype(np.uint8)  # noqa: E731
+    t = 0
+    frames = None
+    for _ in range(n):
+        if frames is None:
+            f0 = new()
+            frames = [f0] * stack
+            t = 0
+        nxt = frames[1:] + [new()]
+        t += 1
+        done = t >= ep_len
+        yield list(frames), rs.uniform(-1, 1, size=A).astype(np.float32), float(rs.uniform(0, 4)), list(nxt), done
+        frames = None if done else nxt

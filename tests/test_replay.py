@@ -1,0 +1,110 @@
+"""Replay sampling: CPU -- the numpy oracle against golden vectors from the reference's own
+ReplayBuffer; GPU -- the device-resident ring + gather kernel against both, bit for bit."""
+import os
+
+import numpy as np
+import pytest
+
+import inputs as gi
+from oracle.replay_oracle import ReplayOracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+A, CAP, B = 2, 32, 3
+
+
+@pytest.fixture(scope="module")
+def G():
+    return np.load(os.path.join(ROOT, "tests", "golden", "replay_golden.npz"))
+
+
+def test_oracle_matches_reference_buffer(G):
+    orc = ReplayOracle((A,), CAP)
+    for t in gi.replay_stream(seed=21, n=45, A=A):
+        orc.add(*t)
+    assert orc.idx == int(G["idx_after"][0]) and orc.full == bool(G["full"][0])
+    for k, s in enumerate((5, 6)):
+        np.random.seed(s)
+        idxs = orc.draw(B)
+        assert np.array_equal(idxs, G[f"s{k}/idxs"])
+        obs, act, rew, nobs, nd = orc.sample(idxs)
+        assert np.array_equal(obs, G[f"s{k}/obs"].astype(np.float32))
+        assert np.array_equal(nobs, G[f"s{k}/next_obs"].astype(np.float32))
+        assert np.array_equal(act, G[f"s{k}/action"]) and np.array_equal(rew, G[f"s{k}/reward"])
+        assert np.array_equal(nd, G[f"s{k}/not_done"])
+
+
+@pytest.mark.gpu
+def test_device_ring_matches_reference_golden(cuda, G):
+    import torch
+
+    from augcl_amd.replay import LazyFrames, ReplayBuffer
+    buf = ReplayBuffer((9, 84, 84), (A,), capacity=CAP, batch_size=B)
+    for of, a, r, nf, d in gi.replay_stream(seed=21, n=45, A=A):
+        buf.add(LazyFrames(of), a, r, LazyFrames(nf), d)
+    assert buf.idx == int(G["idx_after"][0]) and buf.full == bool(G["full"][0])
+    assert buf.frame_seq == 45 + 7  # one new frame per step + one per episode start: frames are stored once
+    for k, s in enumerate((5, 6)):
+        np.random.seed(s)
+        obs, act, rew, nobs, nd = buf.sample()
+        assert obs.dtype == torch.float32 and obs.is_cuda
+        assert np.array_equal(obs.cpu().numpy(), G[f"s{k}/obs"].astype(np.float32))
+        assert np.array_equal(nobs.cpu().numpy(), G[f"s{k}/next_obs"].astype(np.float32))
+        assert np.array_equal(act.cpu().numpy(), G[f"s{k}/action"])
+        assert np.array_equal(rew.cpu().numpy(), G[f"s{k}/reward"])
+        assert np.array_equal(nd.cpu().numpy(), G[f"s{k}/not_done"])
+        u8 = buf.sample(idxs=G[f"s{k}/idxs"], dtype=torch.uint8)[0]
+        assert u8.dtype == torch.uint8 and np.array_equal(u8.cpu().numpy(), G[f"s{k}/obs"])
+
+
+@pytest.mark.gpu
+def test_device_ring_vs_oracle_long_stream_and_ndarray_obs(cuda):
+    import torch
+
+    from augcl_amd.replay import ReplayBuffer
+    cap = 64
+    buf = ReplayBuffer((9, 84, 84), (A,), capacity=cap, batch_size=16)
+    orc = ReplayOracle((A,), cap)
+    for of, a, r, nf, d in gi.replay_stream(seed=3, n=200, A=A, ep_len=11):
+        buf.add(np.concatenate(of, axis=0), a, r, np.concatenate(nf, axis=0), d)  # plain (9,84,84) arrays
+        orc.add(of, a, r, nf, d)
+    assert buf.frame_seq <= 200 + 200 // 11 + 2  # content match de-duplicates consecutive stacks
+    for s in range(3):
+        np.random.seed(100 + s)
+        idxs = orc.draw(16)
+        np.random.seed(100 + s)
+        obs, act, rew, nobs, nd = buf.sample()
+        o2, a2, r2, n2, d2 = orc.sample(idxs)
+        assert np.array_equal(obs.cpu().numpy(), o2) and np.array_equal(nobs.cpu().numpy(), n2)
+        assert np.array_equal(act.cpu().numpy(), a2) and np.array_equal(rew.cpu().numpy(), r2)
+        assert np.array_equal(nd.cpu().numpy(), d2)
+    sd = buf.state_dict()
+    buf2 = ReplayBuffer((9, 84, 84), (A,), capacity=cap, batch_size=16)
+    buf2.load_state_dict(sd)
+    np.random.seed(7)
+    x1 = buf.sample()[0]
+    np.random.seed(7)
+    assert torch.equal(x1, buf2.sample()[0])
+
+
+@pytest.mark.gpu
+def test_ring_overwrite_is_detected_and_agent_consumes_samples(cuda):
+    import torch
+
+    from augcl_amd import _lib
+    from augcl_amd import utils as au
+    from augcl_amd.algorithms import make_agent
+    from augcl_amd.replay import LazyFrames, ReplayBuffer
+    from oracle import sac_oracle as so
+    small = ReplayBuffer((9, 84, 84), (A,), capacity=16, batch_size=4, frame_slack=-8)  # deliberately too small
+    for of, a, r, nf, d in gi.replay_stream(seed=4, n=16, A=A):
+        small.add(LazyFrames(of), a, r, LazyFrames(nf), d)
+    with pytest.raises(_lib.AugclError):
+        small.sample(idxs=np.array([0, 1, 2, 3]))
+    buf = ReplayBuffer((9, 84, 84), (A,), capacity=64, batch_size=8)
+    for of, a, r, nf, d in gi.replay_stream(seed=5, n=40, A=A):
+        buf.add(LazyFrames(of), a, r, LazyFrames(nf), d)
+    agent = make_agent((9, 84, 84), (A,), au.dotdict(algorithm="drq", data_aug="identity", aug_params=None, **so.DEFAULTS))
+    before = agent.critic_group.param.clone()
+    np.random.seed(0)
+    agent.update(buf, None, 0)
+    assert not torch.equal(before, agent.critic_group.param)
