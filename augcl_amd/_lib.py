@@ -66,6 +66,12 @@ _SIGS = {
     "augcl_shift_conv_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _U64, _U64, _I, _P],
     "augcl_adam_f32": [_P, _P, _P, _P, _SZ, _D, _D, _D, _D, _c.c_int64, _D, _P],
     "augcl_ema_f32": [_P, _P, _SZ, _D, _P],
+    "augcl_enc_bf16_conv_first_forward": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
+    "augcl_enc_bf16_conv32_forward": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "augcl_enc_bf16_conv32_backward_data": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "augcl_enc_bf16_conv32_backward_weights": [_P, _P, _P, _P, _P, _SZ, _I, _I, _I, _P],
+    "augcl_enc_bf16_conv_first_backward_weights": [_P, _P, _P, _P, _P, _SZ, _I, _I, _I, _I, _I, _F, _P],
+    "augcl_enc_nchw_f32_to_nhwc_bf16": [_P, _P, _I, _I, _I, _P],
     "augcl_replay_gather": [_P, _P, _P, _I, _I, _I, _I, _P],
     "augcl_enc_conv_first_forward": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
     "augcl_enc_conv32_forward": [_P, _P, _P, _P, _I, _I, _I, _I, _P],

@@ -32,7 +32,8 @@ class _NullLogger:
         pass
 
 
-def run(dev, dist, world, rank, steps=20, warmup=4, B=256, A=6, algo="svea", data_aug="conv", backend=None):
+def run(dev, dist, world, rank, steps=20, warmup=4, B=256, A=6, algo="svea", data_aug="conv", backend=None,
+        precision="f32"):
     from . import dist as apdist
     from . import encoder_ops
     from . import utils as au
@@ -40,6 +41,7 @@ def run(dev, dist, world, rank, steps=20, warmup=4, B=256, A=6, algo="svea", dat
 
     if backend:
         encoder_ops.set_backend(backend)
+    encoder_ops.set_precision(precision)
     hp = dict(discount=0.99, critic_tau=0.01, encoder_tau=0.05, actor_update_freq=2, critic_target_update_freq=2,
               num_shared_layers=11, num_head_layers=0, num_filters=32, projection_dim=100, hidden_dim=1024,
               actor_log_std_min=-10.0, actor_log_std_max=2.0, init_temperature=0.1, actor_lr=1e-3, actor_beta=0.9,
@@ -69,7 +71,9 @@ def run(dev, dist, world, rank, steps=20, warmup=4, B=256, A=6, algo="svea", dat
         t = torch.tensor([wall], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
+    encoder_ops.set_precision("f32")
     flops = 432e9 * (B / 256)  # ~1.69 GFLOP per sample per (average) step
     return {"grad_steps_per_s": steps / wall, "ms_per_update": wall / steps * 1e3, "samples_per_s": world * B * steps / wall,
-            "algo": f"{algo}+{data_aug}", "batch_per_gpu": B, "steps": steps, "dtype": "f32",
+            "algo": f"{algo}+{data_aug}", "batch_per_gpu": B, "steps": steps,
+            "dtype": "f32" if precision == "f32" else "bf16 conv stack (f32 accumulate, f32 heads/optimizer)",
             "approx_TFLOP/s_per_gpu": flops * steps / wall / 1e12, "encoder_backend": encoder_ops.BACKEND}

@@ -1,0 +1,303 @@
+// encoder_bf16.hip -- bf16 PERFORMANCE MODE of the shared conv encoder (BASELINE config 2 "bf16").
+//
+// Same algorithm as encoder_kernels.hip (f32, the parity path), different arithmetic and layout:
+//   * activations live in HBM as bf16 NHWC (one pixel = its 32 channels = 64 contiguous bytes),
+//   * products run on v_mfma_f32_32x32x16_bf16 (16x the f32 MFMA rate), accumulation stays f32,
+//   * weights / biases stay f32 masters and are rounded to bf16 (RNE) into registers per launch.
+// With 18 MFMAs (576 cycles) per 32-pixel x 32-channel tile the layers become HBM-bound, so the kernel is
+// organised around the data movement: 4 LOADER waves stream the next strip's pixels (16-byte chunks,
+// 10 in flight per lane) into the other half of a double-buffered, XOR-swizzled LDS tile while 4 COMPUTE
+// waves read their MFMA B-fragments with one conflict-free ds_read_b128 each (8 channels of one pixel).
+// NOT the parity path: results differ from the f32 reference at bf16 resolution (~3e-3 relative).
+#include "augcl_common.h"
+
+#include <algorithm>
+
+namespace augcl {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int acc_row_b(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+struct ConvBfArgs {
+    const uint4 *in;      // bf16 NHWC (B,Hi,Wi,32) as 16-byte chunks (4 per pixel)
+    const float *w;       // (32,32,3,3) f32 master weights
+    const float *bias;    // (32) or null              [MODE 0]
+    const uint4 *mask;    // a_prev bf16 NHWC (B,Ho,Wo,32) or null [MODE 1]
+    void *out;            // bf16 NHWC (B,Ho,Wo,32), or f32 NCHW (B,32,Ho,Wo) when out_f32
+    int B, Hi, Wi, Ho, Wo, RT, S, relu, n_items, out_f32;
+};
+
+// LDS chunk address of (pixel p, logical chunk c): chunks of 4 neighbouring pixels are rotated against each
+// other so the 16 lanes of a ds_read_b128 group (consecutive pixels, one logical chunk) hit 16 distinct slots
+__device__ __forceinline__ int swz(int p, int c) { return p * 4 + (c ^ ((p >> 2) & 3)); }
+
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void k_conv32_bf16(ConvBfArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint4 lds4[]; // 2 x [G + (RT+2)*Wi + G pixels][4 chunks] (+ gate words)
+    constexpr int P = MODE ? 2 : 0;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = wave >= 4;
+    const int cw = wave & 3;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int Wi = a.Wi;
+    const int G = MODE ? ((2 * Wi + 2 + 3) & ~3) : 0;    // guard pixels (multiple of 4 keeps the swizzle phase)
+    const int tilepix = 2 * G + (a.RT + 2) * Wi;
+    const int gatew = MODE ? ((a.RT * a.Wo + 3) & ~3) : 0; // ReLU gate words (one uint32 per strip pixel)
+    const int bufchunks = tilepix * 4 + gatew / 4;
+    float *lbias = reinterpret_cast<float *>(lds4 + 2 * bufchunks);
+
+    // ---- weights: A fragment of (tap t, channel half s): W_eff[row l31][k = 16s + 8h + j][t], j = 0..7
+    bf16x8 wfrag[18];
+    if (!loader) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = 16 * s + 8 * h + j;
+                    const float wv = MODE == 0 ? a.w[((size_t)l31 * 32 + k) * 9 + t]        // W[co=l31][ci=k][t]
+                                               : a.w[((size_t)k * 32 + l31) * 9 + (8 - t)]; // W[co=k][ci=l31][8-t]
+                    wfrag[t * 2 + s][j] = (__bf16)wv;
+                }
+    }
+    if (tid < 32) lbias[tid] = (MODE == 0 && a.bias) ? a.bias[tid] : 0.0f;
+
+    auto stage = [&](int item, int bi) {
+        const int b = item / a.S, s = item - b * a.S;
+        const int y0 = s * a.RT;
+        const int rows = min(a.RT, a.Ho - y0);
+        const int r0 = MODE ? max(0, y0 - P) : y0;
+        const int r1 = MODE ? min(a.Hi, y0 + rows) : y0 + rows + 2;
+        const int nchunk = (r1 - r0) * Wi * 4;
+        const uint4 *src = a.in + ((size_t)(b * a.Hi + r0) * Wi) * 4;
+        uint4 *dst = lds4 + bi * bufchunks;
+        const int lt = cw * 64 + lane; // 0..255 among the loader threads
+        for (int c0 = 0; c0 < nchunk; c0 += 256 * 10) {
+            uint4 v[10];
+#pragma unroll
+            for (int u = 0; u < 10; ++u) v[u] = src[min(c0 + u * 256 + lt, nchunk - 1)]; // branch-free (idempotent tail)
+#pragma unroll
+            for (int u = 0; u < 10; ++u) {
+                const int q = min(c0 + u * 256 + lt, nchunk - 1);
+                dst[swz(G + (q >> 2), q & 3)] = v[u];
+            }
+        }
+        if (MODE == 1 && a.mask != nullptr) { // ReLU gate bits of the layer below: word[m] bit co = a_prev[m][co] != 0
+            uint32_t *gw = reinterpret_cast<uint32_t *>(dst + tilepix * 4);
+            const int npix = rows * a.Wo;
+            const uint4 *mp = a.mask + ((size_t)(b * a.Ho + y0) * a.Wo) * 4;
+            for (int m = lt; m < npix; m += 256) {
+                uint32_t wbits = 0;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const uint4 v = mp[(size_t)m * 4 + c];
+                    const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { // two bf16 per dword; post-ReLU values are >= 0: gate = (x != 0)
+                        wbits |= ((d[e] & 0x7fffu) != 0 ? 1u : 0u) << (8 * c + 2 * e);
+                        wbits |= ((d[e] & 0x7fff0000u) != 0 ? 1u : 0u) << (8 * c + 2 * e + 1);
+                    }
+                }
+                gw[m] = wbits;
+            }
+        }
+    };
+
+    int it = 0;
+    const int first = blockIdx.x;
+    if (loader && first < a.n_items) stage(first, 0);
+    __syncthreads();
+    for (int item = first; item < a.n_items; item += gridDim.x, ++it) {
+        const int next = item + gridDim.x;
+        if (loader) {
+            if (next < a.n_items) stage(next, (it + 1) & 1);
+        } else {
+            const int b = item / a.S, s = item - b * a.S;
+            const int y0 = s * a.RT;
+            const int rows = min(a.RT, a.Ho - y0);
+            const int npix = rows * a.Wo;
+            const int r0 = MODE ? max(0, y0 - P) : y0;
+            const uint4 *tile = lds4 + (it & 1) * bufchunks;
+            const uint32_t *gatebits = reinterpret_cast<const uint32_t *>(tile + tilepix * 4);
+            const int ntiles = (npix + 31) >> 5;
+            for (int tl = cw; tl < ntiles; tl += 4) {
+                int m = tl * 32 + l31;
+                const bool valid = m < npix;
+                if (!valid) m = npix - 1;
+                const int yy = m / a.Wo, xx = m - yy * a.Wo;
+                const int p0 = G + (y0 + yy - P - r0) * Wi + (xx - P); // top-left tap (in the guard for masked taps)
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = lbias[acc_row_b(r, h)];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int ky = t / 3, kx = t % 3;
+                    const int p = p0 + ky * Wi + kx;
+                    bool ok = true;
+                    if (MODE == 1)
+                        ok = ((unsigned)(y0 + yy + ky - P) < (unsigned)a.Hi) && ((unsigned)(xx + kx - P) < (unsigned)Wi);
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        uint4 raw = tile[swz(p, 2 * s2 + h)];
+                        if (MODE == 1 && !ok) raw = make_uint4(0u, 0u, 0u, 0u);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfrag[t * 2 + s2], __builtin_bit_cast(bf16x8, raw), acc,
+                                                                      0, 0, 0);
+                    }
+                }
+                if (valid) {
+                    const int y = y0 + yy;
+                    uint32_t gate = 0xffffffffu;
+                    if (MODE == 1 && a.mask) gate = gatebits[m];
+                    if (a.out_f32) { // last layer: f32 NCHW for the projection
+                        float *o = reinterpret_cast<float *>(a.out);
+                        const int chw = a.Ho * a.Wo;
+                        const int o0 = (b * 32 * a.Ho + y) * a.Wo + xx;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int co = acc_row_b(r, h);
+                            float v = acc[r];
+                            if (MODE == 0 && a.relu) v = fmaxf(v, 0.0f);
+                            if (MODE == 1) v = ((gate >> co) & 1u) ? v : 0.0f;
+                            o[o0 + co * chw] = v;
+                        }
+                    } else { // bf16 NHWC: 4 x (4 consecutive channels = 8 bytes) per lane
+                        bf16x4 *o = reinterpret_cast<bf16x4 *>(a.out) + ((size_t)(b * a.Ho + y) * a.Wo + xx) * 8;
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            bf16x4 pk;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                float v = acc[g4 * 4 + e];
+                                const int co = 8 * g4 + 4 * h + e;
+                                if (MODE == 0 && a.relu) v = fmaxf(v, 0.0f);
+                                if (MODE == 1) v = ((gate >> co) & 1u) ? v : 0.0f;
+                                pk[e] = (__bf16)v;
+                            }
+                            o[2 * g4 + h] = pk;
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// f32 NCHW (B,32,H,W) -> bf16 NHWC (B,H,W,32): the gradient entering the stack from the projection
+__global__ __launch_bounds__(256) void k_nchw_f32_to_nhwc_bf16(const float *__restrict__ in, __bf16 *__restrict__ out,
+                                                               int B, int HW)
+{
+    // one thread per (pixel, 8-channel chunk): reads are plane-strided but every 128-byte line is fully used by the
+    // 32 lanes that walk consecutive pixels of one channel
+    const size_t total = (size_t)B * HW * 4;
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (size_t)gridDim.x * 256) {
+        const int c = (int)(q / ((size_t)B * HW));        // chunk-major: consecutive threads = consecutive pixels
+        const size_t pix = q - (size_t)c * B * HW;        // b*HW + p
+        const size_t b = pix / HW, p = pix - b * HW;
+        bf16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (__bf16)in[(b * 32 + 8 * c + j) * HW + p];
+        reinterpret_cast<bf16x8 *>(out)[pix * 4 + c] = v;
+    }
+}
+
+} // namespace augcl
+
+using namespace augcl;
+
+namespace {
+constexpr int kBufBytes = 78 * 1024;
+
+int cu_count_bf()
+{
+    int dev = 0, v = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) v = n;
+    }
+    return v;
+}
+
+template <int MODE>
+int launch_conv_bf16(ConvBfArgs &a, const char *name, hipStream_t s)
+{
+    const int Wi = a.Wi;
+    const int G = MODE ? ((2 * Wi + 2 + 3) & ~3) : 0;
+    // bytes per output row: Wi pixels x 64 B (+ 4 B gate word per output pixel); 2 halo rows + 2 guards
+    const int per_row = Wi * 64 + (MODE ? a.Wo * 4 : 0);
+    int rt = (kBufBytes - 2 * G * 64 - 2 * Wi * 64 - 64) / per_row;
+    if (rt < 1) return augcl::fail(AUGCL_E_UNSUPPORTED, "%s: image row too wide for LDS (W=%d)", name, Wi);
+    if (rt > a.Ho) rt = a.Ho;
+    a.S = (a.Ho + rt - 1) / rt;
+    // keep every CU busy: at least 2 items per CU when the batch allows it
+    const int cus = cu_count_bf();
+    while ((long)a.B * a.S < 2L * cus && a.S < a.Ho) ++a.S;
+    a.RT = (a.Ho + a.S - 1) / a.S;
+    a.S = (a.Ho + a.RT - 1) / a.RT;
+    a.n_items = a.B * a.S;
+    const int tilepix = 2 * G + (a.RT + 2) * Wi;
+    const int gatew = MODE ? ((a.RT * a.Wo + 3) & ~3) : 0;
+    const size_t lds = (size_t)2 * (tilepix * 64 + gatew * 4) + 32 * 4;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv32_bf16<MODE>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return augcl::fail(AUGCL_E_LAUNCH, "%s: cannot set dynamic LDS %zu: %s", name, lds, hipGetErrorString(e));
+    const int grid = a.n_items < cus ? a.n_items : cus;
+    hipLaunchKernelGGL(k_conv32_bf16<MODE>, dim3(grid), dim3(512), lds, s, a);
+    return augcl::check_launch(name);
+}
+} // namespace
+
+extern "C" {
+
+int augcl_enc_bf16_conv32_forward(const void *in_bf16_nhwc, const float *w, const float *bias, void *out, int B, int Hi,
+                                  int Wi, int relu, int out_f32_nchw, augcl_stream_t stream)
+{
+    const char *name = "augcl_enc_bf16_conv32_forward";
+    AUGCL_REQUIRE(B >= 0 && Hi >= 3 && Wi >= 3, "%s: bad shape", name);
+    if (B == 0) return AUGCL_OK;
+    AUGCL_REQUIRE(in_bf16_nhwc && w && out, "%s: null tensor", name);
+    AUGCL_REQUIRE(aligned16(in_bf16_nhwc) && aligned16(out), "%s: tensors must be 16-byte aligned", name);
+    AUGCL_REQUIRE((size_t)B * 32 * Hi * Wi < ((size_t)1 << 31), "%s: tensor too large for 32-bit offsets", name);
+    ConvBfArgs a{};
+    a.in = reinterpret_cast<const uint4 *>(in_bf16_nhwc); a.w = w; a.bias = bias; a.mask = nullptr; a.out = out;
+    a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ho = Hi - 2; a.Wo = Wi - 2; a.relu = relu; a.out_f32 = out_f32_nchw;
+    return launch_conv_bf16<0>(a, name, as_stream(stream));
+}
+
+int augcl_enc_bf16_conv32_backward_data(const void *dz_bf16_nhwc, const float *w, const void *act_prev_bf16_nhwc,
+                                        void *dact_bf16_nhwc, int B, int Ho, int Wo, augcl_stream_t stream)
+{
+    const char *name = "augcl_enc_bf16_conv32_backward_data";
+    AUGCL_REQUIRE(B >= 0 && Ho >= 1 && Wo >= 1, "%s: bad shape", name);
+    if (B == 0) return AUGCL_OK;
+    AUGCL_REQUIRE(dz_bf16_nhwc && w && dact_bf16_nhwc, "%s: null tensor", name);
+    AUGCL_REQUIRE(aligned16(dz_bf16_nhwc) && aligned16(dact_bf16_nhwc) && aligned16(act_prev_bf16_nhwc),
+                  "%s: tensors must be 16-byte aligned", name);
+    AUGCL_REQUIRE((size_t)B * 32 * (Ho + 2) * (Wo + 2) < ((size_t)1 << 31), "%s: tensor too large", name);
+    ConvBfArgs a{};
+    a.in = reinterpret_cast<const uint4 *>(dz_bf16_nhwc); a.w = w; a.bias = nullptr;
+    a.mask = reinterpret_cast<const uint4 *>(act_prev_bf16_nhwc); a.out = dact_bf16_nhwc;
+    a.B = B; a.Hi = Ho; a.Wi = Wo; a.Ho = Ho + 2; a.Wo = Wo + 2; a.relu = 0; a.out_f32 = 0;
+    return launch_conv_bf16<1>(a, name, as_stream(stream));
+}
+
+int augcl_enc_nchw_f32_to_nhwc_bf16(const float *in, void *out_bf16_nhwc, int B, int H, int W, augcl_stream_t stream)
+{
+    const char *name = "augcl_enc_nchw_f32_to_nhwc_bf16";
+    AUGCL_REQUIRE(B >= 0 && H > 0 && W > 0, "%s: bad shape", name);
+    if (B == 0) return AUGCL_OK;
+    AUGCL_REQUIRE(in && out_bf16_nhwc && aligned16(out_bf16_nhwc), "%s: bad tensor", name);
+    const size_t total = (size_t)B * H * W * 4;
+    const size_t blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(k_nchw_f32_to_nhwc_bf16, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0,
+                       as_stream(stream), in, reinterpret_cast<__bf16 *>(out_bf16_nhwc), B, H * W);
+    return augcl::check_launch(name);
+}
+
+} // extern "C"

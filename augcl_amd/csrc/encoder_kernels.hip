@@ -297,7 +297,9 @@ struct Conv1Args {
     float scale;
 };
 
-template <int CH> // CH*9 MFMA steps
+typedef __bf16 bf16x4k __attribute__((ext_vector_type(4)));
+
+template <int CH, bool OUT_BF16 = false> // CH*9 MFMA steps; OUT_BF16: write bf16 NHWC (perf mode) instead of f32 NCHW
 __global__ __launch_bounds__(256, 2) void k_conv_first(Conv1Args a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[]; // [2*CH][rows_in][Wi]
@@ -359,7 +361,20 @@ __global__ __launch_bounds__(256, 2) void k_conv_first(Conv1Args a)
                         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[cil * 9 + ky * 3 + kx], pc[ky * a.Wi + kx], acc,
                                                                    0, 0, 0);
             }
-            if (valid) {
+            if (valid && OUT_BF16) {
+                bf16x4k *o = reinterpret_cast<bf16x4k *>(a.out) + ((size_t)(b * a.Ho + y0 + yy) * a.Wo + xx) * 8;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) { // lane holds channels 8*g4 + 4*h + e
+                    bf16x4k pk;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc[g4 * 4 + e];
+                        if (a.relu) v = fmaxf(v, 0.0f);
+                        pk[e] = (__bf16)v;
+                    }
+                    o[2 * g4 + h] = pk;
+                }
+            } else if (valid) {
                 const size_t o0 = ((size_t)b * 32 * a.Ho + (y0 + yy)) * a.Wo + xx;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -397,7 +412,12 @@ struct WgPrefetch { // lane-contiguous dwords: conflict-free ds_write_b32 into t
     float a[8][8], z[8][4];
 };
 
-template <int ABL = 0>
+__device__ __forceinline__ float bf16lo(uint32_t d) { return __uint_as_float(d << 16); }
+__device__ __forceinline__ float bf16hi(uint32_t d) { return __uint_as_float(d & 0xffff0000u); }
+
+// BF16IN: activations / dZ are bf16 NHWC (perf mode): wave w loads 16-byte chunk w (channels 8w..8w+7) of every
+// pixel of the runs -- fully coalesced -- and scatters the 8 values (widened to f32) into its 8 channel planes.
+template <int ABL = 0, bool BF16IN = false>
 __global__ __launch_bounds__(256, 1) void k_wgrad32(WgradArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -421,6 +441,17 @@ __global__ __launch_bounds__(256, 1) void k_wgrad32(WgradArgs a)
         const int y0 = s * a.RT;
         const int rows = min(a.RT, a.Ho - y0);
         const int runA = (rows + 2) * a.Wi, runZ = rows * a.Wo;
+        if (BF16IN) {
+            const uint4 *ga = reinterpret_cast<const uint4 *>(a.act) + ((size_t)(b * a.Hi + y0) * a.Wi) * 4 + wave;
+            const uint4 *gz = reinterpret_cast<const uint4 *>(a.dz) + ((size_t)(b * a.Ho + y0) * a.Wo) * 4 + wave;
+            uint4 *pa = reinterpret_cast<uint4 *>(&pf.a[0][0]); // 8 chunks (A run <= 512 px) + 4 chunks (dZ run <= 256 px)
+            uint4 *pz = reinterpret_cast<uint4 *>(&pf.a[4][0]);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) pa[u] = ga[(size_t)min(lane + 64 * u, runA - 1) * 4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) pz[u] = gz[(size_t)min(lane + 64 * u, runZ - 1) * 4];
+            return;
+        }
         const float *src = a.act + ((size_t)b * 32 * a.Hi + y0) * a.Wi; // rows contiguous in NCHW
         const float *sz = a.dz + ((size_t)b * 32 * a.Ho + y0) * a.Wo;
         const size_t csA = (size_t)a.Hi * a.Wi, csZ = (size_t)a.Ho * a.Wo;
@@ -440,6 +471,32 @@ __global__ __launch_bounds__(256, 1) void k_wgrad32(WgradArgs a)
         const int rows = min(a.RT, a.Ho - s * a.RT);
         const int runA = (rows + 2) * a.Wi, runZ = rows * a.Wo;
         float *ldsA = lds + bi * bufw, *ldsZ = ldsA + 32 * planeA;
+        if (BF16IN) {
+            const uint4 *pa = reinterpret_cast<const uint4 *>(&pf.a[0][0]);
+            const uint4 *pz = reinterpret_cast<const uint4 *>(&pf.a[4][0]);
+            float *da = ldsA + 8 * wave * planeA, *dz = ldsZ + 8 * wave * planeZ;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int p = min(lane + 64 * u, runA - 1);
+                const uint32_t d[4] = {pa[u].x, pa[u].y, pa[u].z, pa[u].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    da[(2 * e) * planeA + p] = bf16lo(d[e]);
+                    da[(2 * e + 1) * planeA + p] = bf16hi(d[e]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int p = min(lane + 64 * u, runZ - 1);
+                const uint32_t d[4] = {pz[u].x, pz[u].y, pz[u].z, pz[u].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    dz[(2 * e) * planeZ + p] = bf16lo(d[e]);
+                    dz[(2 * e + 1) * planeZ + p] = bf16hi(d[e]);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             float *da = ldsA + (8 * wave + k) * planeA, *dz = ldsZ + (8 * wave + k) * planeZ;
@@ -556,7 +613,7 @@ struct Wgrad1Args {
     float scale;
 };
 
-template <int NT>
+template <int NT, bool BF16DZ = false>
 __global__ __launch_bounds__(256, 1) void k_wgrad_first(Wgrad1Args a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -602,11 +659,25 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_first(Wgrad1Args a)
                 const int cb = min(c + 1, a.C - 1); // odd C: the last pair copies the last channel twice (same bytes)
                 wave_copy_runs2<2, false>(src + c * cs, src + cb * cs, ldsX + c * planeX, ldsX + cb * planeX, run, lane, xf);
             }
-            const float *sz = a.dz + ((size_t)b * 32 * a.Ho + y0) * a.Wo;
-            const size_t csZ = (size_t)a.Ho * a.Wo;
-            for (int c = wave * 2; c < 32; c += 8)
-                wave_copy_runs2<3, false>(sz + c * csZ, sz + (c + 1) * csZ, ldsZ + c * planeZ, ldsZ + (c + 1) * planeZ,
-                                          npix, lane, XfId());
+            if (BF16DZ) { // dZ is bf16 NHWC: wave w takes chunk w (channels 8w..8w+7) of every strip pixel
+                const uint4 *gz = reinterpret_cast<const uint4 *>(a.dz) + ((size_t)(b * a.Ho + y0) * a.Wo) * 4 + wave;
+                float *dzl = ldsZ + 8 * wave * planeZ;
+                for (int p = lane; p < npix; p += 64) {
+                    const uint4 v = gz[(size_t)p * 4];
+                    const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        dzl[(2 * e) * planeZ + p] = bf16lo(d[e]);
+                        dzl[(2 * e + 1) * planeZ + p] = bf16hi(d[e]);
+                    }
+                }
+            } else {
+                const float *sz = a.dz + ((size_t)b * 32 * a.Ho + y0) * a.Wo;
+                const size_t csZ = (size_t)a.Ho * a.Wo;
+                for (int c = wave * 2; c < 32; c += 8)
+                    wave_copy_runs2<3, false>(sz + c * csZ, sz + (c + 1) * csZ, ldsZ + c * planeZ, ldsZ + (c + 1) * planeZ,
+                                              npix, lane, XfId());
+            }
         }
         __syncthreads();
         const int npair = (npix + 1) >> 1;
@@ -787,10 +858,10 @@ int augcl_enc_conv32_backward_data(const float *dz, const float *w, const float 
     return augcl::check_launch(name);
 }
 
-int augcl_enc_conv_first_forward(const float *in, const float *w, const float *bias, float *out, int B, int C, int Hi,
-                                 int Wi, int stride, float scale, int relu, augcl_stream_t stream)
+static int conv_first_forward_impl(const float *in, const float *w, const float *bias, float *out, int B, int C, int Hi,
+                                   int Wi, int stride, float scale, int relu, bool out_bf16, augcl_stream_t stream,
+                                   const char *name)
 {
-    const char *name = "augcl_enc_conv_first_forward";
     AUGCL_REQUIRE(B >= 0 && C >= 1 && Hi >= 3 && Wi >= 3 && (stride == 1 || stride == 2) && scale > 0.0f,
                   "%s: bad shape", name);
     if (B == 0) return AUGCL_OK;
@@ -809,10 +880,15 @@ int augcl_enc_conv_first_forward(const float *in, const float *w, const float *b
     a.n_items = B * a.S;
     const size_t lds = (size_t)2 * CH * (stride * (a.RT - 1) + 3) * Wi * 4;
     hipStream_t s = as_stream(stream);
-#define LAUNCH_FIRST(CHV)                                                                     \
-    do {                                                                                      \
-        if (int rc = set_lds(k_conv_first<CHV>, lds, name)) return rc;                        \
-        hipLaunchKernelGGL(k_conv_first<CHV>, dim3(grid_for(a.n_items, 2)), dim3(256), lds, s, a); \
+#define LAUNCH_FIRST(CHV)                                                                                  \
+    do {                                                                                                   \
+        if (out_bf16) {                                                                                    \
+            if (int rc = set_lds(k_conv_first<CHV, true>, lds, name)) return rc;                           \
+            hipLaunchKernelGGL((k_conv_first<CHV, true>), dim3(grid_for(a.n_items, 2)), dim3(256), lds, s, a); \
+        } else {                                                                                           \
+            if (int rc = set_lds(k_conv_first<CHV, false>, lds, name)) return rc;                          \
+            hipLaunchKernelGGL((k_conv_first<CHV, false>), dim3(grid_for(a.n_items, 2)), dim3(256), lds, s, a); \
+        }                                                                                                  \
     } while (0)
     switch (CH) {
     case 1: LAUNCH_FIRST(1); break;
@@ -828,16 +904,31 @@ int augcl_enc_conv_first_forward(const float *in, const float *w, const float *b
     return augcl::check_launch(name);
 }
 
+extern "C" int augcl_enc_conv_first_forward(const float *in, const float *w, const float *bias, float *out, int B, int C,
+                                            int Hi, int Wi, int stride, float scale, int relu, augcl_stream_t stream)
+{
+    return conv_first_forward_impl(in, w, bias, out, B, C, Hi, Wi, stride, scale, relu, false, stream,
+                                   "augcl_enc_conv_first_forward");
+}
+
+extern "C" int augcl_enc_bf16_conv_first_forward(const float *in, const float *w, const float *bias, void *out_bf16_nhwc,
+                                                 int B, int C, int Hi, int Wi, int stride, float scale, int relu,
+                                                 augcl_stream_t stream)
+{
+    return conv_first_forward_impl(in, w, bias, reinterpret_cast<float *>(out_bf16_nhwc), B, C, Hi, Wi, stride, scale,
+                                   relu, true, stream, "augcl_enc_bf16_conv_first_forward");
+}
+
 size_t augcl_enc_wgrad_workspace_bytes(int C)
 {
     // slabs for up to 256 CUs x 1 workgroup + RG rows of the two-level reduction; C = input channels of the layer
     return (size_t)(256 + 8) * ((size_t)32 * C * 9 + 32) * sizeof(float);
 }
 
-int augcl_enc_conv32_backward_weights(const float *act_prev, const float *dz, float *dw, float *db, float *workspace,
-                                      size_t workspace_bytes, int B, int Hi, int Wi, augcl_stream_t stream)
+static int wgrad32_impl(const float *act_prev, const float *dz, float *dw, float *db, float *workspace,
+                        size_t workspace_bytes, int B, int Hi, int Wi, bool bf16in, augcl_stream_t stream,
+                        const char *name)
 {
-    const char *name = "augcl_enc_conv32_backward_weights";
     AUGCL_REQUIRE(B >= 1 && Hi >= 3 && Wi >= 3, "%s: bad shape", name);
     AUGCL_REQUIRE(act_prev && dz && dw && db && workspace, "%s: null tensor", name);
     WgradArgs a{};
@@ -860,9 +951,14 @@ int augcl_enc_conv32_backward_weights(const float *act_prev, const float *dz, fl
     const int grid = grid_for(a.n_items, 1);
     AUGCL_REQUIRE(workspace_bytes >= (size_t)(grid + RG) * WG_SLAB * 4, "%s: workspace too small (%zu < %zu)", name,
                   workspace_bytes, (size_t)(grid + RG) * WG_SLAB * 4);
-    if (int rc = set_lds(k_wgrad32<0>, lds, name)) return rc;
     hipStream_t s = as_stream(stream);
-    hipLaunchKernelGGL(k_wgrad32<0>, dim3(grid), dim3(256), lds, s, a);
+    if (bf16in) {
+        if (int rc = set_lds(k_wgrad32<0, true>, lds, name)) return rc;
+        hipLaunchKernelGGL((k_wgrad32<0, true>), dim3(grid), dim3(256), lds, s, a);
+    } else {
+        if (int rc = set_lds(k_wgrad32<0, false>, lds, name)) return rc;
+        hipLaunchKernelGGL((k_wgrad32<0, false>), dim3(grid), dim3(256), lds, s, a);
+    }
     float *part2 = workspace + (size_t)grid * WG_SLAB;
     hipLaunchKernelGGL(k_reduce_slabs_l1, dim3((WG_SLAB + 255) / 256, RG), dim3(256), 0, s, workspace, grid, WG_SLAB,
                        part2);
@@ -871,11 +967,26 @@ int augcl_enc_conv32_backward_weights(const float *act_prev, const float *dz, fl
     return augcl::check_launch(name);
 }
 
-int augcl_enc_conv_first_backward_weights(const float *x, const float *dz, float *dw, float *db, float *workspace,
-                                          size_t workspace_bytes, int B, int C, int Hi, int Wi, int stride, float scale,
-                                          augcl_stream_t stream)
+int augcl_enc_conv32_backward_weights(const float *act_prev, const float *dz, float *dw, float *db, float *workspace,
+                                      size_t workspace_bytes, int B, int Hi, int Wi, augcl_stream_t stream)
 {
-    const char *name = "augcl_enc_conv_first_backward_weights";
+    return wgrad32_impl(act_prev, dz, dw, db, workspace, workspace_bytes, B, Hi, Wi, false, stream,
+                        "augcl_enc_conv32_backward_weights");
+}
+
+int augcl_enc_bf16_conv32_backward_weights(const void *act_prev_bf16_nhwc, const void *dz_bf16_nhwc, float *dw, float *db,
+                                           float *workspace, size_t workspace_bytes, int B, int Hi, int Wi,
+                                           augcl_stream_t stream)
+{
+    return wgrad32_impl(reinterpret_cast<const float *>(act_prev_bf16_nhwc), reinterpret_cast<const float *>(dz_bf16_nhwc),
+                        dw, db, workspace, workspace_bytes, B, Hi, Wi, true, stream,
+                        "augcl_enc_bf16_conv32_backward_weights");
+}
+
+static int wgrad_first_impl(const float *x, const float *dz, float *dw, float *db, float *workspace,
+                            size_t workspace_bytes, int B, int C, int Hi, int Wi, int stride, float scale,
+                            bool bf16dz, augcl_stream_t stream, const char *name)
+{
     AUGCL_REQUIRE(B >= 1 && C >= 1 && Hi >= 3 && Wi >= 3 && (stride == 1 || stride == 2) && scale > 0.0f,
                   "%s: bad shape", name);
     AUGCL_REQUIRE(x && dz && dw && db && workspace, "%s: null tensor", name);
@@ -901,10 +1012,15 @@ int augcl_enc_conv_first_backward_weights(const float *x, const float *dz, float
     const int slab = 32 * K + 32;
     AUGCL_REQUIRE(workspace_bytes >= (size_t)(grid + RG) * slab * 4, "%s: workspace too small", name);
     hipStream_t s = as_stream(stream);
-#define LAUNCH_WG1(NTV)                                                      \
-    do {                                                                     \
-        if (int rc = set_lds(k_wgrad_first<NTV>, lds, name)) return rc;      \
-        hipLaunchKernelGGL(k_wgrad_first<NTV>, dim3(grid), dim3(256), lds, s, a); \
+#define LAUNCH_WG1(NTV)                                                                      \
+    do {                                                                                     \
+        if (bf16dz) {                                                                        \
+            if (int rc = set_lds(k_wgrad_first<NTV, true>, lds, name)) return rc;            \
+            hipLaunchKernelGGL((k_wgrad_first<NTV, true>), dim3(grid), dim3(256), lds, s, a);  \
+        } else {                                                                             \
+            if (int rc = set_lds(k_wgrad_first<NTV, false>, lds, name)) return rc;           \
+            hipLaunchKernelGGL((k_wgrad_first<NTV, false>), dim3(grid), dim3(256), lds, s, a); \
+        }                                                                                    \
     } while (0)
     switch (NT) {
     case 1: LAUNCH_WG1(1); break;
@@ -920,6 +1036,22 @@ int augcl_enc_conv_first_backward_weights(const float *x, const float *dz, float
     hipLaunchKernelGGL(k_reduce_slabs_l1, dim3((slab + 255) / 256, RG), dim3(256), 0, s, workspace, grid, slab, part2);
     hipLaunchKernelGGL(k_reduce_slabs_l2, dim3((slab + 255) / 256), dim3(256), 0, s, part2, slab, dw, 32 * K, db);
     return augcl::check_launch(name);
+}
+
+int augcl_enc_conv_first_backward_weights(const float *x, const float *dz, float *dw, float *db, float *workspace,
+                                          size_t workspace_bytes, int B, int C, int Hi, int Wi, int stride, float scale,
+                                          augcl_stream_t stream)
+{
+    return wgrad_first_impl(x, dz, dw, db, workspace, workspace_bytes, B, C, Hi, Wi, stride, scale, false, stream,
+                            "augcl_enc_conv_first_backward_weights");
+}
+
+int augcl_enc_bf16_conv_first_backward_weights(const float *x, const void *dz_bf16_nhwc, float *dw, float *db,
+                                               float *workspace, size_t workspace_bytes, int B, int C, int Hi, int Wi,
+                                               int stride, float scale, augcl_stream_t stream)
+{
+    return wgrad_first_impl(x, reinterpret_cast<const float *>(dz_bf16_nhwc), dw, db, workspace, workspace_bytes, B, C, Hi,
+                            Wi, stride, scale, true, stream, "augcl_enc_bf16_conv_first_backward_weights");
 }
 
 } // extern "C"

@@ -96,3 +96,76 @@ class ConvStackFn(torch.autograd.Function):
                 call("augcl_enc_conv32_backward_data", p(dz), p(wi), p(a_prev) if relu_first else None, p(dx), B,
                      dz.shape[2], dz.shape[3], st)
         return (dx, None, None, None, None, *dws, *dbs)
+
+
+class ConvStackBf16Fn(torch.autograd.Function):
+    """bf16 PERFORMANCE MODE of the same stack (augcl_enc_bf16_*): activations bf16 NHWC in HBM, bf16 MFMA with
+    f32 accumulation, f32 master weights and f32 weight gradients.  Not the parity path (bf16 resolution)."""
+
+    @staticmethod
+    def forward(ctx, x, first_stride, input_scale, relu_first, n_layers, *wb):
+        weights, biases = wb[:n_layers], wb[n_layers:]
+        assert not relu_first, "bf16 mode covers the SharedCNN stack (image input)"
+        assert x.dtype == torch.float32 and x.is_contiguous()
+        B, C, H, W = x.shape
+        dev = x.device
+        st = _lib.current_stream(dev)
+        call, p = _lib.call, _lib.ptr
+        need_grad = any(t.requires_grad for t in wb)
+        acts = [x]
+        h, w_ = _out_hw(H, first_stride), _out_hw(W, first_stride)
+        w0, b0 = weights[0].detach(), biases[0].detach()
+        cur = torch.empty((B, h, w_, 32), dtype=torch.bfloat16, device=dev)
+        call("augcl_enc_bf16_conv_first_forward", p(x), p(w0), p(b0), p(cur), B, C, H, W, first_stride, input_scale,
+             1 if n_layers > 1 else 0, st)
+        for i in range(1, n_layers):
+            wi, bi = weights[i].detach(), biases[i].detach()
+            last = i == n_layers - 1
+            ho, wo = h - 2, w_ - 2
+            out = (torch.empty((B, 32, ho, wo), dtype=torch.float32, device=dev) if last
+                   else torch.empty((B, ho, wo, 32), dtype=torch.bfloat16, device=dev))
+            call("augcl_enc_bf16_conv32_forward", p(cur), p(wi), p(bi), p(out), B, h, w_, 0 if last else 1,
+                 1 if last else 0, st)
+            if need_grad:
+                acts.append(cur)
+            cur, h, w_ = out, ho, wo
+        if n_layers == 1:
+            raise NotImplementedError("bf16 mode needs at least two conv layers")
+        if need_grad:
+            ctx.save_for_backward(*acts, *[t.detach() for t in weights])
+            ctx.meta = (first_stride, input_scale, n_layers)
+        return cur
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        first_stride, input_scale, n_layers = ctx.meta
+        saved = ctx.saved_tensors
+        acts, weights = saved[:n_layers], saved[n_layers:]  # acts[0] = x (f32 NCHW), acts[i>0] = a_i (bf16 NHWC)
+        x = acts[0]
+        B = x.shape[0]
+        dev = grad_out.device
+        st = _lib.current_stream(dev)
+        call, p = _lib.call, _lib.ptr
+        g = grad_out.contiguous()
+        dz = torch.empty((B, g.shape[2], g.shape[3], 32), dtype=torch.bfloat16, device=dev)
+        call("augcl_enc_nchw_f32_to_nhwc_bf16", p(g), p(dz), B, g.shape[2], g.shape[3], st)
+        dws, dbs = [None] * n_layers, [None] * n_layers
+        ws32 = _workspace(dev, 32)
+        for i in range(n_layers - 1, 0, -1):
+            a_prev, wi = acts[i], weights[i]  # (B,Hi,Wi,32) bf16
+            dw = torch.empty_like(wi)
+            db = torch.empty(32, dtype=torch.float32, device=dev)
+            call("augcl_enc_bf16_conv32_backward_weights", p(a_prev), p(dz), p(dw), p(db), p(ws32), ws32.numel() * 4, B,
+                 a_prev.shape[1], a_prev.shape[2], st)
+            dws[i], dbs[i] = dw, db
+            dact = torch.empty_like(a_prev)
+            call("augcl_enc_bf16_conv32_backward_data", p(dz), p(wi), p(a_prev), p(dact), B, dz.shape[1], dz.shape[2], st)
+            dz = dact
+        w0 = weights[0]
+        dw = torch.empty_like(w0)
+        db = torch.empty(32, dtype=torch.float32, device=dev)
+        ws = _workspace(dev, w0.shape[1])
+        call("augcl_enc_bf16_conv_first_backward_weights", p(x), p(dz), p(dw), p(db), p(ws), ws.numel() * 4, B, w0.shape[1],
+             x.shape[2], x.shape[3], first_stride, input_scale, st)
+        dws[0], dbs[0] = dw, db
+        return (None, None, None, None, None, *dws, *dbs)

@@ -17,6 +17,13 @@ import torch.nn.functional as F
 from . import _lib
 
 BACKEND = os.environ.get("AUGCL_ENCODER", "hip")
+PRECISION = os.environ.get("AUGCL_PRECISION", "f32")  # "f32" = parity path; "bf16" = performance mode (config 2)
+
+
+def set_precision(name):
+    global PRECISION
+    assert name in ("f32", "bf16")
+    PRECISION = name
 
 
 def set_backend(name):
@@ -40,5 +47,7 @@ def conv_stack(x, weights, biases, first_stride=2, input_scale=255.0, relu_first
         return _conv_stack_torch(x, weights, biases, first_stride, input_scale, relu_first)
     _lib.require_cuda(x, "conv_stack input")
     from . import encoder_hip
+    if PRECISION == "bf16" and not relu_first and len(weights) > 1 and weights[0].shape[0] == 32:
+        return encoder_hip.ConvStackBf16Fn.apply(x, first_stride, float(input_scale), False, len(weights), *weights, *biases)
     return encoder_hip.ConvStackFn.apply(x, first_stride, float(input_scale), bool(relu_first), len(weights),
                                          *weights, *biases)

@@ -150,6 +150,25 @@ int augcl_enc_conv_first_backward_weights(const float *x /* (B,C,Hi,Wi) raw */, 
                                           float *db, float *workspace, size_t workspace_bytes, int B, int C, int Hi,
                                           int Wi, int stride, float scale, augcl_stream_t stream);
 
+/* ---- bf16 PERFORMANCE MODE of the same conv stack (BASELINE config 2 "bf16"; NOT the parity path).
+ * Activations are bf16 NHWC (B,H,W,32) in HBM, products on v_mfma_f32_32x32x16_bf16 with f32 accumulation,
+ * weights/biases stay f32 masters (rounded to bf16 per launch).  The last layer can emit f32 NCHW for the
+ * projection (out_f32_nchw); the incoming gradient is converted with augcl_enc_nchw_f32_to_nhwc_bf16. */
+int augcl_enc_bf16_conv_first_forward(const float *in /* (B,C,Hi,Wi) f32 raw */, const float *w, const float *bias,
+                                      void *out_bf16_nhwc, int B, int C, int Hi, int Wi, int stride, float scale,
+                                      int relu, augcl_stream_t stream);
+int augcl_enc_bf16_conv32_forward(const void *in_bf16_nhwc, const float *w, const float *bias, void *out, int B, int Hi,
+                                  int Wi, int relu, int out_f32_nchw, augcl_stream_t stream);
+int augcl_enc_bf16_conv32_backward_data(const void *dz_bf16_nhwc, const float *w, const void *act_prev_bf16_nhwc,
+                                        void *dact_bf16_nhwc, int B, int Ho, int Wo, augcl_stream_t stream);
+int augcl_enc_bf16_conv32_backward_weights(const void *act_prev_bf16_nhwc, const void *dz_bf16_nhwc, float *dw, float *db,
+                                           float *workspace, size_t workspace_bytes, int B, int Hi, int Wi,
+                                           augcl_stream_t stream);
+int augcl_enc_bf16_conv_first_backward_weights(const float *x /* f32 raw */, const void *dz_bf16_nhwc, float *dw, float *db,
+                                               float *workspace, size_t workspace_bytes, int B, int C, int Hi, int Wi,
+                                               int stride, float scale, augcl_stream_t stream);
+int augcl_enc_nchw_f32_to_nhwc_bf16(const float *in, void *out_bf16_nhwc, int B, int H, int W, augcl_stream_t stream);
+
 /* ---- device-resident replay sampling: ReplayBuffer.sample -> tensor_buffer_samples / _encode_obses /
  * LazyFrames._force (src/utils.py:206-214, 234-240, 272-280, 293-299).  `frames` is a uint8 ring of RGB frames
  * (frame_bytes = 3*H*W each) in HBM; slots[b*stack + k] names the k-th frame of sample b's stack.
