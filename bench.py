@@ -213,7 +213,9 @@ def main():
         res["extras"] = extras
         try:
             from augcl_amd import bench_update
-            res["sac"] = bench_update.run(dev, dist, world, rank, steps=max(10, args.steps // 20))
+            n_upd = max(10, args.steps // 20)
+            res["sac"] = bench_update.run(dev, dist, world, rank, steps=n_upd)  # f32: the parity path
+            res["sac"]["bf16_mode"] = bench_update.run(dev, dist, world, rank, steps=n_upd, precision="bf16")
         except ImportError:
             res["sac"] = None
 
