@@ -301,3 +301,234 @@ int augcl_enc_nchw_f32_to_nhwc_bf16(const float *in, void *out_bf16_nhwc, int B,
 }
 
 } // extern "C"
+
+// =========================================================================================
+// backward-weights in bf16: D_t[co][ci] = sum_p dZ[p][co] * A[p + tap_t][ci], K = 16 pixels per
+// v_mfma_f32_32x32x16_bf16 (8x fewer MFMAs than the f32 path).  Both operands need 8 consecutive PIXELS
+// of one channel per lane, while the NHWC tiles in LDS hold 32 channels of one pixel per 64-byte row:
+// ds_read_b64_tr_b16 delivers exactly that transpose (4 rows x 16 columns per 16-lane group, column-major),
+// so the tiles are staged by plain 16-byte copies and every tap is just a different row address.
+// 4 loader + 4 compute waves, double-buffered {A tile, dZ tile}; partial slabs + fixed-order reduction
+// as in the f32 path (bitwise reproducible).
+// =========================================================================================
+namespace augcl {
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+struct WgBfArgs {
+    const uint4 *act; // a_{l-1} bf16 NHWC (B,Hi,Wi,32)
+    const uint4 *dz;  // bf16 NHWC (B,Ho,Wo,32)
+    float *partial;   // [gridDim.x][32*288 + 32]
+    int B, Hi, Wi, Ho, Wo, RT, S, n_items;
+};
+
+constexpr int WGB_SLAB = 32 * 288 + 32;
+
+__device__ __forceinline__ s16x4 lds_tr(const char *p)
+{
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)(p));
+}
+
+__global__ __launch_bounds__(512, 2) void k_wgrad32_bf16(WgBfArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char ldsb[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = wave >= 4;
+    const int cw = wave & 3;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int Wi = a.Wi, Wo = a.Wo;
+    const int apix = (a.RT + 2) * Wi;                // A tile pixels
+    const int zpix = (a.RT * Wo + 15) & ~15;         // dZ tile pixels, zero-padded to whole 16-pixel steps
+    const int bufbytes = (apix + zpix) * 64;
+    // this lane's part in the transposed reads: it SUPPLIES row q, columns 4pp..4pp+3 of its group's 16-channel block
+    const int q = (lane & 15) >> 2, pp = lane & 3, cblk = (lane >> 4) & 1;
+    const int colbyte = (16 * cblk + 4 * pp) * 2;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    float dbacc = 0.0f;
+
+    auto stage = [&](int item, int bi) {
+        const int b = item / a.S, s = item - b * a.S;
+        const int y0 = s * a.RT;
+        const int rows = min(a.RT, a.Ho - y0);
+        const int na = (rows + 2) * Wi * 4, nz = rows * Wo * 4; // 16-byte chunks
+        const uint4 *ga = a.act + ((size_t)(b * a.Hi + y0) * Wi) * 4;
+        const uint4 *gz = a.dz + ((size_t)(b * a.Ho + y0) * Wo) * 4;
+        uint4 *da = reinterpret_cast<uint4 *>(ldsb + bi * bufbytes);
+        uint4 *dzl = da + apix * 4;
+        const int lt = cw * 64 + lane;
+        for (int c0 = 0; c0 < na; c0 += 256 * 6) {
+            uint4 v[6];
+#pragma unroll
+            for (int u = 0; u < 6; ++u) v[u] = ga[min(c0 + u * 256 + lt, na - 1)];
+#pragma unroll
+            for (int u = 0; u < 6; ++u) da[min(c0 + u * 256 + lt, na - 1)] = v[u];
+        }
+        for (int c0 = 0; c0 < nz; c0 += 256 * 6) {
+            uint4 v[6];
+#pragma unroll
+            for (int u = 0; u < 6; ++u) v[u] = gz[min(c0 + u * 256 + lt, nz - 1)];
+#pragma unroll
+            for (int u = 0; u < 6; ++u) dzl[min(c0 + u * 256 + lt, nz - 1)] = v[u];
+        }
+        for (int c = nz + lt; c < zpix * 4; c += 256) dzl[c] = make_uint4(0u, 0u, 0u, 0u); // zero the padded pixels
+    };
+
+    int it = 0;
+    const int first = blockIdx.x;
+    if (loader && first < a.n_items) stage(first, 0);
+    __syncthreads();
+    for (int item = first; item < a.n_items; item += gridDim.x, ++it) {
+        const int next = item + gridDim.x;
+        if (loader) {
+            if (next < a.n_items) stage(next, (it + 1) & 1);
+        } else {
+            const int s = item % a.S;
+            const int rows = min(a.RT, a.Ho - s * a.RT);
+            const int npix = rows * Wo;
+            const char *At = ldsb + (it & 1) * bufbytes;
+            const char *Zt = At + apix * 64;
+            const int nsteps = (npix + 15) >> 4;
+            for (int k = cw; k < nsteps; k += 4) { // 16 strip pixels per step; all 64 lanes stay active (tr reads)
+                s16x4 zf[2];
+                const char *pa[2];
+#pragma unroll
+                for (int rd = 0; rd < 2; ++rd) {
+                    const int m = 16 * k + 8 * h + 4 * rd + q; // the pixel whose row this lane supplies
+                    zf[rd] = lds_tr(Zt + m * 64 + colbyte);
+                    const int mc = min(m, npix - 1);             // padded pixels: dZ is zero, read any real activation
+                    const int yy = mc / Wo, xx = mc - yy * Wo;
+                    pa[rd] = At + (yy * Wi + xx) * 64 + colbyte;
+                }
+                const s16x8 zfrag = __builtin_shufflevector(zf[0], zf[1], 0, 1, 2, 3, 4, 5, 6, 7);
+                const bf16x8 za = __builtin_bit_cast(bf16x8, zfrag);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dbacc += (float)za[j];
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) { // one kernel row at a time keeps only 6 operand fragments live
+                    s16x4 xf[3][2];
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                        for (int rd = 0; rd < 2; ++rd) xf[kx][rd] = lds_tr(pa[rd] + (ky * Wi + kx) * 64);
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const s16x8 xfrag = __builtin_shufflevector(xf[kx][0], xf[kx][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                        acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(za, __builtin_bit_cast(bf16x8, xfrag),
+                                                                                   acc[ky * 3 + kx], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- fixed-order reduction over the 4 compute waves through LDS, then one slab per workgroup
+    float *lds = reinterpret_cast<float *>(ldsb);
+    float *slab = a.partial + (size_t)blockIdx.x * WGB_SLAB;
+    for (int w = 1; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) lds[(t * 16 + r) * 64 + lane] = acc[t][r];
+            lds[144 * 64 + lane] = dbacc;
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] += lds[(t * 16 + r) * 64 + lane];
+            dbacc += lds[144 * 64 + lane];
+        }
+        __syncthreads();
+    }
+    if (wave == 0) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) slab[(size_t)acc_row_b(r, h) * 288 + l31 * 9 + t] = acc[t][r];
+        const float other = __shfl_xor(dbacc, 32, 64); // lanes (co, h=0/1) hold pixels 8h..8h+7 of every step
+        if (h == 0) slab[32 * 288 + l31] = dbacc + other;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_reduce_slabs_bf_l1(const float *__restrict__ partial, int nslab, int n,
+                                                            float *__restrict__ part2)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int per = (nslab + 7) / 8;
+    const int g0 = blockIdx.y * per, g1 = min(nslab, g0 + per);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int g = g0;
+    for (; g + 3 < g1; g += 4) {
+        s0 += partial[(size_t)g * n + i];
+        s1 += partial[(size_t)(g + 1) * n + i];
+        s2 += partial[(size_t)(g + 2) * n + i];
+        s3 += partial[(size_t)(g + 3) * n + i];
+    }
+    for (; g < g1; ++g) s0 += partial[(size_t)g * n + i];
+    part2[(size_t)blockIdx.y * n + i] = (s0 + s1) + (s2 + s3);
+}
+
+__global__ __launch_bounds__(256) void k_reduce_slabs_bf_l2(const float *__restrict__ part2, int n,
+                                                            float *__restrict__ out_w, int n_w, float *__restrict__ out_b)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+#pragma unroll
+    for (int y = 0; y < 8; ++y) s += part2[(size_t)y * n + i];
+    if (i < n_w) out_w[i] = s;
+    else out_b[i - n_w] = s;
+}
+
+} // namespace augcl
+
+extern "C" int augcl_enc_bf16_conv32_backward_weights_mfma(const void *act_prev_bf16_nhwc, const void *dz_bf16_nhwc,
+                                                           float *dw, float *db, float *workspace,
+                                                           size_t workspace_bytes, int B, int Hi, int Wi,
+                                                           augcl_stream_t stream)
+{
+    const char *name = "augcl_enc_bf16_conv32_backward_weights_mfma";
+    AUGCL_REQUIRE(B >= 1 && Hi >= 3 && Wi >= 3, "%s: bad shape", name);
+    AUGCL_REQUIRE(act_prev_bf16_nhwc && dz_bf16_nhwc && dw && db && workspace, "%s: null tensor", name);
+    AUGCL_REQUIRE(aligned16(act_prev_bf16_nhwc) && aligned16(dz_bf16_nhwc), "%s: tensors must be 16-byte aligned", name);
+    WgBfArgs a{};
+    a.act = reinterpret_cast<const uint4 *>(act_prev_bf16_nhwc);
+    a.dz = reinterpret_cast<const uint4 *>(dz_bf16_nhwc);
+    a.partial = workspace;
+    a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ho = Hi - 2; a.Wo = Wi - 2;
+    // per buffer: (RT+2)*Wi + roundup16(RT*Wo) pixels of 64 bytes
+    int rt = (kBufBytes / 64 - 2 * Wi - 16) / (Wi + a.Wo);
+    AUGCL_REQUIRE(rt >= 1, "%s: image row too wide for LDS", name);
+    if (rt > a.Ho) rt = a.Ho;
+    a.S = (a.Ho + rt - 1) / rt;
+    const int cus = cu_count_bf();
+    while ((long)B * a.S < 2L * cus && a.S < a.Ho) ++a.S;
+    a.RT = (a.Ho + a.S - 1) / a.S;
+    a.S = (a.Ho + a.RT - 1) / a.RT;
+    a.n_items = B * a.S;
+    const int apix = (a.RT + 2) * Wi, zpix = (a.RT * a.Wo + 15) & ~15;
+    size_t lds = (size_t)2 * (apix + zpix) * 64;
+    const size_t red = (size_t)(145 * 64) * 4;
+    if (lds < red) lds = red;
+    const int grid = a.n_items < cus ? a.n_items : cus;
+    AUGCL_REQUIRE(workspace_bytes >= (size_t)(grid + 8) * WGB_SLAB * 4, "%s: workspace too small", name);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wgrad32_bf16),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return augcl::fail(AUGCL_E_LAUNCH, "%s: cannot set dynamic LDS %zu: %s", name, lds, hipGetErrorString(e));
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(k_wgrad32_bf16, dim3(grid), dim3(512), lds, s, a);
+    float *part2 = workspace + (size_t)grid * WGB_SLAB;
+    hipLaunchKernelGGL(k_reduce_slabs_bf_l1, dim3((WGB_SLAB + 255) / 256, 8), dim3(256), 0, s, workspace, grid, WGB_SLAB, part2);
+    hipLaunchKernelGGL(k_reduce_slabs_bf_l2, dim3((WGB_SLAB + 255) / 256), dim3(256), 0, s, part2, WGB_SLAB, dw, 32 * 288, db);
+    return augcl::check_launch(name);
+}

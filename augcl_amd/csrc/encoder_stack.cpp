@@ -1,0 +1,96 @@
+// encoder_stack.cpp -- whole-stack entry points: one C call runs every layer of the conv encoder forward
+// (or backward), so the host pays one FFI crossing per pass instead of one per layer kernel (the bf16 mode's
+// ~5 ms update had become CPU-launch-bound: ~90 ctypes calls + ~60 tensor allocations per step).
+#include "augcl_common.h"
+
+extern "C" {
+
+static inline int out_hw(int h, int stride) { return (h - 3) / stride + 1; }
+
+// precision: 0 = f32 NCHW activations (parity path), 1 = bf16 NHWC activations (performance mode).
+// acts_out[i] = output buffer of layer i; the last layer always writes f32 NCHW.
+int augcl_enc_stack_forward(const float *x, const float *const *w, const float *const *b, void *const *acts_out,
+                            int n_layers, int B, int C, int H, int W, int first_stride, float scale, int precision,
+                            augcl_stream_t stream)
+{
+    AUGCL_REQUIRE(x && w && b && acts_out && n_layers >= 1, "augcl_enc_stack_forward: bad argument");
+    AUGCL_REQUIRE(precision == 0 || n_layers >= 2, "augcl_enc_stack_forward: bf16 mode needs >= 2 layers");
+    int h = H, ww = W, rc;
+    const void *cur = x;
+    for (int i = 0; i < n_layers; ++i) {
+        const int relu = i < n_layers - 1;
+        const bool last = i == n_layers - 1;
+        if (i == 0) {
+            if (precision == 0)
+                rc = augcl_enc_conv_first_forward(x, w[0], b[0], (float *)acts_out[0], B, C, h, ww, first_stride, scale, relu,
+                                                  stream);
+            else
+                rc = augcl_enc_bf16_conv_first_forward(x, w[0], b[0], acts_out[0], B, C, h, ww, first_stride, scale, relu,
+                                                       stream);
+            h = out_hw(h, first_stride);
+            ww = out_hw(ww, first_stride);
+        } else {
+            if (precision == 0)
+                rc = augcl_enc_conv32_forward((const float *)cur, w[i], b[i], (float *)acts_out[i], B, h, ww, relu, stream);
+            else
+                rc = augcl_enc_bf16_conv32_forward(cur, w[i], b[i], acts_out[i], B, h, ww, relu, last ? 1 : 0, stream);
+            h -= 2;
+            ww -= 2;
+        }
+        if (rc != AUGCL_OK) return rc;
+        cur = acts_out[i];
+    }
+    return AUGCL_OK;
+}
+
+// acts_in[i] = input of layer i (acts_in[0] = x raw f32; i >= 1: post-ReLU activation, f32 NCHW or bf16 NHWC);
+// grad_out = f32 NCHW gradient of the last layer's output; dz_a / dz_b = two scratch buffers, each large enough for
+// the largest activation (layer 0's output) in the mode's element type; dw[i] / db[i] receive the gradients.
+int augcl_enc_stack_backward(const void *const *acts_in, const float *const *w, const float *grad_out, float *const *dw,
+                             float *const *db, void *dz_a, void *dz_b, float *ws32, size_t ws32_bytes, float *ws_first,
+                             size_t ws_first_bytes, int n_layers, int B, int C, int H, int W, int first_stride,
+                             float scale, int precision, int bf16_wgrad_mfma, augcl_stream_t stream)
+{
+    AUGCL_REQUIRE(acts_in && w && grad_out && dw && db && dz_a && dz_b && n_layers >= 1, "augcl_enc_stack_backward: bad argument");
+    int hs[64], wsz[64]; // input size of every layer
+    AUGCL_REQUIRE(n_layers <= 63, "augcl_enc_stack_backward: too many layers");
+    hs[0] = H; wsz[0] = W;
+    hs[1] = out_hw(H, first_stride); wsz[1] = out_hw(W, first_stride);
+    for (int i = 2; i <= n_layers; ++i) { hs[i] = hs[i - 1] - 2; wsz[i] = wsz[i - 1] - 2; }
+    int rc;
+    const void *dz = grad_out; // f32 NCHW (B,32,hs[n],ws[n])
+    if (precision == 1) {
+        rc = augcl_enc_nchw_f32_to_nhwc_bf16(grad_out, dz_a, B, hs[n_layers], wsz[n_layers], stream);
+        if (rc != AUGCL_OK) return rc;
+        dz = dz_a;
+    }
+    void *nxt = (dz == dz_a) ? dz_b : dz_a;
+    for (int i = n_layers - 1; i >= 1; --i) {
+        if (precision == 0)
+            rc = augcl_enc_conv32_backward_weights((const float *)acts_in[i], (const float *)dz, dw[i], db[i], ws32, ws32_bytes, B,
+                                                   hs[i], wsz[i], stream);
+        else if (bf16_wgrad_mfma)
+            rc = augcl_enc_bf16_conv32_backward_weights_mfma(acts_in[i], dz, dw[i], db[i], ws32, ws32_bytes, B, hs[i], wsz[i],
+                                                             stream);
+        else
+            rc = augcl_enc_bf16_conv32_backward_weights(acts_in[i], dz, dw[i], db[i], ws32, ws32_bytes, B, hs[i], wsz[i], stream);
+        if (rc != AUGCL_OK) return rc;
+        if (precision == 0)
+            rc = augcl_enc_conv32_backward_data((const float *)dz, w[i], (const float *)acts_in[i], (float *)nxt, B, hs[i + 1],
+                                                wsz[i + 1], stream);
+        else
+            rc = augcl_enc_bf16_conv32_backward_data(dz, w[i], acts_in[i], nxt, B, hs[i + 1], wsz[i + 1], stream);
+        if (rc != AUGCL_OK) return rc;
+        dz = nxt;
+        nxt = (nxt == dz_a) ? dz_b : dz_a;
+    }
+    if (precision == 0)
+        rc = augcl_enc_conv_first_backward_weights((const float *)acts_in[0], (const float *)dz, dw[0], db[0], ws_first,
+                                                   ws_first_bytes, B, C, H, W, first_stride, scale, stream);
+    else
+        rc = augcl_enc_bf16_conv_first_backward_weights((const float *)acts_in[0], dz, dw[0], db[0], ws_first, ws_first_bytes, B,
+                                                        C, H, W, first_stride, scale, stream);
+    return rc;
+}
+
+} // extern "C"

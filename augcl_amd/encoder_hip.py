@@ -21,7 +21,7 @@ def _out_hw(h, stride):
     return (h - 3) // stride + 1
 
 
-class ConvStackFn(torch.autograd.Function):
+class ConvStackLayerwiseFn(torch.autograd.Function):  # per-layer calls: HeadCNN stacks (relu_first) only
     @staticmethod
     def forward(ctx, x, first_stride, input_scale, relu_first, n_layers, *wb):
         weights, biases = wb[:n_layers], wb[n_layers:]
@@ -98,74 +98,75 @@ class ConvStackFn(torch.autograd.Function):
         return (dx, None, None, None, None, *dws, *dbs)
 
 
-class ConvStackBf16Fn(torch.autograd.Function):
-    """bf16 PERFORMANCE MODE of the same stack (augcl_enc_bf16_*): activations bf16 NHWC in HBM, bf16 MFMA with
-    f32 accumulation, f32 master weights and f32 weight gradients.  Not the parity path (bf16 resolution)."""
+# backward-weights of the bf16 mode: "…_mfma" = bf16 MFMA with transposed LDS reads (37 us / layer); the other entry
+# point keeps the f32 MFMA pipe with bf16 inputs widened while staging (59 us).  Switchable for A/B timing.
+_BF16_WGRAD = "augcl_enc_bf16_conv32_backward_weights_mfma"
+
+
+def _ptr_array(ptrs):
+    return (_lib.ctypes.c_void_p * len(ptrs))(*ptrs)
+
+
+class ConvStackFn(torch.autograd.Function):
+    """The SharedCNN stack through the whole-stack C entry points: ONE FFI call per forward, one per backward, one
+    activation arena per pass.  precision "f32" = parity path (f32 NCHW activations, f32 MFMA), "bf16" = performance
+    mode (bf16 NHWC activations, bf16 MFMA, f32 accumulation / master weights / weight gradients)."""
 
     @staticmethod
-    def forward(ctx, x, first_stride, input_scale, relu_first, n_layers, *wb):
-        weights, biases = wb[:n_layers], wb[n_layers:]
-        assert not relu_first, "bf16 mode covers the SharedCNN stack (image input)"
+    def forward(ctx, x, first_stride, input_scale, precision, n_layers, *wb):
+        weights = [t.detach() for t in wb[:n_layers]]
+        biases = [t.detach() for t in wb[n_layers:]]
         assert x.dtype == torch.float32 and x.is_contiguous()
         B, C, H, W = x.shape
         dev = x.device
-        st = _lib.current_stream(dev)
-        call, p = _lib.call, _lib.ptr
+        bf16 = precision == "bf16"
+        adt = torch.bfloat16 if bf16 else torch.float32
+        hs = [_out_hw(H, first_stride)]
+        wsz = [_out_hw(W, first_stride)]
+        for _ in range(1, n_layers):
+            hs.append(hs[-1] - 2)
+            wsz.append(wsz[-1] - 2)
+        numel = [B * 32 * h * w_ for h, w_ in zip(hs, wsz)]
         need_grad = any(t.requires_grad for t in wb)
-        acts = [x]
-        h, w_ = _out_hw(H, first_stride), _out_hw(W, first_stride)
-        w0, b0 = weights[0].detach(), biases[0].detach()
-        cur = torch.empty((B, h, w_, 32), dtype=torch.bfloat16, device=dev)
-        call("augcl_enc_bf16_conv_first_forward", p(x), p(w0), p(b0), p(cur), B, C, H, W, first_stride, input_scale,
-             1 if n_layers > 1 else 0, st)
-        for i in range(1, n_layers):
-            wi, bi = weights[i].detach(), biases[i].detach()
-            last = i == n_layers - 1
-            ho, wo = h - 2, w_ - 2
-            out = (torch.empty((B, 32, ho, wo), dtype=torch.float32, device=dev) if last
-                   else torch.empty((B, ho, wo, 32), dtype=torch.bfloat16, device=dev))
-            call("augcl_enc_bf16_conv32_forward", p(cur), p(wi), p(bi), p(out), B, h, w_, 0 if last else 1,
-                 1 if last else 0, st)
-            if need_grad:
-                acts.append(cur)
-            cur, h, w_ = out, ho, wo
-        if n_layers == 1:
-            raise NotImplementedError("bf16 mode needs at least two conv layers")
+        out = torch.empty((B, 32, hs[-1], wsz[-1]), dtype=torch.float32, device=dev)
+        al = 8  # elements: keeps every slice 16-byte aligned in both element types
+        if need_grad:  # one arena holds every intermediate activation
+            offs, tot = [], 0
+            for n in numel[:-1]:
+                offs.append(tot)
+                tot += (n + al - 1) // al * al
+            arena = torch.empty(max(tot, al), dtype=adt, device=dev)
+            ptrs = [arena.data_ptr() + o * arena.element_size() for o in offs]
+        else:  # two ping-pong buffers
+            big = (max(numel[:-1], default=al) + al - 1) // al * al
+            arena = torch.empty(2 * big, dtype=adt, device=dev)
+            ptrs = [arena.data_ptr() + (i & 1) * big * arena.element_size() for i in range(n_layers - 1)]
+        ptrs.append(out.data_ptr())
+        _lib.call("augcl_enc_stack_forward", x.data_ptr(), _ptr_array([t.data_ptr() for t in weights]),
+                  _ptr_array([t.data_ptr() for t in biases]), _ptr_array(ptrs), n_layers, B, C, H, W, first_stride,
+                  input_scale, 1 if bf16 else 0, _lib.current_stream(dev))
         if need_grad:
-            ctx.save_for_backward(*acts, *[t.detach() for t in weights])
-            ctx.meta = (first_stride, input_scale, n_layers)
-        return cur
+            ctx.save_for_backward(x, arena, *weights)
+            ctx.meta = (first_stride, input_scale, precision, n_layers, ptrs[:-1], max(numel))
+        return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        first_stride, input_scale, n_layers = ctx.meta
-        saved = ctx.saved_tensors
-        acts, weights = saved[:n_layers], saved[n_layers:]  # acts[0] = x (f32 NCHW), acts[i>0] = a_i (bf16 NHWC)
-        x = acts[0]
-        B = x.shape[0]
-        dev = grad_out.device
-        st = _lib.current_stream(dev)
-        call, p = _lib.call, _lib.ptr
+        first_stride, input_scale, precision, n_layers, act_ptrs, max_numel = ctx.meta
+        x, arena = ctx.saved_tensors[:2]
+        weights = ctx.saved_tensors[2:]
+        B, C, H, W = x.shape
+        dev = x.device
+        bf16 = precision == "bf16"
         g = grad_out.contiguous()
-        dz = torch.empty((B, g.shape[2], g.shape[3], 32), dtype=torch.bfloat16, device=dev)
-        call("augcl_enc_nchw_f32_to_nhwc_bf16", p(g), p(dz), B, g.shape[2], g.shape[3], st)
-        dws, dbs = [None] * n_layers, [None] * n_layers
-        ws32 = _workspace(dev, 32)
-        for i in range(n_layers - 1, 0, -1):
-            a_prev, wi = acts[i], weights[i]  # (B,Hi,Wi,32) bf16
-            dw = torch.empty_like(wi)
-            db = torch.empty(32, dtype=torch.float32, device=dev)
-            call("augcl_enc_bf16_conv32_backward_weights", p(a_prev), p(dz), p(dw), p(db), p(ws32), ws32.numel() * 4, B,
-                 a_prev.shape[1], a_prev.shape[2], st)
-            dws[i], dbs[i] = dw, db
-            dact = torch.empty_like(a_prev)
-            call("augcl_enc_bf16_conv32_backward_data", p(dz), p(wi), p(a_prev), p(dact), B, dz.shape[1], dz.shape[2], st)
-            dz = dact
-        w0 = weights[0]
-        dw = torch.empty_like(w0)
-        db = torch.empty(32, dtype=torch.float32, device=dev)
-        ws = _workspace(dev, w0.shape[1])
-        call("augcl_enc_bf16_conv_first_backward_weights", p(x), p(dz), p(dw), p(db), p(ws), ws.numel() * 4, B, w0.shape[1],
-             x.shape[2], x.shape[3], first_stride, input_scale, st)
-        dws[0], dbs[0] = dw, db
-        return (None, None, None, None, None, *dws, *dbs)
+        dws = [torch.empty_like(w) for w in weights]
+        dbs = torch.empty((n_layers, 32), dtype=torch.float32, device=dev)
+        dz = torch.empty(2 * ((max_numel + 7) // 8 * 8), dtype=torch.bfloat16 if bf16 else torch.float32, device=dev)
+        half = dz.numel() // 2 * dz.element_size()
+        ws32, wsf = _workspace(dev, 32), _workspace(dev, C)
+        _lib.call("augcl_enc_stack_backward", _ptr_array([x.data_ptr()] + list(act_ptrs)),
+                  _ptr_array([w.data_ptr() for w in weights]), g.data_ptr(), _ptr_array([t.data_ptr() for t in dws]),
+                  _ptr_array([dbs[i].data_ptr() for i in range(n_layers)]), dz.data_ptr(), dz.data_ptr() + half,
+                  ws32.data_ptr(), ws32.numel() * 4, wsf.data_ptr(), wsf.numel() * 4, n_layers, B, C, H, W, first_stride,
+                  input_scale, 1 if bf16 else 0, 1 if _BF16_WGRAD.endswith("_mfma") else 0, _lib.current_stream(dev))
+        return (None, None, None, None, None, *dws, *[dbs[i] for i in range(n_layers)])

@@ -47,7 +47,10 @@ def conv_stack(x, weights, biases, first_stride=2, input_scale=255.0, relu_first
         return _conv_stack_torch(x, weights, biases, first_stride, input_scale, relu_first)
     _lib.require_cuda(x, "conv_stack input")
     from . import encoder_hip
-    if PRECISION == "bf16" and not relu_first and len(weights) > 1 and weights[0].shape[0] == 32:
-        return encoder_hip.ConvStackBf16Fn.apply(x, first_stride, float(input_scale), False, len(weights), *weights, *biases)
-    return encoder_hip.ConvStackFn.apply(x, first_stride, float(input_scale), bool(relu_first), len(weights),
-                                         *weights, *biases)
+    if relu_first:  # HeadCNN stacks (num_head_layers > 0): per-layer path, f32
+        return encoder_hip.ConvStackLayerwiseFn.apply(x, first_stride, float(input_scale), True, len(weights), *weights,
+                                                      *biases)
+    for w in weights:
+        assert w.shape[0] == 32 and w.is_contiguous(), "encoder kernels are built for 32 contiguous filters"
+    precision = PRECISION if len(weights) > 1 else "f32"
+    return encoder_hip.ConvStackFn.apply(x, first_stride, float(input_scale), precision, len(weights), *weights, *biases)

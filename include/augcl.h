@@ -164,10 +164,27 @@ int augcl_enc_bf16_conv32_backward_data(const void *dz_bf16_nhwc, const float *w
 int augcl_enc_bf16_conv32_backward_weights(const void *act_prev_bf16_nhwc, const void *dz_bf16_nhwc, float *dw, float *db,
                                            float *workspace, size_t workspace_bytes, int B, int Hi, int Wi,
                                            augcl_stream_t stream);
+/* same result on the bf16 MFMA pipe (transposed LDS reads supply the pixel-major operands): 8x fewer MFMAs */
+int augcl_enc_bf16_conv32_backward_weights_mfma(const void *act_prev_bf16_nhwc, const void *dz_bf16_nhwc, float *dw,
+                                                float *db, float *workspace, size_t workspace_bytes, int B, int Hi,
+                                                int Wi, augcl_stream_t stream);
 int augcl_enc_bf16_conv_first_backward_weights(const float *x /* f32 raw */, const void *dz_bf16_nhwc, float *dw, float *db,
                                                float *workspace, size_t workspace_bytes, int B, int C, int Hi, int Wi,
                                                int stride, float scale, augcl_stream_t stream);
 int augcl_enc_nchw_f32_to_nhwc_bf16(const float *in, void *out_bf16_nhwc, int B, int H, int W, augcl_stream_t stream);
+
+/* ---- whole-stack entry points: every layer of the encoder forward / backward behind ONE call (the host pays one
+ * FFI crossing per pass).  precision 0 = f32 NCHW (parity path), 1 = bf16 NHWC (performance mode).
+ * forward: acts_out[i] = output buffer of layer i (the last layer always writes f32 NCHW).
+ * backward: acts_in[i] = input of layer i (acts_in[0] = the raw f32 image batch); dz_a / dz_b = two scratch buffers
+ * of the largest activation's size; dw[i] / db[i] receive the weight / bias gradients. */
+int augcl_enc_stack_forward(const float *x, const float *const *w, const float *const *b, void *const *acts_out,
+                            int n_layers, int B, int C, int H, int W, int first_stride, float scale, int precision,
+                            augcl_stream_t stream);
+int augcl_enc_stack_backward(const void *const *acts_in, const float *const *w, const float *grad_out, float *const *dw,
+                             float *const *db, void *dz_a, void *dz_b, float *ws32, size_t ws32_bytes, float *ws_first,
+                             size_t ws_first_bytes, int n_layers, int B, int C, int H, int W, int first_stride,
+                             float scale, int precision, int bf16_wgrad_mfma, augcl_stream_t stream);
 
 /* ---- device-resident replay sampling: ReplayBuffer.sample -> tensor_buffer_samples / _encode_obses /
  * LazyFrames._force (src/utils.py:206-214, 234-240, 272-280, 293-299).  `frames` is a uint8 ring of RGB frames
