@@ -138,7 +138,16 @@ class SAC(object):
             feat = self.actor.encoder.features(obs)
         same_cnn = critic.encoder.shared_cnn is self.actor.encoder.shared_cnn
         _, pi, log_pi, log_std = self.actor(obs, detach=True, features=feat)
-        actor_Q1, actor_Q2 = critic(obs, pi, detach=True, features=feat if same_cnn else None)
+        # the critic only relays d(loss)/d(pi) here: its own weight gradients (which the reference computes and then
+        # discards at the next critic zero_grad) are not built
+        cparams = [p for p in critic.parameters() if p.requires_grad]
+        for p in cparams:
+            p.requires_grad_(False)
+        try:
+            actor_Q1, actor_Q2 = critic(obs, pi, detach=True, features=feat if same_cnn else None)
+        finally:
+            for p in cparams:
+                p.requires_grad_(True)
         actor_Q = torch.min(actor_Q1, actor_Q2)
         actor_loss = (self.alpha.detach() * log_pi - actor_Q).mean()
         if L is not None:

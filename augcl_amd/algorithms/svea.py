@@ -12,16 +12,24 @@ class SVEA(RAD):
         self.svea_alpha = args.svea_alpha
         self.svea_beta = args.svea_beta
 
-    def update_critic(self, obs, action, reward, next_obs, not_done, L=None, step=None, obs_aug=None):
+    def update_critic(self, obs, action, reward, next_obs, not_done, L=None, step=None, obs_aug=None, obs_both=None):
+        """svea.py:15-64.  The reference runs the critic twice (shifted batch, augmented batch) and adds the two
+        weighted losses; here both halves go through the critic as ONE 2B batch -- every per-sample quantity is
+        unchanged (no batch statistics anywhere on this path: LayerNorm is per sample), each half's MSE mean is taken
+        over its own B rows, and the network sees half as many, larger launches."""
         target_Q = self.calculate_target_Q(next_obs=next_obs, reward=reward, not_done=not_done)
-        current_Q1, current_Q2 = self.critic(obs, action)
-        critic_loss_shift = self.svea_alpha * self._q_loss(current_Q1, current_Q2, target_Q)
-        if obs_aug is None:
-            # apply_aug never writes its input except color_jitter (in place, like the reference's):
-            # only then is the reference's obs.clone() needed to keep `obs` intact for the actor update
-            obs_aug = self.apply_aug(obs.clone() if self._aug_mutates() else obs)
-        current_Q1_aug, current_Q2_aug = self.critic(obs_aug, action)
-        critic_loss_aug = self.svea_beta * self._q_loss(current_Q1_aug, current_Q2_aug, target_Q)
+        B = obs.shape[0]
+        if obs_both is None:
+            if obs_aug is None:
+                # apply_aug never writes its input except color_jitter (in place, like the reference's):
+                # only then is the reference's obs.clone() needed to keep `obs` intact for the actor update
+                obs_aug = self.apply_aug(obs.clone() if self._aug_mutates() else obs)
+            obs_both = torch.cat([obs, obs_aug], dim=0)
+        q1, q2 = self.critic(obs_both, torch.cat([action, action], dim=0))
+        y2 = torch.cat([target_Q, target_Q], dim=0)
+        se = (q1 - y2).square() + (q2 - y2).square()  # per-sample (Q1-y)^2 + (Q2-y)^2
+        critic_loss_shift = self.svea_alpha * se[:B].mean()  # = alpha * (mse(Q1,y) + mse(Q2,y)) on the shifted half
+        critic_loss_aug = self.svea_beta * se[B:].mean()
         critic_loss = critic_loss_shift + critic_loss_aug
         if L is not None:
             self._log(L, "train_critic/shift_loss", critic_loss_shift, step)
@@ -33,13 +41,15 @@ class SVEA(RAD):
 
     def update(self, replay_buffer, L, step):
         obs, action, reward, next_obs, not_done = replay_buffer.sample()
-        obs_aug = None
+        obs_both = None
         if self._fused_front_end(obs):
-            # one pass over the (uint8 or f32) batch: random_shift AND random_conv(random_shift) together
-            obs, obs_aug = augmentations.shift_conv(obs)
+            # one pass over the (uint8 or f32) batch: random_shift AND random_conv(random_shift) together, written
+            # as the two halves of one (2B,C,H,W) buffer so the critic consumes them without a concatenation copy
+            obs_both = augmentations.shift_conv(obs, stacked=True)
+            obs = obs_both[:obs.shape[0]]
         else:
             obs = augmentations.random_shift(obs)
-        self.update_critic(obs, action, reward, next_obs, not_done, L, step, obs_aug=obs_aug)
+        self.update_critic(obs, action, reward, next_obs, not_done, L, step, obs_both=obs_both)
         if step % self.actor_update_freq == 0:
             self.update_actor_and_alpha(obs, L, step)
         if step % self.critic_target_update_freq == 0:

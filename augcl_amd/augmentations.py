@@ -109,9 +109,10 @@ def random_conv(x, *, weights=None, out=None):
     return out
 
 
-def shift_conv(obs, pad=4, *, oy=None, ox=None, weights=None, want_shift=True, want_aug=True):
+def shift_conv(obs, pad=4, *, oy=None, ox=None, weights=None, want_shift=True, want_aug=True, stacked=False):
     """Fused SVEA/AugCL front end (src/algorithms/svea.py:68 + :49): one pass over the (uint8 or
-    f32) observation producing random_shift(obs) and random_conv(random_shift(obs))."""
+    f32) observation producing random_shift(obs) and random_conv(random_shift(obs)).
+    stacked=True returns ONE (2B,C,H,W) tensor: rows [0,B) = shifted, rows [B,2B) = shifted + conv."""
     _check_bchw(obs, "shift_conv")
     B, C, H, W = obs.shape
     oy = _i32(oy, B, obs.device, "oy")
@@ -119,12 +120,16 @@ def shift_conv(obs, pad=4, *, oy=None, ox=None, weights=None, want_shift=True, w
     if weights is not None:
         weights = torch.as_tensor(weights, device=obs.device, dtype=torch.float32).contiguous()
     seed, off, s0 = _next_call()
-    o_s = torch.empty((B, C, H, W), dtype=torch.float32, device=obs.device) if want_shift else None
-    o_a = torch.empty((B, C, H, W), dtype=torch.float32, device=obs.device) if want_aug else None
+    if stacked:
+        both = torch.empty((2 * B, C, H, W), dtype=torch.float32, device=obs.device)
+        o_s, o_a = both[:B], both[B:]
+    else:
+        o_s = torch.empty((B, C, H, W), dtype=torch.float32, device=obs.device) if want_shift else None
+        o_a = torch.empty((B, C, H, W), dtype=torch.float32, device=obs.device) if want_aug else None
     fn = {torch.uint8: "augcl_shift_conv_u8_f32", torch.float32: "augcl_shift_conv_f32"}[obs.dtype]
     _lib.call(fn, _lib.ptr(obs), _lib.ptr(o_s), _lib.ptr(o_a), B, C // 3, H, W, int(pad), _lib.ptr(oy), _lib.ptr(ox),
               _lib.ptr(weights), seed, off, s0, _lib.current_stream(obs.device))
-    return o_s, o_a
+    return both if stacked else (o_s, o_a)
 
 
 # overlay image source: the reference streams COCO / Places365 through a 16-worker DataLoader

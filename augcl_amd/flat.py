@@ -34,7 +34,7 @@ class FlatGroup:
             a, b = self.slices[n]
             self.param[a:b].copy_(p.data.reshape(-1))
             p.data = self.param[a:b].view(self.shapes[n])
-            p.grad = self.grad[a:b].view(self.shapes[n])
+            p.grad = None
             self.params.append(p)
 
     def rebind(self):
@@ -44,7 +44,24 @@ class FlatGroup:
             if p.data.data_ptr() != self.param[a:b].data_ptr():
                 self.param[a:b].copy_(p.data.reshape(-1))
                 p.data = self.param[a:b].view(self.shapes[n])
-            p.grad = self.grad[a:b].view(self.shapes[n])
+
+    def gather_grads(self):
+        """Copy the parameters' autograd gradients into the flat bucket (one multi-tensor launch)."""
+        g = self
+        views, grads, missing = [], [], False
+        for n, p in zip(g.names, g.params):
+            if p.grad is None:
+                missing = True
+                continue
+            a, b = g.slices[n]
+            if p.grad.data_ptr() == g.grad[a:b].data_ptr():
+                continue  # already in the bucket
+            views.append(g.grad[a:b].view(g.shapes[n]))
+            grads.append(p.grad)
+        if missing:
+            g.grad.zero_()  # a parameter that received no gradient contributes zero (torch.optim.Adam skips it)
+        if grads:
+            torch._foreach_copy_(views, grads)
 
     def segment(self, prefix):
         """[begin, end) of the contiguous run of tensors whose name starts with prefix."""
@@ -57,7 +74,11 @@ class FlatGroup:
 
 class FlatAdam:
     """torch.optim.Adam(params, lr, betas=(beta1, 0.999)) over a FlatGroup, one HIP launch per step.
-    zero_grad() zeroes the flat gradient buffer (grads stay allocated views: set_to_none=False)."""
+
+    Gradients: zero_grad() drops the parameters' .grad (set_to_none), so autograd hands every parameter a fresh
+    gradient tensor without an accumulate kernel; step() gathers them into the flat gradient bucket with one
+    multi-tensor copy (the bucket is what the data-parallel all-reduce and the fused Adam kernel consume).
+    Pre-assigned .grad views would cost one `grad += new` launch per parameter per backward (~40 per step)."""
 
     def __init__(self, group, lr, betas=(0.9, 0.999), eps=1e-8, reducer=None):
         self.group, self.lr, self.betas, self.eps = group, float(lr), (float(betas[0]), float(betas[1])), float(eps)
@@ -66,15 +87,13 @@ class FlatAdam:
         self.step_count = 0
         self.reducer = reducer  # data-parallel gradient exchange (dist.GradReducer) or None
 
-    def zero_grad(self, set_to_none=False):
-        self.group.grad.zero_()
-        for p in self.group.params:  # autograd may have replaced a .grad it found undefined
-            if p.grad is None or p.grad.data_ptr() == 0:
-                self.group.rebind()
-                break
+    def zero_grad(self, set_to_none=True):
+        for p in self.group.params:
+            p.grad = None
 
     def step(self):
         g = self.group
+        g.gather_grads()
         scale = 1.0
         if self.reducer is not None:
             scale = self.reducer.allreduce_sum_(g.grad)  # returns 1/world_size

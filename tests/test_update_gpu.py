@@ -131,7 +131,7 @@ def test_adam_and_ema_kernels_match_torch(cuda):
         ref.grad = g.clone()
         opt.step()
         fopt.zero_grad()
-        par.grad.copy_(g.to(cuda))
+        par.grad = g.to(cuda)
         fopt.step()
     torch.cuda.synchronize()
     np.testing.assert_allclose(par.detach().cpu().numpy(), ref.detach().numpy(), rtol=2e-6, atol=2e-8)
