@@ -41,12 +41,8 @@ class AugCL(RAD):
         if L is not None:
             self._log(L, "train_critic_weak/loss", critic_loss_shift, step)
             self._log(L, "train_critic_strong/loss", critic_loss_aug, step)
-        self.critic_weak_optimizer.zero_grad()
-        critic_loss_shift.backward()
-        self.critic_weak_optimizer.step()
-        self.critic_optimizer.zero_grad()
-        critic_loss_aug.backward()
-        self.critic_optimizer.step()
+        self.critic_weak_optimizer.backward_step(critic_loss_shift)  # zero_grad / backward / step (augcl.py:50-52)
+        self.critic_optimizer.backward_step(critic_loss_aug)         # (augcl.py:54-56)
 
     def soft_update_critic_target(self):
         self._soft_update_from(self._weak_group)  # the target tracks the weak critic (augcl.py:58-67)

@@ -34,9 +34,7 @@ class DrQ(SAC):
             self._log(L, f"train_critic/target_Q_variance_m={self.m}", var(targets), step)
             self._log(L, f"train_critic/Q1_variance_k={self.k}", var(q1s), step)
             self._log(L, f"train_critic/Q2_variance_k={self.k}", var(q2s), step)
-        self.critic_optimizer.zero_grad()
-        critic_loss.backward()
-        self.critic_optimizer.step()
+        self.critic_optimizer.backward_step(critic_loss)  # zero_grad / backward / step
 
     def update(self, replay_buffer, L, step):
         obs, action, reward, next_obs, not_done = replay_buffer.sample()

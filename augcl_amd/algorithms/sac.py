@@ -126,9 +126,7 @@ class SAC(object):
         current_Q1, current_Q2 = self.critic(obs, action)
         critic_loss = self._q_loss(current_Q1, current_Q2, target_Q)
         self._log(L, "train_critic/loss", critic_loss, step)
-        self.critic_optimizer.zero_grad()
-        critic_loss.backward()
-        self.critic_optimizer.step()
+        self.critic_optimizer.backward_step(critic_loss)  # zero_grad / backward / step (sac.py:115-117)
 
     def update_actor_and_alpha(self, obs, L=None, step=None, update_alpha=True, critic=None):
         """sac.py:119-146.  The actor's and the critic's encoders share the CNN and see the same obs
@@ -138,25 +136,16 @@ class SAC(object):
             feat = self.actor.encoder.features(obs)
         same_cnn = critic.encoder.shared_cnn is self.actor.encoder.shared_cnn
         _, pi, log_pi, log_std = self.actor(obs, detach=True, features=feat)
-        # the critic only relays d(loss)/d(pi) here: its own weight gradients (which the reference computes and then
-        # discards at the next critic zero_grad) are not built
-        cparams = [p for p in critic.parameters() if p.requires_grad]
-        for p in cparams:
-            p.requires_grad_(False)
-        try:
-            actor_Q1, actor_Q2 = critic(obs, pi, detach=True, features=feat if same_cnn else None)
-        finally:
-            for p in cparams:
-                p.requires_grad_(True)
+        actor_Q1, actor_Q2 = critic(obs, pi, detach=True, features=feat if same_cnn else None)
         actor_Q = torch.min(actor_Q1, actor_Q2)
         actor_loss = (self.alpha.detach() * log_pi - actor_Q).mean()
         if L is not None:
             entropy = 0.5 * log_std.shape[1] * (1.0 + np.log(2 * np.pi)) + log_std.sum(dim=-1)
             self._log(L, "train_actor/loss", actor_loss, step)
             self._log(L, "train_actor/mean_entropy", entropy.mean(), step)
-        self.actor_optimizer.zero_grad()
-        actor_loss.backward()
-        self.actor_optimizer.step()
+        # zero_grad / backward / step (sac.py:133-135); the critic's own weight gradients, which the reference
+        # computes here and discards at the next critic zero_grad, are never built
+        self.actor_optimizer.backward_step(actor_loss)
         if update_alpha:
             self.log_alpha_optimizer.zero_grad()
             alpha_loss = (self.alpha * (-log_pi - self.target_entropy).detach()).mean()

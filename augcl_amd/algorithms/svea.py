@@ -35,9 +35,7 @@ class SVEA(RAD):
             self._log(L, "train_critic/shift_loss", critic_loss_shift, step)
             self._log(L, "train_critic/aug_loss", critic_loss_aug, step)
             self._log(L, "train_critic/loss", critic_loss, step)
-        self.critic_optimizer.zero_grad()
-        critic_loss.backward()
-        self.critic_optimizer.step()
+        self.critic_optimizer.backward_step(critic_loss)  # zero_grad / backward / step
 
     def update(self, replay_buffer, L, step):
         obs, action, reward, next_obs, not_done = replay_buffer.sample()

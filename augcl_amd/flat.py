@@ -91,9 +91,24 @@ class FlatAdam:
         for p in self.group.params:
             p.grad = None
 
-    def step(self):
+    def backward_step(self, loss):
+        """zero_grad(); loss.backward(); step() of the reference in one go: gradients are taken ONLY with respect to
+        this group's parameters (torch.autograd.grad prunes every other weight-gradient branch, e.g. the critic's
+        weights inside the actor loss, sac.py:119-133) and land in the flat bucket by one multi-tensor copy."""
         g = self.group
-        g.gather_grads()
+        grads = torch.autograd.grad(loss, g.params, allow_unused=True)
+        if any(t is None for t in grads):
+            g.grad.zero_()
+        views = [g.grad[g.slices[n][0]:g.slices[n][1]].view(g.shapes[n]) for n, t in zip(g.names, grads) if t is not None]
+        torch._foreach_copy_(views, [t for t in grads if t is not None])
+        self._apply()
+
+    def step(self):
+        self.group.gather_grads()
+        self._apply()
+
+    def _apply(self):
+        g = self.group
         scale = 1.0
         if self.reducer is not None:
             scale = self.reducer.allreduce_sum_(g.grad)  # returns 1/world_size
