@@ -2,7 +2,8 @@
 
 Same names, argument meaning and return conventions as the reference:
 
-    aug_to_func["shift" | "conv" | "overlay" | "color_jitter" | "identity"](x, **params)
+    aug_to_func["shift" | "conv" | "overlay" | "color_jitter" | "identity" |
+                "crop" | "flip" | "rotate" | "cutout_color" | "grayscale"](x, **params)
 
 x is a contiguous (B, C, H, W) float32 tensor holding 0..255 values on the GPU
 (what `ReplayBuffer.sample()` returns, src/utils.py:206-214); a uint8 tensor is also
@@ -220,7 +221,154 @@ def color_jitter(imgs, p=1, *, idx=None, order=None, contrast=None, saturation=N
     return imgs.view(b, c, h, w)
 
 
+# ---------------------------------------------------------------- rest of the registry (index / select operators)
+_AFFINE = {0: (1, 0, 0, 0, 1, 0), 1: (0, 1, 0, -1, 0, -1), 2: (-1, 0, -2, 0, -1, -1), 3: (0, -1, -2, 1, 0, 0),
+           4: (1, 0, 0, 0, -1, -1)}  # -1 -> W-1, -2 -> H-1 (filled in per call)
+
+
+def _affine_gather(x, coef, Hout, Wout, name):
+    _check_bchw(x, name)
+    if x.dtype != torch.float32:
+        raise TypeError(f"{name}: float32 input expected")
+    B, C, H, W = x.shape
+    x = x.contiguous()
+    coef = np.ascontiguousarray(coef, dtype=np.int32).reshape(B, 6)
+    # every source index the map can produce must be inside the frame (corners suffice: the map is affine)
+    for ys, xs in ((0, 0), (Hout - 1, 0), (0, Wout - 1), (Hout - 1, Wout - 1)):
+        sy = coef[:, 0] * ys + coef[:, 1] * xs + coef[:, 2]
+        sx = coef[:, 3] * ys + coef[:, 4] * xs + coef[:, 5]
+        if B and (sy.min() < 0 or sy.max() >= H or sx.min() < 0 or sx.max() >= W):
+            raise ValueError(f"{name}: source window leaves the {H}x{W} frame")
+    coef_t = torch.from_numpy(coef).to(x.device, non_blocking=True)
+    out = torch.empty((B, C, Hout, Wout), dtype=torch.float32, device=x.device)
+    _lib.call("augcl_affine_gather_f32", _lib.ptr(x), _lib.ptr(out), B, C, H, W, Hout, Wout, _lib.ptr(coef_t),
+              _lib.current_stream(x.device))
+    return out
+
+
+def _kind_coef(kind, H, W):
+    rows = np.array([_AFFINE[int(k)] for k in kind], dtype=np.int32).reshape(-1, 6)
+    fix = np.where(rows[:, [2, 5]] == -1, W - 1, np.where(rows[:, [2, 5]] == -2, H - 1, rows[:, [2, 5]]))
+    rows[:, [2, 5]] = fix
+    return rows
+
+
+def random_crop(x, size=84, w1=None, h1=None, return_w1_h1=False):
+    """src/augmentations.py:385-414: out[i,c,y,x] = x[i,c,w1[i]+y,h1[i]+x]; w1,h1 ~ LongTensor(n).random_(0, crop_max)
+    on torch's default CPU generator (upper bound exclusive, as in the reference), or given."""
+    assert (w1 is None and h1 is None) or (w1 is not None and h1 is not None), \
+        "must either specify both w1 and h1 or neither of them"
+    _check_bchw(x, "random_crop")
+    n = x.shape[0]
+    crop_max = x.shape[-1] - size
+    if crop_max <= 0:
+        return (x, None, None) if return_w1_h1 else x
+    if w1 is None:
+        w1 = torch.LongTensor(n).random_(0, crop_max)
+        h1 = torch.LongTensor(n).random_(0, crop_max)
+    w1n = torch.as_tensor(w1).cpu().numpy().astype(np.int32).reshape(n)
+    h1n = torch.as_tensor(h1).cpu().numpy().astype(np.int32).reshape(n)
+    coef = np.tile(np.array([1, 0, 0, 0, 1, 0], np.int32), (n, 1))
+    coef[:, 2], coef[:, 5] = w1n, h1n
+    cropped = _affine_gather(x, coef, size, size, "random_crop")
+    return (cropped, w1, h1) if return_w1_h1 else cropped
+
+
+def random_flip(images, p=0.2, *, mask=None):
+    """src/augmentations.py:139-168: horizontal flip of the samples with np.random.uniform <= p."""
+    _check_bchw(images, "random_flip")
+    B, _, H, W = images.shape
+    if mask is None:
+        mask = np.random.uniform(0.0, 1.0, size=(B,)) <= p
+    kind = np.where(np.asarray(mask, bool).reshape(B), 4, 0)
+    return _affine_gather(images, _kind_coef(kind, H, W), H, W, "random_flip")
+
+
+def random_rotation(images, p=0.3, *, rot=None):
+    """src/augmentations.py:171-213: with probability p a sample is turned by randint(1,4) quarter turns
+    (torch.rot90 over the two spatial dims); rot (ints in 0..3) overrides the draw."""
+    _check_bchw(images, "random_rotation")
+    B, _, H, W = images.shape
+    if H != W:
+        raise ValueError("random_rotation: square frames expected")
+    if rot is None:
+        rnd = np.random.uniform(0.0, 1.0, size=(B,))
+        rnd_rot = np.random.randint(1, 4, size=(B,))
+        rot = rnd_rot * (rnd <= p)
+    rot = np.asarray(rot).reshape(B)
+    if B and (rot.min() < 0 or rot.max() > 3):
+        raise ValueError("random_rotation: rot must be in 0..3")
+    return _affine_gather(images, _kind_coef(rot, H, W), H, W, "random_rotation")
+
+
+def random_cutout_color(imgs, min_cut=10, max_cut=30, *, w1=None, h1=None, color=None):
+    """src/augmentations.py:327-350: rows h1..2*h1-1, cols w1..2*w1-1 of every channel take a per-(sample,channel)
+    colour randint(0,255)/255.  The reference computes this in numpy and returns a HOST tensor; this one stays on
+    the device (its callers move the result there anyway)."""
+    _check_bchw(imgs, "random_cutout_color")
+    if imgs.dtype != torch.float32:
+        raise TypeError("random_cutout_color: float32 input expected")
+    n, c, h, w = imgs.shape
+    if w1 is None:
+        w1 = np.random.randint(min_cut, max_cut, n)
+    if h1 is None:
+        h1 = np.random.randint(min_cut, max_cut, n)
+    if color is None:
+        color = np.random.randint(0, 255, size=(n, c)) / 255.0
+    box = np.stack([np.asarray(h1).reshape(n), np.asarray(w1).reshape(n)], axis=1).astype(np.int32)
+    if n and box.min() < 0:
+        raise ValueError("random_cutout_color: negative box origin")
+    color = np.ascontiguousarray(color, dtype=np.float32).reshape(n, c)
+    imgs = imgs.detach().contiguous()
+    box_t = torch.from_numpy(np.ascontiguousarray(box)).to(imgs.device, non_blocking=True)
+    col_t = torch.from_numpy(color).to(imgs.device, non_blocking=True)
+    out = torch.empty_like(imgs)
+    _lib.call("augcl_cutout_color_f32", _lib.ptr(imgs), _lib.ptr(out), n, c, h, w, _lib.ptr(box_t), _lib.ptr(col_t),
+              _lib.current_stream(imgs.device))
+    return out
+
+
+def random_grayscale(images, p=0.3, *, mask=None):
+    """src/augmentations.py:89-136, literal: t = uint8(images*255) (the cast wraps mod 256 beyond 255, as torch's
+    host cast does), the samples with np.random.uniform <= p take per-frame gray = uint8(.2989r+.587g+.114b);
+    returns t/255.  Written for [0,1] frames; on 0..255 floats the wrap makes it the reference's own garbage."""
+    _check_bchw(images, "random_grayscale")
+    if images.dtype != torch.float32:
+        raise TypeError("random_grayscale: float32 input expected")
+    B, C, H, W = images.shape
+    if C % 3:
+        raise ValueError("random_grayscale: channel count must be a multiple of 3")
+    if mask is None:
+        mask = np.random.uniform(0.0, 1.0, size=(B,)) <= p
+    mask_t = torch.from_numpy(np.ascontiguousarray(np.asarray(mask).reshape(B), dtype=np.uint8)).to(
+        images.device, non_blocking=True)
+    images = images.contiguous()
+    out = torch.empty_like(images)
+    _lib.call("augcl_random_grayscale_f32", _lib.ptr(images), _lib.ptr(out), B, C // 3, H, W, _lib.ptr(mask_t),
+              _lib.current_stream(images.device))
+    return out
+
+
+def _needs_kornia_hsv(name):
+    def fn(*_a, **_k):
+        raise NotImplementedError(
+            f"{name}: depends on kornia.color.rgb_to_hsv thresholds (src/augmentations.py:277-324) whose arithmetic "
+            "cannot be pinned here (kornia absent); not built -- see DESIGN.md")
+    fn.__name__ = name
+    return fn
+
+
+splice = _needs_kornia_hsv("splice")
+CS_splice = _needs_kornia_hsv("CS_splice")
+
 aug_to_func = {
+    "grayscale": random_grayscale,
+    "flip": random_flip,
+    "rotate": random_rotation,
+    "crop": random_crop,
+    "cutout_color": random_cutout_color,
+    "splice": splice,
+    "CS_splice": CS_splice,
     "conv": random_conv,
     "shift": random_shift,
     "color_jitter": color_jitter,

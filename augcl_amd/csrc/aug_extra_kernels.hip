@@ -1,0 +1,115 @@
+// aug_extra_kernels.hip -- the rest of the reference's augmentation registry:
+// random_crop / random_flip / random_rotation (one per-sample integer-affine gather), random_cutout_color,
+// random_grayscale.  All are index / select operators on the pixel grid: HBM-bound, bit-exact.
+#include "augcl_common.h"
+
+namespace augcl {
+
+// out[b,c,y,x] = in[b,c, ay*y + by*x + cy, ax*y + bx*x + cx]   (coef[b] = {ay,by,cy,ax,bx,cx})
+//   crop (oy,ox): {1,0,oy, 0,1,ox};  hflip: {1,0,0, 0,-1,W-1};  rot90: {0,1,0, -1,0,W-1};
+//   rot180: {-1,0,H-1, 0,-1,W-1};  rot270: {0,-1,H-1, 1,0,0};  identity: {1,0,0, 0,1,0}
+__global__ __launch_bounds__(256) void k_affine_gather(const float *__restrict__ in, float *__restrict__ out, int C,
+                                                       int Hin, int Win, int Hout, int Wout,
+                                                       const int32_t *__restrict__ coef)
+{
+    const int plane = blockIdx.y; // b*C + c
+    const int b = plane / C;
+    const int ay = coef[b * 6 + 0], by = coef[b * 6 + 1], cy = coef[b * 6 + 2];
+    const int ax = coef[b * 6 + 3], bx = coef[b * 6 + 4], cx = coef[b * 6 + 5];
+    const float *__restrict__ src = in + (size_t)plane * Hin * Win;
+    float *__restrict__ dst = out + (size_t)plane * Hout * Wout;
+    const int n = Hout * Wout;
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
+        const int y = j / Wout, x = j - y * Wout;
+        int sy = ay * y + by * x + cy, sx = ax * y + bx * x + cx;
+        sy = sy < 0 ? 0 : (sy >= Hin ? Hin - 1 : sy); // host validates the coefficients; stay in bounds regardless
+        sx = sx < 0 ? 0 : (sx >= Win ? Win - 1 : sx);
+        dst[j] = src[sy * Win + sx];
+    }
+}
+
+// random_cutout_color (src/augmentations.py:327-350): box rows h1..2*h1-1, cols w1..2*w1-1 <- colour[b][c]
+__global__ __launch_bounds__(256) void k_cutout_color(const float *__restrict__ in, float *__restrict__ out, int C, int H,
+                                                      int W, const int32_t *__restrict__ box,
+                                                      const float *__restrict__ color)
+{
+    const int plane = blockIdx.y;
+    const int b = plane / C;
+    const int h1 = box[2 * b], w1 = box[2 * b + 1];
+    const float col = color[plane];
+    const int n = H * W;
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
+        const int y = j / W, x = j - y * W;
+        const bool inside = y >= h1 && y < 2 * h1 && x >= w1 && x < 2 * w1;
+        out[(size_t)plane * n + j] = inside ? col : in[(size_t)plane * n + j];
+    }
+}
+
+// random_grayscale (src/augmentations.py:89-136), literal: t = uint8(x*255) (C-style wrap, what torch's CPU cast
+// does), gray = uint8(0.2989 r + 0.587 g + 0.114 b) on t, out = (mask ? gray : t) / 255.
+__device__ __forceinline__ float u8wrap(float v) { return (float)((int)v & 255); }
+
+__global__ __launch_bounds__(256) void k_random_grayscale(const float *__restrict__ in, float *__restrict__ out,
+                                                          int frames, int n /* H*W */, const uint8_t *__restrict__ mask)
+{
+    const int fidx = blockIdx.y; // b*frames + f
+    const int b = fidx / frames;
+    const bool m = mask[b] != 0;
+    const float *__restrict__ src = in + (size_t)fidx * 3 * n;
+    float *__restrict__ dst = out + (size_t)fidx * 3 * n;
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
+        const float r = u8wrap(src[j] * 255.0f), g = u8wrap(src[n + j] * 255.0f), bl = u8wrap(src[2 * n + j] * 255.0f);
+        const float gray = u8wrap((r * 0.2989f + g * 0.587f) + bl * 0.114f);
+        dst[j] = (m ? gray : r) / 255.0f;
+        dst[n + j] = (m ? gray : g) / 255.0f;
+        dst[2 * n + j] = (m ? gray : bl) / 255.0f;
+    }
+}
+
+} // namespace augcl
+
+using namespace augcl;
+
+extern "C" {
+
+int augcl_affine_gather_f32(const float *in, float *out, int B, int C, int Hin, int Win, int Hout, int Wout,
+                            const int32_t *coef, augcl_stream_t stream)
+{
+    const char *name = "augcl_affine_gather_f32";
+    AUGCL_REQUIRE(B >= 0 && C > 0 && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0, "%s: bad shape", name);
+    if (B == 0) return AUGCL_OK;
+    AUGCL_REQUIRE(in && out && coef && in != out, "%s: bad tensor", name);
+    const int n = Hout * Wout;
+    const int gx = (n + 255) / 256 < 32 ? (n + 255) / 256 : 32;
+    hipLaunchKernelGGL(k_affine_gather, dim3(gx, B * C), dim3(256), 0, as_stream(stream), in, out, C, Hin, Win, Hout, Wout,
+                       coef);
+    return augcl::check_launch(name);
+}
+
+int augcl_cutout_color_f32(const float *in, float *out, int B, int C, int H, int W, const int32_t *box,
+                           const float *color, augcl_stream_t stream)
+{
+    const char *name = "augcl_cutout_color_f32";
+    AUGCL_REQUIRE(B >= 0 && C > 0 && H > 0 && W > 0, "%s: bad shape", name);
+    if (B == 0) return AUGCL_OK;
+    AUGCL_REQUIRE(in && out && box && color, "%s: null tensor", name);
+    const int n = H * W;
+    const int gx = (n + 255) / 256 < 32 ? (n + 255) / 256 : 32;
+    hipLaunchKernelGGL(k_cutout_color, dim3(gx, B * C), dim3(256), 0, as_stream(stream), in, out, C, H, W, box, color);
+    return augcl::check_launch(name);
+}
+
+int augcl_random_grayscale_f32(const float *in, float *out, int B, int frames, int H, int W, const uint8_t *mask,
+                               augcl_stream_t stream)
+{
+    const char *name = "augcl_random_grayscale_f32";
+    AUGCL_REQUIRE(B >= 0 && frames > 0 && H > 0 && W > 0, "%s: bad shape", name);
+    if (B == 0) return AUGCL_OK;
+    AUGCL_REQUIRE(in && out && mask, "%s: null tensor", name);
+    const int n = H * W;
+    const int gx = (n + 255) / 256 < 32 ? (n + 255) / 256 : 32;
+    hipLaunchKernelGGL(k_random_grayscale, dim3(gx, B * frames), dim3(256), 0, as_stream(stream), in, out, frames, n, mask);
+    return augcl::check_launch(name);
+}
+
+} // extern "C"

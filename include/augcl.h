@@ -100,6 +100,20 @@ int augcl_color_jitter_f32(float *inout, int B, int frames, int H, int W,
                            double contrast, double saturation, double hue,
                            float bound, float scale, augcl_stream_t stream);
 
+/* ---- rest of the augmentation registry (src/augmentations.py:436-449), all index/select operators, bit-exact:
+ * random_crop (L385-433: out[b,c,y,x] = in[b,c,w1[b]+y,h1[b]+x] -- the reference's w1 indexes ROWS), random_flip
+ * (L139-168), random_rotation (L171-213) share ONE per-sample integer-affine gather:
+ *   out[b,c,y,x] = in[b,c, ay*y+by*x+cy, ax*y+bx*x+cx], coef = device int32[B][6] = {ay,by,cy,ax,bx,cx}.
+ * random_cutout_color (L327-350): box rows h1..2*h1-1, cols w1..2*w1-1 of every channel <- color[b][c];
+ * box = device int32[B][2] = {h1,w1}.   random_grayscale (L89-136), literal: t = uint8(x*255) with C-style wrap,
+ * gray = uint8(.2989r+.587g+.114b), out = (mask[b] ? gray : t)/255. */
+int augcl_affine_gather_f32(const float *in, float *out, int B, int C, int Hin, int Win, int Hout, int Wout,
+                            const int32_t *coef, augcl_stream_t stream);
+int augcl_cutout_color_f32(const float *in, float *out, int B, int C, int H, int W, const int32_t *box,
+                           const float *color, augcl_stream_t stream);
+int augcl_random_grayscale_f32(const float *in, float *out, int B, int frames, int H, int W, const uint8_t *mask,
+                               augcl_stream_t stream);
+
 /* ---- fused SVEA/AugCL front end: src/algorithms/svea.py:68 + :49 (random_shift, then
  * apply_aug=random_conv on the shifted clone) in one pass over the uint8/f32 observation:
  * out_shift = random_shift(in); out_aug = random_conv(out_shift).  Either output may be NULL. */

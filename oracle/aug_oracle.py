@@ -139,3 +139,73 @@ def color_jitter_c(x, idx, order, contrast, saturation, hue, bound=1.0, scale=1.
                                   ctypes.c_double(contrast), ctypes.c_double(saturation), ctypes.c_double(hue),
                                   ctypes.c_float(bound), ctypes.c_float(scale))
     return out
+
+
+# ---------------------------------------------------------------- rest of the registry: numpy
+# index / select restatements, explicit random parameters.  Bit-exact operators.
+def affine_coef(kind, n, H=84, W=84, a=None, b=None):
+    """int32 (n,6) {ay,by,cy,ax,bx,cx} rows for out[y,x] = in[ay*y+by*x+cy, ax*y+bx*x+cx].
+    kind: per-sample array of 0 identity / 1 rot90 / 2 rot180 / 3 rot270 / 4 hflip / 5 crop(a=row0, b=col0)."""
+    table = {0: (1, 0, 0, 0, 1, 0), 1: (0, 1, 0, -1, 0, W - 1), 2: (-1, 0, H - 1, 0, -1, W - 1),
+             3: (0, -1, H - 1, 1, 0, 0), 4: (1, 0, 0, 0, -1, W - 1)}
+    out = np.empty((n, 6), np.int32)
+    for i in range(n):
+        k = int(kind[i])
+        out[i] = (1, 0, int(a[i]), 0, 1, int(b[i])) if k == 5 else table[k]
+    return out
+
+
+def affine_gather_np(x, coef, Hout, Wout):
+    """One integer-affine gather covers random_crop / random_flip / random_rotation."""
+    x = np.asarray(x)
+    B = x.shape[0]
+    yy, xx = np.mgrid[0:Hout, 0:Wout]
+    out = np.empty(x.shape[:2] + (Hout, Wout), x.dtype)
+    for i in range(B):
+        ay, by, cy, ax, bx, cx = (int(v) for v in coef[i])
+        out[i] = x[i][:, ay * yy + by * xx + cy, ax * yy + bx * xx + cx]
+    return out
+
+
+def random_crop_np(x, w1, h1, size=84):
+    """src/augmentations.py:385-433: windows[arange(n), w1, h1] on the NHWC view -> out[i,c,y,x] =
+    x[i,c,w1[i]+y,h1[i]+x] (the reference's `w1` walks ROWS, `h1` columns)."""
+    x = np.asarray(x)
+    return np.stack([x[i, :, int(w1[i]):int(w1[i]) + size, int(h1[i]):int(h1[i]) + size] for i in range(x.shape[0])])
+
+
+def random_flip_np(x, mask):
+    """src/augmentations.py:139-168: out = mask*flip([3]) + (1-mask)*x, one mask bit per sample."""
+    x = np.asarray(x)
+    out = x.copy()
+    m = np.asarray(mask, bool)
+    out[m] = x[m][..., ::-1]
+    return out
+
+
+def random_rotation_np(x, rot):
+    """src/augmentations.py:171-213: rot[i] in {0,1,2,3} quarter turns (torch.rot90 over dims [2,3])."""
+    x = np.asarray(x)
+    return np.stack([np.rot90(x[i], int(rot[i]), axes=(1, 2)) for i in range(x.shape[0])])
+
+
+def random_cutout_color_np(x, w1, h1, color):
+    """src/augmentations.py:327-350: img[:, h1:2*h1, w1:2*w1] = color[i][:,None,None] (numpy slicing clips)."""
+    out = np.array(x, copy=True)
+    for i in range(out.shape[0]):
+        h, w = int(h1[i]), int(w1[i])
+        out[i, :, h:h + h, w:w + w] = np.asarray(color[i], out.dtype).reshape(-1, 1, 1)
+    return out
+
+
+def random_grayscale_np(x, mask):
+    """src/augmentations.py:89-136, literal: uint8(x*255) with C-style wrap (torch CPU cast), per-frame
+    gray = uint8(.2989 r + .587 g + .114 b) in f32 left-to-right, out = (mask ? gray : t) / 255."""
+    x = np.asarray(x, np.float32)
+    B, C, H, W = x.shape
+    t = ((x * np.float32(255.0)).astype(np.int64) & 255).astype(np.float32).reshape(B, C // 3, 3, H, W)
+    gray = (t[:, :, 0] * np.float32(0.2989) + t[:, :, 1] * np.float32(0.587)) + t[:, :, 2] * np.float32(0.114)
+    gray = np.floor(gray).astype(np.float32)  # values in [0,255]: uint8 cast == truncation
+    m = np.asarray(mask, bool)[:, None, None, None, None]
+    out = np.where(m, gray[:, :, None], t)
+    return (out.reshape(B, C, H, W) / np.float32(255.0)).astype(np.float32)

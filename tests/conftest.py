@@ -19,6 +19,12 @@ def golden_aug():
 
 
 @pytest.fixture(scope="session")
+def golden_aug_extra():
+    import numpy as np
+    return np.load(os.path.join(ROOT, "tests", "golden", "aug_extra_golden.npz"))
+
+
+@pytest.fixture(scope="session")
 def cuda():
     import torch
     if not torch.cuda.is_available():

@@ -205,5 +205,70 @@ def make_aug():
     print("wrote aug_golden.npz", {k: v.shape for k, v in out.items()})
 
 
+def make_extra():
+    """Rest of the registry (augmentations.py:436-449): crop / flip / rotate / cutout_color / grayscale.
+    The reference draws from np.random / torch's default generator; each call is seeded and the same draws are
+    replayed afterwards to record the parameters.  Must run in the process that already installed the stubs."""
+    import augmentations as ref_aug
+
+    B = 4
+    out = {}
+    x = torch.from_numpy(gi.obs_u8(seed=21, B=B).astype(np.float32))
+
+    # random_crop (L385-433) 100x100 -> 84x84, drawn and explicit offsets
+    xb = torch.from_numpy(gi.obs_u8(seed=22, B=B, H=100, W=100).astype(np.float32))
+    torch.manual_seed(404)
+    y, w1, h1 = ref_aug.random_crop(xb.clone(), size=84, return_w1_h1=True)
+    torch.manual_seed(404)
+    w1r = torch.LongTensor(B).random_(0, 16)
+    h1r = torch.LongTensor(B).random_(0, 16)
+    assert torch.equal(w1, w1r) and torch.equal(h1, h1r)
+    out["crop_out_u8"] = y.numpy().astype(np.uint8)
+    out["crop_w1"], out["crop_h1"] = w1.numpy().astype(np.int32), h1.numpy().astype(np.int32)
+    assert y.shape == (B, 9, 84, 84)
+
+    # random_flip (L139-168); p raised so both branches occur in 4 samples
+    np.random.seed(505)
+    y = ref_aug.random_flip(x.clone(), p=0.5)
+    np.random.seed(505)
+    mask = np.random.uniform(0.0, 1.0, size=(B,)) <= 0.5
+    assert 0 < mask.sum() < B
+    out["flip_out_u8"], out["flip_mask"] = y.numpy().astype(np.uint8), mask
+
+    # random_rotation (L171-213)
+    np.random.seed(606)
+    y = ref_aug.random_rotation(x.clone(), p=0.8)
+    np.random.seed(606)
+    rnd = np.random.uniform(0.0, 1.0, size=(B,))
+    rot = np.random.randint(1, 4, size=(B,)) * (rnd <= 0.8)
+    out["rot_out_u8"], out["rot_k"] = y.numpy().astype(np.uint8), rot.astype(np.int32)
+    assert len(set(rot.tolist())) >= 3, rot
+
+    # random_cutout_color (L327-350) -- numpy on the host in the reference
+    np.random.seed(707)
+    y = ref_aug.random_cutout_color(x.clone())
+    np.random.seed(707)
+    w1 = np.random.randint(10, 30, B)
+    h1 = np.random.randint(10, 30, B)
+    col = np.random.randint(0, 255, size=(B, 9)) / 255.0
+    out["cutout_out"] = y.numpy()
+    out["cutout_w1"], out["cutout_h1"] = w1.astype(np.int32), h1.astype(np.int32)
+    out["cutout_color"] = col.astype(np.float32)
+
+    # random_grayscale (L89-136): on [0,1] frames (what the arithmetic is written for) and, literally, on the
+    # 0..255 floats the training code would hand it (uint8 wrap of x*255)
+    for tag, xin, seed in (("gray01", x / 255.0, 808), ("gray255", x.clone(), 809)):
+        np.random.seed(seed)
+        y = ref_aug.random_grayscale(xin.clone(), p=0.5)
+        np.random.seed(seed)
+        mask = np.random.uniform(0.0, 1.0, size=(B,)) <= 0.5
+        assert 0 < mask.sum() < B
+        out[tag + "_out"], out[tag + "_mask"] = y.numpy(), mask
+
+    np.savez_compressed(os.path.join(HERE, "aug_extra_golden.npz"), **out)
+    print("wrote aug_extra_golden.npz", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
-    make_aug()  # networks / update() goldens: make_golden_sac.py (separate process)
+    make_aug()
+    make_extra()  # networks / update() goldens: make_golden_sac.py (separate process)

@@ -262,3 +262,101 @@ def test_jitter_draws_its_own_params_like_the_reference(cuda):
     assert y.shape == x0.shape and not torch.equal(y, x0)
     # only frame-rows 0..B-1 of the 3B rows can ever be selected (reference quirk, kept)
     assert torch.equal(y.view(12, -1)[4:], x0.view(12, -1)[4:])
+
+
+# ---------------------------------------------------------------- rest of the registry
+@pytest.mark.gpu
+def test_extra_ops_golden_bit_exact(cuda, golden_aug_extra):
+    g = golden_aug_extra
+    x = gi.obs_u8(21, 4).astype(np.float32)
+    xb = gi.obs_u8(22, 4, H=100, W=100).astype(np.float32)
+    got, w1, h1 = aug.random_crop(dev(xb, cuda), size=84, w1=torch.from_numpy(g["crop_w1"].astype(np.int64)),
+                                  h1=torch.from_numpy(g["crop_h1"].astype(np.int64)), return_w1_h1=True)
+    assert np.array_equal(host(got), g["crop_out_u8"].astype(np.float32))
+    assert np.array_equal(host(aug.random_flip(dev(x, cuda), mask=g["flip_mask"])), g["flip_out_u8"].astype(np.float32))
+    assert np.array_equal(host(aug.random_rotation(dev(x, cuda), rot=g["rot_k"])), g["rot_out_u8"].astype(np.float32))
+    got = aug.random_cutout_color(dev(x, cuda), w1=g["cutout_w1"], h1=g["cutout_h1"], color=g["cutout_color"])
+    assert np.array_equal(host(got), g["cutout_out"])
+    got = aug.random_grayscale(dev(x / np.float32(255.0), cuda), mask=g["gray01_mask"])
+    assert np.array_equal(host(got), g["gray01_out"])
+    got = aug.random_grayscale(dev(x, cuda), mask=g["gray255_mask"])
+    assert np.array_equal(host(got), g["gray255_out"])
+
+
+@pytest.mark.gpu
+def test_extra_ops_draw_like_the_reference(cuda):
+    """Without explicit parameters the shims consume np.random / torch's generator exactly as the reference does
+    (same calls, same order), so a seeded reference run and a seeded run here pick the same samples."""
+    B = 6
+    x = gi.obs_u8(31, B).astype(np.float32)
+    xd = dev(x, cuda)
+    np.random.seed(5)
+    got = host(aug.aug_to_func["flip"](xd, p=0.5))
+    np.random.seed(5)
+    assert np.array_equal(got, orc.random_flip_np(x, np.random.uniform(0.0, 1.0, size=(B,)) <= 0.5))
+
+    np.random.seed(6)
+    got = host(aug.aug_to_func["rotate"](xd, p=0.7))
+    np.random.seed(6)
+    rnd = np.random.uniform(0.0, 1.0, size=(B,))
+    rot = np.random.randint(1, 4, size=(B,)) * (rnd <= 0.7)
+    assert np.array_equal(got, orc.random_rotation_np(x, rot))
+
+    np.random.seed(7)
+    got = host(aug.aug_to_func["cutout_color"](xd))
+    np.random.seed(7)
+    w1, h1 = np.random.randint(10, 30, B), np.random.randint(10, 30, B)
+    col = np.random.randint(0, 255, size=(B, 9)) / 255.0
+    assert np.array_equal(got, orc.random_cutout_color_np(x, w1, h1, col))
+
+    np.random.seed(8)
+    got = host(aug.aug_to_func["grayscale"](xd / 255.0, p=0.5))
+    np.random.seed(8)
+    assert np.array_equal(got, orc.random_grayscale_np(x / np.float32(255.0), np.random.uniform(0, 1, size=(B,)) <= 0.5))
+
+    xb = gi.obs_u8(32, B, H=100, W=100).astype(np.float32)
+    torch.manual_seed(9)
+    got = host(aug.aug_to_func["crop"](dev(xb, cuda)))
+    torch.manual_seed(9)
+    w1 = torch.LongTensor(B).random_(0, 16)
+    h1 = torch.LongTensor(B).random_(0, 16)
+    assert np.array_equal(got, orc.random_crop_np(xb, w1.numpy(), h1.numpy()))
+    # crop_max <= 0: the input comes back untouched (reference L397-400)
+    same, a, b = aug.random_crop(xd, size=84, return_w1_h1=True)
+    assert same is xd and a is None and b is None
+
+
+@pytest.mark.gpu
+def test_extra_ops_edges_and_properties(cuda):
+    x = gi.obs_u8(33, 3, C=3, H=20, W=20).astype(np.float32)
+    xd = dev(x, cuda)
+    # four quarter turns / two flips are the identity; rot180 = flip rows and columns
+    y = xd
+    for _ in range(4):
+        y = aug.random_rotation(y, rot=[1, 1, 1])
+    assert torch.equal(y, xd)
+    assert torch.equal(aug.random_flip(aug.random_flip(xd, mask=[1, 0, 1]), mask=[1, 0, 1]), xd)
+    assert torch.equal(aug.random_rotation(xd, rot=[2, 2, 2]), xd.flip([2, 3]))
+    assert torch.equal(aug.random_rotation(xd, rot=[1, 3, 0]),
+                       torch.stack([xd[0].rot90(1, [1, 2]), xd[1].rot90(3, [1, 2]), xd[2]]))
+    # cutout box clipped by the frame edge (h1 + h1 > H), as numpy slicing clips
+    got = host(aug.random_cutout_color(xd, w1=[15, 0, 19], h1=[12, 19, 0], color=np.full((3, 3), 0.5, np.float32)))
+    assert np.array_equal(got, orc.random_cutout_color_np(x, [15, 0, 19], [12, 19, 0], np.full((3, 3), 0.5)))
+    # out-of-frame crop window is refused on the host, before any launch
+    with pytest.raises(ValueError):
+        aug.random_crop(xd, size=16, w1=torch.tensor([0, 5, 0]), h1=torch.tensor([0, 0, 0]))
+    # empty batch
+    z = torch.empty((0, 9, 84, 84), device=cuda)
+    assert aug.random_flip(z).shape == z.shape and aug.random_grayscale(z).shape == z.shape
+    assert aug.random_cutout_color(z).shape == z.shape
+    with pytest.raises(NotImplementedError):
+        aug.aug_to_func["splice"](xd)
+    # full batch: flip is an involution; the uint8 quantisation is idempotent (the gray mix itself is not: its
+    # coefficients sum to 0.9999, so gray(g,g,g) = g-1)
+    big = torch.rand((256, 9, 84, 84), device=cuda)
+    m = np.arange(256) % 2 == 0
+    assert torch.equal(aug.random_flip(aug.random_flip(big, mask=m), mask=m), big)
+    g1 = aug.random_grayscale(big, mask=m)
+    assert torch.equal(aug.random_grayscale(g1, mask=np.zeros(256, bool)), g1)
+    v = g1.view(256, 3, 3, 84, 84)[m]
+    assert torch.equal(v[:, :, 0], v[:, :, 1]) and torch.equal(v[:, :, 0], v[:, :, 2])

@@ -77,3 +77,33 @@ def test_edge_cases():
         got = orc.random_shift_c(x, [oy], [ox])
         assert np.array_equal(got, orc.random_shift_np(x, [oy], [ox]))
     assert np.array_equal(orc.random_shift_c(x, [4], [4]), x)  # centre crop = identity
+
+
+# ---------------------------------------------------------------- rest of the registry (aug_extra_golden.npz)
+def test_crop_flip_rotate_bit_exact(golden_aug_extra):
+    g = golden_aug_extra
+    n = 4
+    x = gi.obs_u8(21, n).astype(np.float32)
+    xb = gi.obs_u8(22, n, H=100, W=100).astype(np.float32)
+    want = g["crop_out_u8"].astype(np.float32)
+    assert np.array_equal(orc.random_crop_np(xb, g["crop_w1"], g["crop_h1"]), want)
+    coef = orc.affine_coef([5] * n, n, 100, 100, a=g["crop_w1"], b=g["crop_h1"])
+    assert np.array_equal(orc.affine_gather_np(xb, coef, 84, 84), want)
+
+    want = g["flip_out_u8"].astype(np.float32)
+    assert np.array_equal(orc.random_flip_np(x, g["flip_mask"]), want)
+    coef = orc.affine_coef(np.where(g["flip_mask"], 4, 0), n)
+    assert np.array_equal(orc.affine_gather_np(x, coef, 84, 84), want)
+
+    want = g["rot_out_u8"].astype(np.float32)
+    assert np.array_equal(orc.random_rotation_np(x, g["rot_k"]), want)
+    assert np.array_equal(orc.affine_gather_np(x, orc.affine_coef(g["rot_k"], n), 84, 84), want)
+
+
+def test_cutout_and_grayscale_bit_exact(golden_aug_extra):
+    g = golden_aug_extra
+    x = gi.obs_u8(21, 4).astype(np.float32)
+    got = orc.random_cutout_color_np(x, g["cutout_w1"], g["cutout_h1"], g["cutout_color"])
+    assert np.array_equal(got, g["cutout_out"])
+    assert np.array_equal(orc.random_grayscale_np(x / np.float32(255.0), g["gray01_mask"]), g["gray01_out"])
+    assert np.array_equal(orc.random_grayscale_np(x, g["gray255_mask"]), g["gray255_out"])
