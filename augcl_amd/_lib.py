@@ -67,6 +67,7 @@ _SIGS = {
     "augcl_affine_gather_f32": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
     "augcl_cutout_color_f32": [_P, _P, _I, _I, _I, _I, _P, _P, _P],
     "augcl_random_grayscale_f32": [_P, _P, _I, _I, _I, _I, _P, _P],
+    "augcl_splice_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _F, _F, _P],
     "augcl_adam_f32": [_P, _P, _P, _P, _SZ, _D, _D, _D, _D, _c.c_int64, _D, _P],
     "augcl_ema_f32": [_P, _P, _SZ, _D, _P],
     "augcl_enc_bf16_conv_first_forward": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],

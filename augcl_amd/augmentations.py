@@ -3,7 +3,7 @@
 Same names, argument meaning and return conventions as the reference:
 
     aug_to_func["shift" | "conv" | "overlay" | "color_jitter" | "identity" |
-                "crop" | "flip" | "rotate" | "cutout_color" | "grayscale"](x, **params)
+                "crop" | "flip" | "rotate" | "cutout_color" | "grayscale" | "splice" | "CS_splice"](x, **params)
 
 x is a contiguous (B, C, H, W) float32 tensor holding 0..255 values on the GPU
 (what `ReplayBuffer.sample()` returns, src/utils.py:206-214); a uint8 tensor is also
@@ -349,17 +349,64 @@ def random_grayscale(images, p=0.3, *, mask=None):
     return out
 
 
-def _needs_kornia_hsv(name):
-    def fn(*_a, **_k):
-        raise NotImplementedError(
-            f"{name}: depends on kornia.color.rgb_to_hsv thresholds (src/augmentations.py:277-324) whose arithmetic "
-            "cannot be pinned here (kornia absent); not built -- see DESIGN.md")
-    fn.__name__ = name
-    return fn
+KORNIA_HSV_EPS = 1e-6  # kornia.color.rgb_to_hsv default
 
 
-splice = _needs_kornia_hsv("splice")
-CS_splice = _needs_kornia_hsv("CS_splice")
+def _splice(x, name, cs_mode, hue_thres, sat_thres, val_thres, imgs):
+    _check_bchw(x, name)
+    if x.dtype != torch.float32:
+        raise TypeError(f"{name}: float32 input expected")
+    n, c, h, w = x.shape
+    if c % 3:
+        raise ValueError(f"{name}: channel count must be a multiple of 3")
+    if imgs is None:
+        if _overlay_source is None:
+            raise FileNotFoundError("failed to find image data: no overlay source registered "
+                                    "(augmentations.set_overlay_source)")
+        imgs = _overlay_source(n, w, x.device)
+    imgs = torch.as_tensor(imgs, device=x.device, dtype=torch.float32).contiguous()
+    if tuple(imgs.shape) != (n, 3, h, w):
+        raise ValueError(f"{name}: overlay batch must be {(n, 3, h, w)}, got {tuple(imgs.shape)}")
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    _lib.call("augcl_splice_f32", _lib.ptr(x), _lib.ptr(imgs), _lib.ptr(out), n, c // 3, h, w, int(cs_mode),
+              float(hue_thres), float(sat_thres), float(val_thres), KORNIA_HSV_EPS, _lib.current_stream(x.device))
+    return out
+
+
+def splice(x, hue_thres=0, sat_thres=0, val_thres=0.6, *, imgs=None):
+    """src/augmentations.py:298-309: pixels of x/255 whose (hue, saturation, value) all exceed the thresholds are
+    kept, the rest is replaced by an overlay image; *255.  (0.6 val for video_hard, 0.4 for video_easy.)
+    Frame j of the (n*frames,3,h,w) view pairs with overlay image j % n, as the reference's tiling does."""
+    return _splice(x, "splice", 0, hue_thres, sat_thres, val_thres, imgs)
+
+
+def CS_splice(x, hue_thres=3.5, sat_thres=0, val_thres=0, *, imgs=None):
+    """src/augmentations.py:312-324 (cartpole variant): overlay everywhere the first mask holds, except where
+    the (hue>0, sat, value>0.6) mask holds too."""
+    return _splice(x, "CS_splice", 1, hue_thres, sat_thres, val_thres, imgs)
+
+
+def batch_from_obs(obs, batch_size=32):
+    """src/augmentations.py:353-362: copy a single observation along the batch dimension."""
+    if isinstance(obs, torch.Tensor):
+        if len(obs.shape) == 3:
+            obs = obs.unsqueeze(0)
+        return obs.repeat(batch_size, 1, 1, 1)
+    if len(obs.shape) == 3:
+        obs = np.expand_dims(obs, axis=0)
+    return np.repeat(obs, repeats=batch_size, axis=0)
+
+
+def prepare_pad_batch(obs, next_obs, action, batch_size=32, *, device="cuda"):
+    """src/augmentations.py:365-371 (PAD test-time adaptation batch): numpy obs/next_obs/action -> device, tiled
+    batch_size times, obs and next_obs independently random-cropped to 84."""
+    batch_obs = batch_from_obs(torch.from_numpy(obs).to(device), batch_size)
+    batch_next_obs = batch_from_obs(torch.from_numpy(next_obs).to(device), batch_size)
+    batch_action = torch.from_numpy(action).to(device).unsqueeze(0).repeat(batch_size, 1)
+    f = lambda t: t if t.dtype == torch.float32 else t.float()  # noqa: E731  (the gather kernel is f32)
+    return random_crop(f(batch_obs)), random_crop(f(batch_next_obs)), batch_action
+
 
 aug_to_func = {
     "grayscale": random_grayscale,

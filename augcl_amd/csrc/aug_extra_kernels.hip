@@ -66,6 +66,44 @@ __global__ __launch_bounds__(256) void k_random_grayscale(const float *__restric
     }
 }
 
+// splice / CS_splice (src/augmentations.py:277-324).  Frame j = b*frames + f of the (B*frames,3,H,W) view pairs with
+// overlay image j % B -- the reference tiles the image batch along dim 0 (`.repeat(frames,1,1,1)`), kept as is.
+// HSV planes follow kornia.color.rgb_to_hsv (0.5.x): v = max, s = (max-min)/(v+eps), first-maximum channel selects
+// h6 in {b'-g', 2d+r'-b', 4d+g'-r'} (x' = max-x, d = max-min or 1), h = 2*pi*((h6/d/6) mod 1).
+// keep  = all(hsv > thres);  splice: out = keep ? rgb : overlay;  CS_splice: out = (keep2 | !keep) ? rgb : overlay
+// with keep2 = all(hsv > (0, sat_thres, 0.6)).  Everything * 255 at the end, rgb = x / 255.
+__global__ __launch_bounds__(256) void k_splice(const float *__restrict__ x, const float *__restrict__ imgs,
+                                                float *__restrict__ out, int B, int n /* H*W */, int cs_mode, float ht,
+                                                float st, float vt, float eps)
+{
+    const int j = blockIdx.y; // frame index in the (B*frames) view
+    const float *__restrict__ src = x + (size_t)j * 3 * n;
+    const float *__restrict__ ov = imgs + (size_t)(j % B) * 3 * n;
+    float *__restrict__ dst = out + (size_t)j * 3 * n;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < n; p += gridDim.x * 256) {
+        const float r = src[p] / 255.0f, g = src[n + p] / 255.0f, b = src[2 * n + p] / 255.0f;
+        const float mx = fmaxf(fmaxf(r, g), b), mn = fminf(fminf(r, g), b);
+        const float dc = mx - mn;
+        const float sat = dc / (mx + eps);
+        const float d = dc == 0.0f ? 1.0f : dc;
+        const float rc = mx - r, gc = mx - g, bc = mx - b;
+        float h6;
+        if (r == mx) h6 = bc - gc;
+        else if (g == mx) h6 = (2.0f * d + rc) - bc;
+        else h6 = (4.0f * d + gc) - rc;
+        float h = (h6 / d) / 6.0f;
+        h = fmodf(h, 1.0f);
+        if (h != 0.0f && h < 0.0f) h += 1.0f;
+        h = 6.283185307179586f * h;
+        const bool keep = h > ht && sat > st && mx > vt;
+        bool use_rgb = keep;
+        if (cs_mode) use_rgb = (h > 0.0f && sat > st && mx > 0.6f) || !keep;
+        dst[p] = (use_rgb ? r : ov[p]) * 255.0f;
+        dst[n + p] = (use_rgb ? g : ov[n + p]) * 255.0f;
+        dst[2 * n + p] = (use_rgb ? b : ov[2 * n + p]) * 255.0f;
+    }
+}
+
 } // namespace augcl
 
 using namespace augcl;
@@ -109,6 +147,20 @@ int augcl_random_grayscale_f32(const float *in, float *out, int B, int frames, i
     const int n = H * W;
     const int gx = (n + 255) / 256 < 32 ? (n + 255) / 256 : 32;
     hipLaunchKernelGGL(k_random_grayscale, dim3(gx, B * frames), dim3(256), 0, as_stream(stream), in, out, frames, n, mask);
+    return augcl::check_launch(name);
+}
+
+int augcl_splice_f32(const float *x, const float *imgs, float *out, int B, int frames, int H, int W, int cs_mode,
+                     float hue_thres, float sat_thres, float val_thres, float eps, augcl_stream_t stream)
+{
+    const char *name = "augcl_splice_f32";
+    AUGCL_REQUIRE(B >= 0 && frames > 0 && H > 0 && W > 0, "%s: bad shape", name);
+    if (B == 0) return AUGCL_OK;
+    AUGCL_REQUIRE(x && imgs && out && x != out, "%s: bad tensor", name);
+    const int n = H * W;
+    const int gx = (n + 255) / 256 < 32 ? (n + 255) / 256 : 32;
+    hipLaunchKernelGGL(k_splice, dim3(gx, B * frames), dim3(256), 0, as_stream(stream), x, imgs, out, B, n, cs_mode,
+                       hue_thres, sat_thres, val_thres, eps);
     return augcl::check_launch(name);
 }
 

@@ -126,9 +126,21 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("AUGCL_FORCE_DIST") == "1":  # the override rehearses the RCCL path on one GPU
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        # RCCL prints a version banner on STDOUT when its communicator comes up; stdout carries the one JSON line,
+        # so point fd 1 at stderr until the first collective has run
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=dev)
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from augcl_amd import _lib, augmentations as aug

@@ -113,6 +113,12 @@ int augcl_cutout_color_f32(const float *in, float *out, int B, int C, int H, int
                            const float *color, augcl_stream_t stream);
 int augcl_random_grayscale_f32(const float *in, float *out, int B, int frames, int H, int W, const uint8_t *mask,
                                augcl_stream_t stream);
+/* splice (cs_mode 0, src/augmentations.py:298-309) / CS_splice (cs_mode 1, L312-324) + create_hsv_mask (L277-285):
+ * HSV-keyed replacement of x/255 by an overlay image; frame j of the (B*frames,3,H,W) view pairs with imgs[j % B]
+ * (the reference's batch-dim tiling).  HSV per kornia.color.rgb_to_hsv (hue in radians, s = d/(v+eps)).
+ * x, out: (B, 3*frames, H, W) f32; imgs: (B,3,H,W) f32 in [0,1]. */
+int augcl_splice_f32(const float *x, const float *imgs, float *out, int B, int frames, int H, int W, int cs_mode,
+                     float hue_thres, float sat_thres, float val_thres, float eps, augcl_stream_t stream);
 
 /* ---- fused SVEA/AugCL front end: src/algorithms/svea.py:68 + :49 (random_shift, then
  * apply_aug=random_conv on the shifted clone) in one pass over the uint8/f32 observation:

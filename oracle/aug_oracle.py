@@ -209,3 +209,40 @@ def random_grayscale_np(x, mask):
     m = np.asarray(mask, bool)[:, None, None, None, None]
     out = np.where(m, gray[:, :, None], t)
     return (out.reshape(B, C, H, W) / np.float32(255.0)).astype(np.float32)
+
+
+def rgb_to_hsv_np(rgb, eps=1e-6):
+    """kornia.color.rgb_to_hsv (kornia is unpinned in the reference's setup/conda.yaml:22; algorithm of 0.5.x
+    kornia/color/hsv.py restated: parity unpinned for the arithmetic).  rgb (N,3,H,W) f32 -> h (radians), s, v."""
+    f = np.float32
+    r, g, b = rgb[:, 0], rgb[:, 1], rgb[:, 2]
+    mx = np.maximum(np.maximum(r, g), b)
+    mn = np.minimum(np.minimum(r, g), b)
+    dc = mx - mn
+    s = dc / (mx + f(eps))
+    d = np.where(dc == 0, f(1.0), dc)
+    rc, gc, bc = mx - r, mx - g, mx - b
+    h6 = np.where(r == mx, bc - gc, np.where(g == mx, (f(2.0) * d + rc) - bc, (f(4.0) * d + gc) - rc))
+    h = (h6 / d) / f(6.0)
+    h = np.fmod(h, f(1.0))
+    h = np.where((h != 0) & (h < 0), h + f(1.0), h)
+    return f(2 * np.pi) * h, s, mx
+
+
+def splice_np(x, imgs, hue_thres=0.0, sat_thres=0.0, val_thres=0.6, cs=False, eps=1e-6):
+    """src/augmentations.py:298-324 (+ create_hsv_mask L277-285).  cs=True is CS_splice (pass hue_thres=3.5,
+    val_thres=0).  Frame j of the (n*frames,3,h,w) view takes overlay image j % n (batch-dim tiling, L302/L316)."""
+    x = np.asarray(x, np.float32)
+    n, c, hh, ww = x.shape
+    rgb = x.reshape(-1, 3, hh, ww) / np.float32(255.0)
+    ov = np.tile(np.asarray(imgs, np.float32), (c // 3, 1, 1, 1))
+    h, s, v = rgb_to_hsv_np(rgb, eps)
+    f = np.float32
+    keep = (h > f(hue_thres)) & (s > f(sat_thres)) & (v > f(val_thres))
+    if cs:
+        keep2 = (h > f(0)) & (s > f(sat_thres)) & (v > f(0.6))
+        use = keep2 | ~keep
+    else:
+        use = keep
+    out = np.where(use[:, None], rgb, ov)
+    return (out.reshape(n, c, hh, ww) * np.float32(255.0)).astype(np.float32)

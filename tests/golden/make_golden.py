@@ -138,6 +138,29 @@ def _install_stubs():
             return img
 
     sys.modules["torchvision.transforms"].ColorJitter = _ColorJitter
+
+    def rgb_to_hsv(image, eps=1e-6):
+        """Stand-in for the absent kornia.color.rgb_to_hsv: torch restatement of kornia 0.5.x kornia/color/hsv.py
+        (first-maximum channel selection, hue in radians)."""
+        import math
+        maxc, _ = image.max(-3)
+        maxc_mask = image == maxc.unsqueeze(-3)
+        _, max_indices = ((maxc_mask.cumsum(-3) == 1) & maxc_mask).max(-3)
+        minc = image.min(-3)[0]
+        v = maxc
+        deltac = maxc - minc
+        s = deltac / (v + eps)
+        deltac = torch.where(deltac == 0, torch.ones_like(deltac), deltac)
+        maxc_tmp = maxc.unsqueeze(-3) - image
+        rc, gc, bc = maxc_tmp[..., 0, :, :], maxc_tmp[..., 1, :, :], maxc_tmp[..., 2, :, :]
+        h = torch.stack([bc - gc, 2.0 * deltac + rc - bc, 4.0 * deltac + gc - rc], dim=-3)
+        h = torch.gather(h, dim=-3, index=max_indices[..., None, :, :]).squeeze(-3)
+        h = h / deltac
+        h = (h / 6.0) % 1.0
+        h = 2 * math.pi * h
+        return torch.stack([h, s, v], dim=-3)
+
+    sys.modules["kornia.color"].rgb_to_hsv = rgb_to_hsv
     return RandomCrop, _ColorJitter
 
 
@@ -264,6 +287,22 @@ def make_extra():
         mask = np.random.uniform(0.0, 1.0, size=(B,)) <= 0.5
         assert 0 < mask.sum() < B
         out[tag + "_out"], out[tag + "_mask"] = y.numpy(), mask
+
+    # splice / CS_splice (L277-324): kornia's rgb_to_hsv is the stand-in above (parity unpinned for its
+    # arithmetic); the goldens pin the reference's call site: batch-dim overlay tiling, mask logic, /255 ... *255.
+    # Image-like frames (gray patches, saturated primaries) so every branch of the HSV code is hit.
+    xs = torch.from_numpy(gi.smooth_obs_u8(seed=23, B=B).astype(np.float32))
+    ov = torch.from_numpy(gi.overlay_imgs(seed=24, B=B))
+    ref_aug.dataloader = object()
+    ref_aug._get_data_batch = lambda batch_size: ov.clone()
+    xin = xs.clone()
+    out["splice_out"] = ref_aug.splice(xin).numpy()
+    out["splice_easy_out"] = ref_aug.splice(xin, val_thres=0.4).numpy()
+    out["cs_splice_out"] = ref_aug.CS_splice(xin).numpy()
+    assert torch.equal(xin, xs)  # neither mutates its input
+    for k in ("splice_out", "splice_easy_out", "cs_splice_out"):
+        frac = float((np.abs(out[k] - xs.numpy()) > 0.5).mean())
+        assert 0.05 < frac < 0.95, (k, frac)  # both branches well populated
 
     np.savez_compressed(os.path.join(HERE, "aug_extra_golden.npz"), **out)
     print("wrote aug_extra_golden.npz", {k: v.shape for k, v in out.items()})

@@ -349,8 +349,6 @@ def test_extra_ops_edges_and_properties(cuda):
     z = torch.empty((0, 9, 84, 84), device=cuda)
     assert aug.random_flip(z).shape == z.shape and aug.random_grayscale(z).shape == z.shape
     assert aug.random_cutout_color(z).shape == z.shape
-    with pytest.raises(NotImplementedError):
-        aug.aug_to_func["splice"](xd)
     # full batch: flip is an involution; the uint8 quantisation is idempotent (the gray mix itself is not: its
     # coefficients sum to 0.9999, so gray(g,g,g) = g-1)
     big = torch.rand((256, 9, 84, 84), device=cuda)
@@ -360,3 +358,33 @@ def test_extra_ops_edges_and_properties(cuda):
     assert torch.equal(aug.random_grayscale(g1, mask=np.zeros(256, bool)), g1)
     v = g1.view(256, 3, 3, 84, 84)[m]
     assert torch.equal(v[:, :, 0], v[:, :, 1]) and torch.equal(v[:, :, 0], v[:, :, 2])
+
+
+@pytest.mark.gpu
+def test_splice_golden_and_oracle(cuda, golden_aug_extra):
+    g = golden_aug_extra
+    x = gi.smooth_obs_u8(23, 4).astype(np.float32)
+    ov = gi.overlay_imgs(24, 4)
+    xd, ovd = dev(x, cuda), dev(ov, cuda)
+    assert np.array_equal(host(aug.splice(xd, imgs=ovd)), g["splice_out"])
+    assert np.array_equal(host(aug.splice(xd, val_thres=0.4, imgs=ovd)), g["splice_easy_out"])
+    assert np.array_equal(host(aug.CS_splice(xd, imgs=ovd)), g["cs_splice_out"])
+    assert np.array_equal(host(xd), x)  # input untouched
+    # uniform-noise frames, full batch, registered image source, odd thresholds
+    B = 256
+    xn = gi.obs_u8(41, B).astype(np.float32)
+    src = aug.SyntheticOverlaySource(seed=3)
+    aug.set_overlay_source(src)
+    try:
+        got = aug.aug_to_func["splice"](dev(xn, cuda), 1.0, 0.2, 0.5)
+        chk = aug.SyntheticOverlaySource(seed=3)  # replays the registered source's stream
+        imgs = host(chk(B, 84, cuda))
+        want = orc.splice_np(xn, imgs, 1.0, 0.2, 0.5)
+        assert np.array_equal(host(got), want)
+        got = aug.aug_to_func["CS_splice"](dev(xn, cuda))
+        imgs2 = host(chk(B, 84, cuda))
+        assert np.array_equal(host(got), orc.splice_np(xn, imgs2, 3.5, 0.0, 0.0, cs=True))
+    finally:
+        aug.set_overlay_source(None)
+    with pytest.raises(FileNotFoundError):
+        aug.splice(xd)

@@ -107,3 +107,13 @@ def test_cutout_and_grayscale_bit_exact(golden_aug_extra):
     assert np.array_equal(got, g["cutout_out"])
     assert np.array_equal(orc.random_grayscale_np(x / np.float32(255.0), g["gray01_mask"]), g["gray01_out"])
     assert np.array_equal(orc.random_grayscale_np(x, g["gray255_mask"]), g["gray255_out"])
+
+
+def test_splice_matches_callsite_golden(golden_aug_extra):
+    # parity unpinned for kornia's HSV arithmetic (kornia absent; restated): pins the call site and the mask logic
+    g = golden_aug_extra
+    x = gi.smooth_obs_u8(23, 4).astype(np.float32)
+    ov = gi.overlay_imgs(24, 4)
+    assert np.array_equal(orc.splice_np(x, ov), g["splice_out"])
+    assert np.array_equal(orc.splice_np(x, ov, val_thres=0.4), g["splice_easy_out"])
+    assert np.array_equal(orc.splice_np(x, ov, hue_thres=3.5, val_thres=0.0, cs=True), g["cs_splice_out"])
