@@ -300,7 +300,7 @@ struct Conv1Args {
 typedef __bf16 bf16x4k __attribute__((ext_vector_type(4)));
 
 template <int CH, bool OUT_BF16 = false> // CH*9 MFMA steps; OUT_BF16: write bf16 NHWC (perf mode) instead of f32 NCHW
-__global__ __launch_bounds__(256, 2) void k_conv_first(Conv1Args a)
+__global__ __launch_bounds__(256, 3) void k_conv_first(Conv1Args a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[]; // [2*CH][rows_in][Wi]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -614,7 +614,7 @@ struct Wgrad1Args {
 };
 
 template <int NT, bool BF16DZ = false>
-__global__ __launch_bounds__(256, 1) void k_wgrad_first(Wgrad1Args a)
+__global__ __launch_bounds__(256, (NT <= 3 ? 4 : NT <= 6 ? 2 : 1)) void k_wgrad_first(Wgrad1Args a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -776,6 +776,9 @@ using namespace augcl;
 namespace {
 
 constexpr int kMaxLds = 76 * 1024; // two workgroups per CU within the 160 KiB LDS
+constexpr int kFirstLds = 50 * 1024; // first-layer forward: three workgroups per CU
+constexpr int kWg1Lds = 37 * 1024;   // first-layer backward-weights: four workgroups per CU
+constexpr int kWg1PerCu = 4;
 constexpr int kBufLds = 78 * 1024; // one of the two tile buffers of a double-buffered, one-per-CU workgroup
 
 int pick_rt(int Ho, int words_per_row_pair /* LDS words per output row (all planes) */, int extra_rows,
@@ -872,7 +875,9 @@ static int conv_first_forward_impl(const float *in, const float *w, const float 
     a.Ho = (Hi - 3) / stride + 1; a.Wo = (Wi - 3) / stride + 1;
     const int CH = (C + 1) / 2;
     // LDS rows per strip: stride*(RT-1)+3 for 2*CH planes
-    int rt = (kMaxLds / 4 / (2 * CH * Wi) - 3) / stride + 1;
+    // three workgroups per CU (measured best: staging of one overlaps the MFMA loops of the others)
+    int rt = (kFirstLds / 4 / (2 * CH * Wi) - 3) / stride + 1;
+    if (rt < 1) rt = (kMaxLds / 4 / (2 * CH * Wi) - 3) / stride + 1;
     AUGCL_REQUIRE(rt >= 1, "%s: image row too wide for LDS", name);
     if (rt > a.Ho) rt = a.Ho;
     a.S = (a.Ho + rt - 1) / rt;
@@ -884,10 +889,10 @@ static int conv_first_forward_impl(const float *in, const float *w, const float 
     do {                                                                                                   \
         if (out_bf16) {                                                                                    \
             if (int rc = set_lds(k_conv_first<CHV, true>, lds, name)) return rc;                           \
-            hipLaunchKernelGGL((k_conv_first<CHV, true>), dim3(grid_for(a.n_items, 2)), dim3(256), lds, s, a); \
+            hipLaunchKernelGGL((k_conv_first<CHV, true>), dim3(grid_for(a.n_items, 3)), dim3(256), lds, s, a); \
         } else {                                                                                           \
             if (int rc = set_lds(k_conv_first<CHV, false>, lds, name)) return rc;                          \
-            hipLaunchKernelGGL((k_conv_first<CHV, false>), dim3(grid_for(a.n_items, 2)), dim3(256), lds, s, a); \
+            hipLaunchKernelGGL((k_conv_first<CHV, false>), dim3(grid_for(a.n_items, 3)), dim3(256), lds, s, a); \
         }                                                                                                  \
     } while (0)
     switch (CH) {
@@ -921,8 +926,10 @@ extern "C" int augcl_enc_bf16_conv_first_forward(const float *in, const float *w
 
 size_t augcl_enc_wgrad_workspace_bytes(int C)
 {
-    // slabs for up to 256 CUs x 1 workgroup + RG rows of the two-level reduction; C = input channels of the layer
-    return (size_t)(256 + 8) * ((size_t)32 * C * 9 + 32) * sizeof(float);
+    // slabs for up to 256 CUs x workgroups per CU (1 for the 32-channel layers, kWg1PerCu for a first layer) + RG
+    // rows of the two-level reduction; C = input channels of the layer
+    const size_t per_cu = C == 32 ? 1 : kWg1PerCu;
+    return (size_t)(256 * per_cu + 8) * ((size_t)32 * C * 9 + 32) * sizeof(float);
 }
 
 static int wgrad32_impl(const float *act_prev, const float *dz, float *dw, float *db, float *workspace,
@@ -994,9 +1001,15 @@ static int wgrad_first_impl(const float *x, const float *dz, float *dw, float *d
     a.x = x; a.dz = dz; a.partial = workspace;
     a.B = B; a.C = C; a.Hi = Hi; a.Wi = Wi; a.stride = stride; a.scale = scale;
     a.Ho = (Hi - 3) / stride + 1; a.Wo = (Wi - 3) / stride + 1;
-    const int budget = 150 * 1024;
-    // words: X planes C*(stride*(RT-1)+3)*Wi + Z planes 32*(RT*Wo|1)
-    int rt = (budget / 4 - 3 * C * Wi - 64) / (C * stride * Wi + 32 * a.Wo);
+    // words: X planes C*(stride*(RT-1)+3)*Wi + Z planes 32*(RT*Wo|1).  Four small workgroups per CU: the kernel
+    // stages and computes in turn, so co-resident workgroups are what overlaps the two (221 -> 132 us at B=512)
+    const int nt = (C * 9 + 31) / 32;
+    int per_cu = nt <= 3 ? kWg1PerCu : nt <= 6 ? 2 : 1; // matches the kernel's launch bounds (accumulator tiles)
+    int rt = (kWg1Lds * kWg1PerCu / per_cu / 4 - 3 * C * Wi - 64) / (C * stride * Wi + 32 * a.Wo);
+    if (rt < 1) {
+        per_cu = 1;
+        rt = (150 * 1024 / 4 - 3 * C * Wi - 64) / (C * stride * Wi + 32 * a.Wo);
+    }
     AUGCL_REQUIRE(rt >= 1, "%s: image row too wide for LDS", name);
     if (rt > a.Ho) rt = a.Ho;
     a.S = (a.Ho + rt - 1) / rt;
@@ -1008,7 +1021,7 @@ static int wgrad_first_impl(const float *x, const float *dz, float *dw, float *d
     size_t lds = (size_t)(C * planeX + 32 * planeZ) * 4;
     const size_t red = (size_t)((NT * 16 + 1) * 64) * 4;
     if (lds < red) lds = red;
-    const int grid = grid_for(a.n_items, 1);
+    const int grid = grid_for(a.n_items, per_cu);
     const int slab = 32 * K + 32;
     AUGCL_REQUIRE(workspace_bytes >= (size_t)(grid + RG) * slab * 4, "%s: workspace too small", name);
     hipStream_t s = as_stream(stream);
