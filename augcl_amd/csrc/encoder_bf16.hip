@@ -330,6 +330,9 @@ __device__ __forceinline__ s16x4 lds_tr(const char *p)
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)(p));
 }
 
+constexpr int WG_U = 18; // 16-byte chunks per loader lane per item: 256 lanes x 18 x 16 B = 72 KB
+typedef uint32_t vu4 __attribute__((ext_vector_type(4))); // native vector: prefetch arrays of it stay in registers
+
 __global__ __launch_bounds__(512, 2) void k_wgrad32_bf16(WgBfArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char ldsb[];
@@ -346,86 +349,120 @@ __global__ __launch_bounds__(512, 2) void k_wgrad32_bf16(WgBfArgs a)
     const int q = (lane & 15) >> 2, pp = lane & 3, cblk = (lane >> 4) & 1;
     const int colbyte = (16 * cblk + 4 * pp) * 2;
 
+    // ---- loader side.  One item's A + dZ chunks fit WG_U 16-byte loads per loader lane (the host sizes RT for it),
+    // so an item is ONE round of loads.  The loader runs two items ahead of the compute waves: item i is being
+    // read from LDS buffer i&1, item i+1 is written into the other buffer at the start of the iteration from
+    // registers whose loads were issued TWO iterations ago, and the loads of items i+2 / i+3 are in flight in the
+    // two register sets -- ~2 x 70 KB per CU always outstanding, which is what hides the HBM latency.
+    const int lt = cw * 64 + lane; // 0..255 among the loader threads
+    auto geom = [&](int item, const vu4 *&ga, const vu4 *&gz, int &na, int &nz) {
+        const int b = item / a.S, s = item - b * a.S;
+        const int y0 = s * a.RT;
+        const int rows = min(a.RT, a.Ho - y0);
+        na = (rows + 2) * Wi * 4; // 16-byte chunks
+        nz = rows * Wo * 4;
+        ga = reinterpret_cast<const vu4 *>(a.act) + ((size_t)(b * a.Hi + y0) * Wi) * 4;
+        gz = reinterpret_cast<const vu4 *>(a.dz) + ((size_t)(b * a.Ho + y0) * Wo) * 4;
+    };
+    auto issue = [&](int item, vu4(&v)[WG_U]) {
+        const vu4 *ga, *gz;
+        int na, nz;
+        geom(item, ga, gz, na, nz);
+#pragma unroll
+        for (int u = 0; u < WG_U; ++u) { // branch-free: the tail re-reads the last chunk
+            const int c = min(u * 256 + lt, na + nz - 1);
+            v[u] = c < na ? ga[c] : gz[c - na];
+        }
+    };
+    auto commit = [&](int item, int bi, const vu4(&v)[WG_U]) {
+        const vu4 *ga, *gz;
+        int na, nz;
+        geom(item, ga, gz, na, nz);
+        vu4 *da = reinterpret_cast<vu4 *>(ldsb + bi * bufbytes);
+#pragma unroll
+        for (int u = 0; u < WG_U; ++u) {
+            const int c = min(u * 256 + lt, na + nz - 1);
+            da[c < na ? c : apix * 4 + (c - na)] = v[u];
+        }
+        vu4 *dzl = da + apix * 4;
+        for (int c = nz + lt; c < zpix * 4; c += 256) dzl[c] = vu4{0u, 0u, 0u, 0u}; // zero the padded pixels
+    };
+    const int first = blockIdx.x, G = gridDim.x, n = a.n_items;
+    // The two roles run DIFFERENT code with the same barrier sequence (1 + one per item + 6): the branch is
+    // wave-uniform, and keeping the accumulators and the prefetch registers in separate branches keeps their
+    // live ranges apart (together they would not fit the register file).
+    if (loader) {
+        vu4 ra[WG_U], rb[WG_U];
+        if (first < n) {
+            issue(first, ra);
+            commit(first, 0, ra);
+        }
+        if (first + G < n) issue(first + G, ra);
+        if (first + 2 * G < n) issue(first + 2 * G, rb);
+        __syncthreads();
+        for (int item = first; item < n; item += 2 * G) {
+            if (item + G < n) commit(item + G, 1, ra); // even half: the compute waves read buffer 0
+            if (item + 3 * G < n) issue(item + 3 * G, ra);
+            __syncthreads();
+            if (item + G >= n) break;
+            if (item + 2 * G < n) commit(item + 2 * G, 0, rb); // odd half: they read buffer 1
+            if (item + 4 * G < n) issue(item + 4 * G, rb);
+            __syncthreads();
+        }
+        for (int w = 0; w < 6; ++w) __syncthreads(); // the compute waves' reduction barriers
+        return;
+    }
+
     f32x16 acc[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
     float dbacc = 0.0f;
-
-    auto stage = [&](int item, int bi) {
-        const int b = item / a.S, s = item - b * a.S;
-        const int y0 = s * a.RT;
-        const int rows = min(a.RT, a.Ho - y0);
-        const int na = (rows + 2) * Wi * 4, nz = rows * Wo * 4; // 16-byte chunks
-        const uint4 *ga = a.act + ((size_t)(b * a.Hi + y0) * Wi) * 4;
-        const uint4 *gz = a.dz + ((size_t)(b * a.Ho + y0) * Wo) * 4;
-        uint4 *da = reinterpret_cast<uint4 *>(ldsb + bi * bufbytes);
-        uint4 *dzl = da + apix * 4;
-        const int lt = cw * 64 + lane;
-        for (int c0 = 0; c0 < na; c0 += 256 * 6) {
-            uint4 v[6];
+    auto compute = [&](int item, int bi) {
+        const int s = item % a.S;
+        const int rows = min(a.RT, a.Ho - s * a.RT);
+        const int npix = rows * Wo;
+        const char *At = ldsb + bi * bufbytes;
+        const char *Zt = At + apix * 64;
+        const int nsteps = (npix + 15) >> 4;
+        for (int k = cw; k < nsteps; k += 4) { // 16 strip pixels per step; all 64 lanes stay active (tr reads)
+            s16x4 zf[2];
+            const char *pa[2];
 #pragma unroll
-            for (int u = 0; u < 6; ++u) v[u] = ga[min(c0 + u * 256 + lt, na - 1)];
+            for (int rd = 0; rd < 2; ++rd) {
+                const int m = 16 * k + 8 * h + 4 * rd + q; // the pixel whose row this lane supplies
+                zf[rd] = lds_tr(Zt + m * 64 + colbyte);
+                const int mc = min(m, npix - 1);             // padded pixels: dZ is zero, read any real activation
+                const int yy = mc / Wo, xx = mc - yy * Wo;
+                pa[rd] = At + (yy * Wi + xx) * 64 + colbyte;
+            }
+            const s16x8 zfrag = __builtin_shufflevector(zf[0], zf[1], 0, 1, 2, 3, 4, 5, 6, 7);
+            const bf16x8 za = __builtin_bit_cast(bf16x8, zfrag);
 #pragma unroll
-            for (int u = 0; u < 6; ++u) da[min(c0 + u * 256 + lt, na - 1)] = v[u];
-        }
-        for (int c0 = 0; c0 < nz; c0 += 256 * 6) {
-            uint4 v[6];
+            for (int j = 0; j < 8; ++j) dbacc += (float)za[j];
 #pragma unroll
-            for (int u = 0; u < 6; ++u) v[u] = gz[min(c0 + u * 256 + lt, nz - 1)];
+            for (int ky = 0; ky < 3; ++ky) { // one kernel row at a time keeps only 6 operand fragments live
+                s16x4 xf[3][2];
 #pragma unroll
-            for (int u = 0; u < 6; ++u) dzl[min(c0 + u * 256 + lt, nz - 1)] = v[u];
-        }
-        for (int c = nz + lt; c < zpix * 4; c += 256) dzl[c] = make_uint4(0u, 0u, 0u, 0u); // zero the padded pixels
-    };
-
-    int it = 0;
-    const int first = blockIdx.x;
-    if (loader && first < a.n_items) stage(first, 0);
-    __syncthreads();
-    for (int item = first; item < a.n_items; item += gridDim.x, ++it) {
-        const int next = item + gridDim.x;
-        if (loader) {
-            if (next < a.n_items) stage(next, (it + 1) & 1);
-        } else {
-            const int s = item % a.S;
-            const int rows = min(a.RT, a.Ho - s * a.RT);
-            const int npix = rows * Wo;
-            const char *At = ldsb + (it & 1) * bufbytes;
-            const char *Zt = At + apix * 64;
-            const int nsteps = (npix + 15) >> 4;
-            for (int k = cw; k < nsteps; k += 4) { // 16 strip pixels per step; all 64 lanes stay active (tr reads)
-                s16x4 zf[2];
-                const char *pa[2];
+                for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-                for (int rd = 0; rd < 2; ++rd) {
-                    const int m = 16 * k + 8 * h + 4 * rd + q; // the pixel whose row this lane supplies
-                    zf[rd] = lds_tr(Zt + m * 64 + colbyte);
-                    const int mc = min(m, npix - 1);             // padded pixels: dZ is zero, read any real activation
-                    const int yy = mc / Wo, xx = mc - yy * Wo;
-                    pa[rd] = At + (yy * Wi + xx) * 64 + colbyte;
-                }
-                const s16x8 zfrag = __builtin_shufflevector(zf[0], zf[1], 0, 1, 2, 3, 4, 5, 6, 7);
-                const bf16x8 za = __builtin_bit_cast(bf16x8, zfrag);
+                    for (int rd = 0; rd < 2; ++rd) xf[kx][rd] = lds_tr(pa[rd] + (ky * Wi + kx) * 64);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) dbacc += (float)za[j];
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky) { // one kernel row at a time keeps only 6 operand fragments live
-                    s16x4 xf[3][2];
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-                        for (int rd = 0; rd < 2; ++rd) xf[kx][rd] = lds_tr(pa[rd] + (ky * Wi + kx) * 64);
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        const s16x8 xfrag = __builtin_shufflevector(xf[kx][0], xf[kx][1], 0, 1, 2, 3, 4, 5, 6, 7);
-                        acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(za, __builtin_bit_cast(bf16x8, xfrag),
-                                                                                   acc[ky * 3 + kx], 0, 0, 0);
-                    }
+                for (int kx = 0; kx < 3; ++kx) {
+                    const s16x8 xfrag = __builtin_shufflevector(xf[kx][0], xf[kx][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                    acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(za, __builtin_bit_cast(bf16x8, xfrag),
+                                                                               acc[ky * 3 + kx], 0, 0, 0);
                 }
             }
         }
+    };
+    __syncthreads();
+    for (int item = first; item < n; item += 2 * G) {
+        compute(item, 0);
+        __syncthreads();
+        if (item + G >= n) break;
+        compute(item + G, 1);
         __syncthreads();
     }
     // ---- fixed-order reduction over the 4 compute waves through LDS, then one slab per workgroup
@@ -508,6 +545,8 @@ extern "C" int augcl_enc_bf16_conv32_backward_weights_mfma(const void *act_prev_
     a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ho = Hi - 2; a.Wo = Wi - 2;
     // per buffer: (RT+2)*Wi + roundup16(RT*Wo) pixels of 64 bytes
     int rt = (kBufBytes / 64 - 2 * Wi - 16) / (Wi + a.Wo);
+    const int rt_round = (256 * WG_U / 4 - 2 * Wi) / (Wi + a.Wo); // (RT+2)*Wi + RT*Wo pixels <= one round of loads
+    if (rt > rt_round) rt = rt_round;
     AUGCL_REQUIRE(rt >= 1, "%s: image row too wide for LDS", name);
     if (rt > a.Ho) rt = a.Ho;
     a.S = (a.Ho + rt - 1) / rt;
