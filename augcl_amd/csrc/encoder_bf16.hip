@@ -28,16 +28,26 @@ struct ConvBfArgs {
     const uint4 *mask;    // a_prev bf16 NHWC (B,Ho,Wo,32) or null [MODE 1]
     void *out;            // bf16 NHWC (B,Ho,Wo,32), or f32 NCHW (B,32,Ho,Wo) when out_f32
     int B, Hi, Wi, Ho, Wo, RT, S, relu, n_items, out_f32;
+    uint32_t magic_wi, magic_wo; // floor(2^32 / W) + 1: x / W == umulhi(x, magic) for the pixel counts used here
 };
 
-// LDS chunk address of (pixel p, logical chunk c): chunks of 4 neighbouring pixels are rotated against each
-// other so the 16 lanes of a ds_read_b128 group (consecutive pixels, one logical chunk) hit 16 distinct slots
-__device__ __forceinline__ int swz(int p, int c) { return p * 4 + (c ^ ((p >> 2) & 3)); }
+typedef uint32_t vu4 __attribute__((ext_vector_type(4))); // native vectors: register arrays of them stay in registers
+typedef float vf4 __attribute__((ext_vector_type(4)));
+constexpr int CV_U = 10;        // tile chunks (16 B) per loader lane per strip: 256 x 10 x 16 B = 40 KB
+constexpr int CV_MP = 3;        // backward-data: gate pixels per loader lane per strip (4 chunks each)
+constexpr int PIXB = 80;        // LDS bytes per pixel slot: 64 data + 16 pad.  16 consecutive pixels x one 16-byte
+                                // chunk then fall into 16 distinct bank quads (20 p mod 64), and every tap of a
+                                // tile is base + a constant: no per-read address arithmetic
+constexpr int WST_ROW = 292;    // weight staging row pitch in floats (16-byte aligned rows, conflict-free reads)
+constexpr int WST_BYTES = 32 * WST_ROW * 4;
 
+// MODE 0: forward (valid 3x3).  MODE 1: backward-data = full correlation of dZ with the flipped, transposed
+// weights; its LDS tile keeps every dZ row with 2 zero pixels in front (which double as the 2 behind the previous
+// row) and zero rows outside the image, so no tap needs masking.
 template <int MODE>
 __global__ __launch_bounds__(512, 2) void k_conv32_bf16(ConvBfArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) uint4 lds4[]; // 2 x [G + (RT+2)*Wi + G pixels][4 chunks] (+ gate words)
+    extern __shared__ __attribute__((aligned(16))) char ldsc[]; // 2 x {tile [(RT+2) rows][Wl pixels][80 B], gate words}
     constexpr int P = MODE ? 2 : 0;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -45,146 +55,249 @@ __global__ __launch_bounds__(512, 2) void k_conv32_bf16(ConvBfArgs a)
     const int cw = wave & 3;
     const int l31 = lane & 31, h = lane >> 5;
     const int Wi = a.Wi;
-    const int G = MODE ? ((2 * Wi + 2 + 3) & ~3) : 0;    // guard pixels (multiple of 4 keeps the swizzle phase)
-    const int tilepix = 2 * G + (a.RT + 2) * Wi;
+    const int Wl = MODE ? Wi + 2 : Wi;                     // LDS row pitch in pixels
+    const int tilepix = (a.RT + 2) * Wl + (MODE ? 2 : 0);
     const int gatew = MODE ? ((a.RT * a.Wo + 3) & ~3) : 0; // ReLU gate words (one uint32 per strip pixel)
-    const int bufchunks = tilepix * 4 + gatew / 4;
-    float *lbias = reinterpret_cast<float *>(lds4 + 2 * bufchunks);
+    const int bufbytes = tilepix * PIXB + gatew * 4;
+    float *lbias = reinterpret_cast<float *>(ldsc + max(2 * bufbytes, bufbytes + WST_BYTES));
+    const int first = blockIdx.x, NG = gridDim.x, n = a.n_items;
 
-    // ---- weights: A fragment of (tap t, channel half s): W_eff[row l31][k = 16s + 8h + j][t], j = 0..7
-    bf16x8 wfrag[18];
-    if (!loader) {
-#pragma unroll
-        for (int t = 0; t < 9; ++t)
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int k = 16 * s + 8 * h + j;
-                    const float wv = MODE == 0 ? a.w[((size_t)l31 * 32 + k) * 9 + t]        // W[co=l31][ci=k][t]
-                                               : a.w[((size_t)k * 32 + l31) * 9 + (8 - t)]; // W[co=k][ci=l31][8-t]
-                    wfrag[t * 2 + s][j] = (__bf16)wv;
-                }
+    // ---- weights: all 512 threads copy the 36 KB of f32 masters into LDS with coalesced 16-byte loads (the region
+    // of tile buffer 1, which is first written after the second barrier); the compute waves then pick their
+    // MFMA A-fragments out of LDS.  (Per-lane global gathers cost ~4 us per launch: 2304 cache lines per wave.)
+    {
+        float *wst = reinterpret_cast<float *>(ldsc + bufbytes);
+        const vf4 *w4 = reinterpret_cast<const vf4 *>(a.w);
+        for (int i = tid; i < 32 * 288 / 4; i += 512) {
+            const int row = (4 * i) / 288, col = 4 * i - row * 288;
+            *reinterpret_cast<vf4 *>(wst + row * WST_ROW + col) = w4[i];
+        }
+        if (tid < 32) lbias[tid] = (MODE == 0 && a.bias) ? a.bias[tid] : 0.0f;
     }
-    if (tid < 32) lbias[tid] = (MODE == 0 && a.bias) ? a.bias[tid] : 0.0f;
+    __syncthreads();
 
-    auto stage = [&](int item, int bi) {
+    // The two roles run DIFFERENT code with the same barrier sequence (2 + one per item): the branch is
+    // wave-uniform, and the separate branches keep the prefetch registers and the weight fragments apart.
+    if (loader) {
+        // One strip = ONE round of loads (the host sizes RT for it): CV_U tile chunks per lane, plus, for
+        // backward-data, the 4 chunks of CV_MP gate pixels.  The loader runs two strips ahead of the compute
+        // waves: strip i is read from LDS buffer i&1, strip i+1 is written into the other buffer from registers
+        // whose loads were issued two iterations ago, strips i+2 / i+3 are in flight in the two register sets.
+        const int lt = cw * 64 + lane; // 0..255 among the loader threads
+        struct Regs {
+            vu4 d[CV_U];
+            vu4 m[MODE ? CV_MP * 4 : 1];
+        };
+        struct Geo {
+            int rows, r0, r1, rbase, nchunk, npix;
+            const vu4 *src, *mp;
+        };
+        auto geom = [&](int item) {
+            Geo g;
+            const int b = item / a.S, s = item - b * a.S;
+            const int y0 = s * a.RT;
+            g.rows = min(a.RT, a.Ho - y0);
+            g.rbase = y0 - P;                                   // image row of tile row 0
+            g.r0 = MODE ? max(0, g.rbase) : y0;                 // image rows [r0, r1) exist
+            g.r1 = MODE ? min(a.Hi, y0 + g.rows) : y0 + g.rows + 2;
+            g.nchunk = (g.r1 - g.r0) * Wi * 4;
+            g.npix = g.rows * a.Wo;
+            g.src = reinterpret_cast<const vu4 *>(a.in) + ((size_t)(b * a.Hi + g.r0) * Wi) * 4;
+            g.mp = reinterpret_cast<const vu4 *>(a.mask) + ((size_t)(b * a.Ho + y0) * a.Wo) * 4;
+            return g;
+        };
+        auto issue = [&](int item, Regs &R) {
+            const Geo g = geom(item);
+#pragma unroll
+            for (int u = 0; u < CV_U; ++u) R.d[u] = g.src[min(u * 256 + lt, g.nchunk - 1)]; // branch-free (idempotent tail)
+            if (MODE == 1 && a.mask != nullptr) {
+#pragma unroll
+                for (int j = 0; j < CV_MP; ++j) {
+                    const int m = min(lt + 256 * j, g.npix - 1);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) R.m[j * 4 + c] = g.mp[(size_t)m * 4 + c];
+                }
+            }
+        };
+        auto commit = [&](int item, int bi, const Regs &R) {
+            const Geo g = geom(item);
+            char *dst = ldsc + bi * bufbytes;
+#pragma unroll
+            for (int u = 0; u < CV_U; ++u) {
+                const int q = min(u * 256 + lt, g.nchunk - 1);
+                int lp = q >> 2; // MODE 0: the tile is the contiguous run of rows
+                if (MODE == 1) {
+                    const int rr = (int)__umulhi((uint32_t)lp, a.magic_wi), x = lp - rr * Wi;
+                    lp = (rr + g.r0 - g.rbase) * Wl + x + 2;
+                }
+                *reinterpret_cast<vu4 *>(dst + lp * PIXB + (q & 3) * 16) = R.d[u];
+            }
+            if (MODE == 1) {
+                const vu4 zero = {0u, 0u, 0u, 0u};
+                // the 2 pad pixels in front of every tile row (and behind the last one)
+                for (int id = lt; id < (g.rows + 3) * 8; id += 256)
+                    *reinterpret_cast<vu4 *>(dst + ((id >> 3) * Wl + ((id >> 2) & 1)) * PIXB + (id & 3) * 16) = zero;
+                // tile rows above / below the image
+                const int top = g.r0 - g.rbase, bot = g.rbase + g.rows + 2 - g.r1, rowch = Wi * 4;
+                for (int id = lt; id < (top + bot) * rowch; id += 256) {
+                    const int jr = (int)__umulhi((uint32_t)(id >> 2), a.magic_wi), x = (id >> 2) - jr * Wi;
+                    const int j = jr < top ? jr : (g.r1 - g.rbase) + (jr - top);
+                    *reinterpret_cast<vu4 *>(dst + (j * Wl + x + 2) * PIXB + (id & 3) * 16) = zero;
+                }
+            }
+            if (MODE == 1 && a.mask != nullptr) { // ReLU gate bits of the layer below: word[m] bit co = a_prev[m][co] != 0
+                uint32_t *gw = reinterpret_cast<uint32_t *>(dst + tilepix * PIXB);
+#pragma unroll
+                for (int j = 0; j < CV_MP; ++j) {
+                    uint32_t wbits = 0;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const vu4 v = R.m[j * 4 + c];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { // two bf16 per dword; post-ReLU values are >= 0: gate = (x != 0)
+                            wbits |= ((v[e] & 0x7fffu) != 0 ? 1u : 0u) << (8 * c + 2 * e);
+                            wbits |= ((v[e] & 0x7fff0000u) != 0 ? 1u : 0u) << (8 * c + 2 * e + 1);
+                        }
+                    }
+                    gw[min(lt + 256 * j, g.npix - 1)] = wbits;
+                }
+            }
+        };
+        Regs ra, rb;
+        if (first < n) {
+            issue(first, ra);
+            commit(first, 0, ra);
+        }
+        if (first + NG < n) issue(first + NG, ra);
+        if (first + 2 * NG < n) issue(first + 2 * NG, rb);
+        __syncthreads();
+        for (int item = first; item < n; item += 2 * NG) {
+            if (item + NG < n) commit(item + NG, 1, ra); // even half: the compute waves read buffer 0
+            if (item + 3 * NG < n) issue(item + 3 * NG, ra);
+            __syncthreads();
+            if (item + NG >= n) break;
+            if (item + 2 * NG < n) commit(item + 2 * NG, 0, rb); // odd half: they read buffer 1
+            if (item + 4 * NG < n) issue(item + 4 * NG, rb);
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ---- compute waves.  A fragment of (tap t, channel half s): W_eff[row l31][k = 16s + 8h + j][t], j = 0..7
+    bf16x8 wfrag[18];
+    {
+        const float *wst = reinterpret_cast<const float *>(ldsc + bufbytes);
+        if (MODE == 0) { // W[co = l31][ci = k][t]: 72 contiguous floats per channel half
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                vf4 tmp[18];
+                const vf4 *src = reinterpret_cast<const vf4 *>(wst + l31 * WST_ROW + (16 * s + 8 * h) * 9);
+#pragma unroll
+                for (int v = 0; v < 18; ++v) tmp[v] = src[v];
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) wfrag[t * 2 + s][j] = (__bf16)tmp[(j * 9 + t) >> 2][(j * 9 + t) & 3];
+            }
+        } else { // W[co = k][ci = l31][8 - t]
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        wfrag[t * 2 + s][j] = (__bf16)wst[(16 * s + 8 * h + j) * WST_ROW + l31 * 9 + (8 - t)];
+        }
+    }
+    const int rowb = Wl * PIXB; // LDS bytes between tile rows
+    auto compute = [&](int item, int bi) {
         const int b = item / a.S, s = item - b * a.S;
         const int y0 = s * a.RT;
         const int rows = min(a.RT, a.Ho - y0);
-        const int r0 = MODE ? max(0, y0 - P) : y0;
-        const int r1 = MODE ? min(a.Hi, y0 + rows) : y0 + rows + 2;
-        const int nchunk = (r1 - r0) * Wi * 4;
-        const uint4 *src = a.in + ((size_t)(b * a.Hi + r0) * Wi) * 4;
-        uint4 *dst = lds4 + bi * bufchunks;
-        const int lt = cw * 64 + lane; // 0..255 among the loader threads
-        for (int c0 = 0; c0 < nchunk; c0 += 256 * 10) {
-            uint4 v[10];
+        const int npix = rows * a.Wo;
+        const char *tile = ldsc + bi * bufbytes;
+        const uint32_t *gatebits = reinterpret_cast<const uint32_t *>(tile + tilepix * PIXB);
+        const int ntiles = (npix + 31) >> 5;
+        if (cw >= ntiles) return; // wave-uniform
+        // this lane's pixel of tile tl: index m in the strip, (yy, xx), and the LDS byte of its top-left tap
+        // (both modes: tile row yy + ky, tile pixel xx + kx -- backward-data's +2 shift cancels its -2 taps)
+        auto locate = [&](int tl, int &m_, bool &valid_, int &yy_, int &xx_, int &off_) {
+            m_ = tl * 32 + l31;
+            valid_ = m_ < npix;
+            if (!valid_) m_ = npix - 1;
+            yy_ = (int)__umulhi((uint32_t)m_, a.magic_wo);
+            xx_ = m_ - yy_ * a.Wo;
+            off_ = (yy_ * Wl + xx_) * PIXB + h * 16;
+        };
+        // operand i = (tap t = i/2, channel half s2 = i&1): one ds_read_b128 at row base + constant.  The 18 reads
+        // of a tile run NINE MFMAs ahead of their use, across tile boundaries (an MFMA never waits for LDS).
+        auto rd = [&](int off_, int i) {
+            const int t = i >> 1;
+            return *reinterpret_cast<const vu4 *>(tile + off_ + (t / 3) * rowb + ((t % 3) * PIXB + (i & 1) * 32));
+        };
+        int m, yy, xx, off;
+        bool valid;
+        locate(cw, m, valid, yy, xx, off);
+        vu4 raw[18];
 #pragma unroll
-            for (int u = 0; u < 10; ++u) v[u] = src[min(c0 + u * 256 + lt, nchunk - 1)]; // branch-free (idempotent tail)
+        for (int i = 0; i < 9; ++i) raw[i] = rd(off, i);
+        for (int tl = cw; tl < ntiles; tl += 4) {
+            int m2, yy2, xx2, off2;
+            bool valid2;
+            locate(tl + 4 < ntiles ? tl + 4 : tl, m2, valid2, yy2, xx2, off2); // no next tile: re-read this one
+            f32x16 acc;
 #pragma unroll
-            for (int u = 0; u < 10; ++u) {
-                const int q = min(c0 + u * 256 + lt, nchunk - 1);
-                dst[swz(G + (q >> 2), q & 3)] = v[u];
+            for (int r = 0; r < 16; ++r) acc[r] = lbias[acc_row_b(r, h)];
+#pragma unroll
+            for (int i = 0; i < 18; ++i) {
+                if (i < 9) raw[i + 9] = rd(off, i + 9);
+                else raw[i - 9] = rd(off2, i - 9);
+                __builtin_amdgcn_sched_barrier(0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfrag[i], __builtin_bit_cast(bf16x8, raw[i]), acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
-        }
-        if (MODE == 1 && a.mask != nullptr) { // ReLU gate bits of the layer below: word[m] bit co = a_prev[m][co] != 0
-            uint32_t *gw = reinterpret_cast<uint32_t *>(dst + tilepix * 4);
-            const int npix = rows * a.Wo;
-            const uint4 *mp = a.mask + ((size_t)(b * a.Ho + y0) * a.Wo) * 4;
-            for (int m = lt; m < npix; m += 256) {
-                uint32_t wbits = 0;
+            if (valid) {
+                const int y = y0 + yy;
+                uint32_t gate = 0xffffffffu;
+                if (MODE == 1 && a.mask) gate = gatebits[m];
+                if (a.out_f32) { // last layer: f32 NCHW for the projection
+                    float *o = reinterpret_cast<float *>(a.out);
+                    const int chw = a.Ho * a.Wo;
+                    const int o0 = (b * 32 * a.Ho + y) * a.Wo + xx;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const uint4 v = mp[(size_t)m * 4 + c];
-                    const uint32_t d[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { // two bf16 per dword; post-ReLU values are >= 0: gate = (x != 0)
-                        wbits |= ((d[e] & 0x7fffu) != 0 ? 1u : 0u) << (8 * c + 2 * e);
-                        wbits |= ((d[e] & 0x7fff0000u) != 0 ? 1u : 0u) << (8 * c + 2 * e + 1);
+                    for (int r = 0; r < 16; ++r) {
+                        const int co = acc_row_b(r, h);
+                        float v = acc[r];
+                        if (MODE == 0 && a.relu) v = fmaxf(v, 0.0f);
+                        if (MODE == 1) v = ((gate >> co) & 1u) ? v : 0.0f;
+                        o[o0 + co * chw] = v;
                     }
-                }
-                gw[m] = wbits;
-            }
-        }
-    };
-
-    int it = 0;
-    const int first = blockIdx.x;
-    if (loader && first < a.n_items) stage(first, 0);
-    __syncthreads();
-    for (int item = first; item < a.n_items; item += gridDim.x, ++it) {
-        const int next = item + gridDim.x;
-        if (loader) {
-            if (next < a.n_items) stage(next, (it + 1) & 1);
-        } else {
-            const int b = item / a.S, s = item - b * a.S;
-            const int y0 = s * a.RT;
-            const int rows = min(a.RT, a.Ho - y0);
-            const int npix = rows * a.Wo;
-            const int r0 = MODE ? max(0, y0 - P) : y0;
-            const uint4 *tile = lds4 + (it & 1) * bufchunks;
-            const uint32_t *gatebits = reinterpret_cast<const uint32_t *>(tile + tilepix * 4);
-            const int ntiles = (npix + 31) >> 5;
-            for (int tl = cw; tl < ntiles; tl += 4) {
-                int m = tl * 32 + l31;
-                const bool valid = m < npix;
-                if (!valid) m = npix - 1;
-                const int yy = m / a.Wo, xx = m - yy * a.Wo;
-                const int p0 = G + (y0 + yy - P - r0) * Wi + (xx - P); // top-left tap (in the guard for masked taps)
-                f32x16 acc;
+                } else { // bf16 NHWC: 4 x (4 consecutive channels = 8 bytes) per lane
+                    bf16x4 *o = reinterpret_cast<bf16x4 *>(a.out) + ((size_t)(b * a.Ho + y) * a.Wo + xx) * 8;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = lbias[acc_row_b(r, h)];
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        bf16x4 pk;
 #pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const int ky = t / 3, kx = t % 3;
-                    const int p = p0 + ky * Wi + kx;
-                    bool ok = true;
-                    if (MODE == 1)
-                        ok = ((unsigned)(y0 + yy + ky - P) < (unsigned)a.Hi) && ((unsigned)(xx + kx - P) < (unsigned)Wi);
-#pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2) {
-                        uint4 raw = tile[swz(p, 2 * s2 + h)];
-                        if (MODE == 1 && !ok) raw = make_uint4(0u, 0u, 0u, 0u);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfrag[t * 2 + s2], __builtin_bit_cast(bf16x8, raw), acc,
-                                                                      0, 0, 0);
-                    }
-                }
-                if (valid) {
-                    const int y = y0 + yy;
-                    uint32_t gate = 0xffffffffu;
-                    if (MODE == 1 && a.mask) gate = gatebits[m];
-                    if (a.out_f32) { // last layer: f32 NCHW for the projection
-                        float *o = reinterpret_cast<float *>(a.out);
-                        const int chw = a.Ho * a.Wo;
-                        const int o0 = (b * 32 * a.Ho + y) * a.Wo + xx;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int co = acc_row_b(r, h);
-                            float v = acc[r];
+                        for (int e = 0; e < 4; ++e) {
+                            float v = acc[g4 * 4 + e];
+                            const int co = 8 * g4 + 4 * h + e;
                             if (MODE == 0 && a.relu) v = fmaxf(v, 0.0f);
                             if (MODE == 1) v = ((gate >> co) & 1u) ? v : 0.0f;
-                            o[o0 + co * chw] = v;
+                            pk[e] = (__bf16)v;
                         }
-                    } else { // bf16 NHWC: 4 x (4 consecutive channels = 8 bytes) per lane
-                        bf16x4 *o = reinterpret_cast<bf16x4 *>(a.out) + ((size_t)(b * a.Ho + y) * a.Wo + xx) * 8;
-#pragma unroll
-                        for (int g4 = 0; g4 < 4; ++g4) {
-                            bf16x4 pk;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                float v = acc[g4 * 4 + e];
-                                const int co = 8 * g4 + 4 * h + e;
-                                if (MODE == 0 && a.relu) v = fmaxf(v, 0.0f);
-                                if (MODE == 1) v = ((gate >> co) & 1u) ? v : 0.0f;
-                                pk[e] = (__bf16)v;
-                            }
-                            o[2 * g4 + h] = pk;
-                        }
+                        o[2 * g4 + h] = pk;
                     }
                 }
             }
+            m = m2; valid = valid2; yy = yy2; xx = xx2; off = off2;
         }
+    };
+    __syncthreads();
+    for (int item = first; item < n; item += 2 * NG) {
+        compute(item, 0);
+        __syncthreads();
+        if (item + NG >= n) break;
+        compute(item + NG, 1);
         __syncthreads();
     }
 }
@@ -227,11 +340,15 @@ int cu_count_bf()
 template <int MODE>
 int launch_conv_bf16(ConvBfArgs &a, const char *name, hipStream_t s)
 {
+    using namespace augcl;
     const int Wi = a.Wi;
-    const int G = MODE ? ((2 * Wi + 2 + 3) & ~3) : 0;
-    // bytes per output row: Wi pixels x 64 B (+ 4 B gate word per output pixel); 2 halo rows + 2 guards
-    const int per_row = Wi * 64 + (MODE ? a.Wo * 4 : 0);
-    int rt = (kBufBytes - 2 * G * 64 - 2 * Wi * 64 - 64) / per_row;
+    const int Wl = MODE ? Wi + 2 : Wi;
+    // LDS per output row: Wl pixel slots of 80 B (+ 4 B gate word per output pixel); 2 halo rows
+    const int per_row = Wl * PIXB + (MODE ? a.Wo * 4 : 0);
+    int rt = (kBufBytes - 2 * Wl * PIXB - 2 * PIXB - 16) / per_row;
+    // a strip is one round of loader loads: (RT+2)*Wi pixels <= 64*CV_U, RT*Wo gate pixels <= 256*CV_MP
+    rt = std::min(rt, 64 * CV_U / Wi - 2);
+    if (MODE) rt = std::min(rt, 256 * CV_MP / a.Wo);
     if (rt < 1) return augcl::fail(AUGCL_E_UNSUPPORTED, "%s: image row too wide for LDS (W=%d)", name, Wi);
     if (rt > a.Ho) rt = a.Ho;
     a.S = (a.Ho + rt - 1) / rt;
@@ -241,9 +358,12 @@ int launch_conv_bf16(ConvBfArgs &a, const char *name, hipStream_t s)
     a.RT = (a.Ho + a.S - 1) / a.S;
     a.S = (a.Ho + a.RT - 1) / a.RT;
     a.n_items = a.B * a.S;
-    const int tilepix = 2 * G + (a.RT + 2) * Wi;
+    a.magic_wi = (uint32_t)(0x100000000ull / (unsigned)Wi) + 1u;
+    a.magic_wo = (uint32_t)(0x100000000ull / (unsigned)a.Wo) + 1u;
+    const int tilepix = (a.RT + 2) * Wl + (MODE ? 2 : 0);
     const int gatew = MODE ? ((a.RT * a.Wo + 3) & ~3) : 0;
-    const size_t lds = (size_t)2 * (tilepix * 64 + gatew * 4) + 32 * 4;
+    const int bufbytes = tilepix * PIXB + gatew * 4;
+    const size_t lds = (size_t)std::max(2 * bufbytes, bufbytes + WST_BYTES) + 32 * 4;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv32_bf16<MODE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return augcl::fail(AUGCL_E_LAUNCH, "%s: cannot set dynamic LDS %zu: %s", name, lds, hipGetErrorString(e));
@@ -262,7 +382,7 @@ int augcl_enc_bf16_conv32_forward(const void *in_bf16_nhwc, const float *w, cons
     AUGCL_REQUIRE(B >= 0 && Hi >= 3 && Wi >= 3, "%s: bad shape", name);
     if (B == 0) return AUGCL_OK;
     AUGCL_REQUIRE(in_bf16_nhwc && w && out, "%s: null tensor", name);
-    AUGCL_REQUIRE(aligned16(in_bf16_nhwc) && aligned16(out), "%s: tensors must be 16-byte aligned", name);
+    AUGCL_REQUIRE(aligned16(in_bf16_nhwc) && aligned16(out) && aligned16(w), "%s: tensors must be 16-byte aligned", name);
     AUGCL_REQUIRE((size_t)B * 32 * Hi * Wi < ((size_t)1 << 31), "%s: tensor too large for 32-bit offsets", name);
     ConvBfArgs a{};
     a.in = reinterpret_cast<const uint4 *>(in_bf16_nhwc); a.w = w; a.bias = bias; a.mask = nullptr; a.out = out;
@@ -277,7 +397,7 @@ int augcl_enc_bf16_conv32_backward_data(const void *dz_bf16_nhwc, const float *w
     AUGCL_REQUIRE(B >= 0 && Ho >= 1 && Wo >= 1, "%s: bad shape", name);
     if (B == 0) return AUGCL_OK;
     AUGCL_REQUIRE(dz_bf16_nhwc && w && dact_bf16_nhwc, "%s: null tensor", name);
-    AUGCL_REQUIRE(aligned16(dz_bf16_nhwc) && aligned16(dact_bf16_nhwc) && aligned16(act_prev_bf16_nhwc),
+    AUGCL_REQUIRE(aligned16(dz_bf16_nhwc) && aligned16(dact_bf16_nhwc) && aligned16(act_prev_bf16_nhwc) && aligned16(w),
                   "%s: tensors must be 16-byte aligned", name);
     AUGCL_REQUIRE((size_t)B * 32 * (Ho + 2) * (Wo + 2) < ((size_t)1 << 31), "%s: tensor too large", name);
     ConvBfArgs a{};
@@ -331,7 +451,6 @@ __device__ __forceinline__ s16x4 lds_tr(const char *p)
 }
 
 constexpr int WG_U = 18; // 16-byte chunks per loader lane per item: 256 lanes x 18 x 16 B = 72 KB
-typedef uint32_t vu4 __attribute__((ext_vector_type(4))); // native vector: prefetch arrays of it stay in registers
 
 __global__ __launch_bounds__(512, 2) void k_wgrad32_bf16(WgBfArgs a)
 {
