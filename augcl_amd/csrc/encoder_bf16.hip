@@ -34,7 +34,6 @@ struct ConvBfArgs {
 typedef uint32_t vu4 __attribute__((ext_vector_type(4))); // native vectors: register arrays of them stay in registers
 typedef float vf4 __attribute__((ext_vector_type(4)));
 constexpr int CV_U = 10;        // tile chunks (16 B) per loader lane per strip: 256 x 10 x 16 B = 40 KB
-constexpr int CV_MP = 3;        // backward-data: gate pixels per loader lane per strip (4 chunks each)
 constexpr int PIXB = 80;        // LDS bytes per pixel slot: 64 data + 16 pad.  16 consecutive pixels x one 16-byte
                                 // chunk then fall into 16 distinct bank quads (20 p mod 64), and every tap of a
                                 // tile is base + a constant: no per-read address arithmetic
@@ -44,7 +43,11 @@ constexpr int WST_BYTES = 32 * WST_ROW * 4;
 // MODE 0: forward (valid 3x3).  MODE 1: backward-data = full correlation of dZ with the flipped, transposed
 // weights; its LDS tile keeps every dZ row with 2 zero pixels in front (which double as the 2 behind the previous
 // row) and zero rows outside the image, so no tap needs masking.
-template <int MODE>
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t vu2 __attribute__((ext_vector_type(2)));
+
+template <int MODE, bool RELU, bool OUT_F32>
 __global__ __launch_bounds__(512, 2) void k_conv32_bf16(ConvBfArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char ldsc[]; // 2 x {tile [(RT+2) rows][Wl pixels][80 B], gate words}
@@ -57,8 +60,7 @@ __global__ __launch_bounds__(512, 2) void k_conv32_bf16(ConvBfArgs a)
     const int Wi = a.Wi;
     const int Wl = MODE ? Wi + 2 : Wi;                     // LDS row pitch in pixels
     const int tilepix = (a.RT + 2) * Wl + (MODE ? 2 : 0);
-    const int gatew = MODE ? ((a.RT * a.Wo + 3) & ~3) : 0; // ReLU gate words (one uint32 per strip pixel)
-    const int bufbytes = tilepix * PIXB + gatew * 4;
+    const int bufbytes = tilepix * PIXB;
     float *lbias = reinterpret_cast<float *>(ldsc + max(2 * bufbytes, bufbytes + WST_BYTES));
     const int first = blockIdx.x, NG = gridDim.x, n = a.n_items;
 
@@ -79,18 +81,17 @@ __global__ __launch_bounds__(512, 2) void k_conv32_bf16(ConvBfArgs a)
     // The two roles run DIFFERENT code with the same barrier sequence (2 + one per item): the branch is
     // wave-uniform, and the separate branches keep the prefetch registers and the weight fragments apart.
     if (loader) {
-        // One strip = ONE round of loads (the host sizes RT for it): CV_U tile chunks per lane, plus, for
-        // backward-data, the 4 chunks of CV_MP gate pixels.  The loader runs two strips ahead of the compute
+        // One strip = ONE round of loads (the host sizes RT for it): CV_U tile chunks per lane.
+        // The loader runs two strips ahead of the compute
         // waves: strip i is read from LDS buffer i&1, strip i+1 is written into the other buffer from registers
         // whose loads were issued two iterations ago, strips i+2 / i+3 are in flight in the two register sets.
         const int lt = cw * 64 + lane; // 0..255 among the loader threads
         struct Regs {
             vu4 d[CV_U];
-            vu4 m[MODE ? CV_MP * 4 : 1];
         };
         struct Geo {
-            int rows, r0, r1, rbase, nchunk, npix;
-            const vu4 *src, *mp;
+            int rows, r0, r1, rbase, nchunk;
+            const vu4 *src;
         };
         auto geom = [&](int item) {
             Geo g;
@@ -101,23 +102,13 @@ __global__ __launch_bounds__(512, 2) void k_conv32_bf16(ConvBfArgs a)
             g.r0 = MODE ? max(0, g.rbase) : y0;                 // image rows [r0, r1) exist
             g.r1 = MODE ? min(a.Hi, y0 + g.rows) : y0 + g.rows + 2;
             g.nchunk = (g.r1 - g.r0) * Wi * 4;
-            g.npix = g.rows * a.Wo;
             g.src = reinterpret_cast<const vu4 *>(a.in) + ((size_t)(b * a.Hi + g.r0) * Wi) * 4;
-            g.mp = reinterpret_cast<const vu4 *>(a.mask) + ((size_t)(b * a.Ho + y0) * a.Wo) * 4;
             return g;
         };
         auto issue = [&](int item, Regs &R) {
             const Geo g = geom(item);
 #pragma unroll
             for (int u = 0; u < CV_U; ++u) R.d[u] = g.src[min(u * 256 + lt, g.nchunk - 1)]; // branch-free (idempotent tail)
-            if (MODE == 1 && a.mask != nullptr) {
-#pragma unroll
-                for (int j = 0; j < CV_MP; ++j) {
-                    const int m = min(lt + 256 * j, g.npix - 1);
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) R.m[j * 4 + c] = g.mp[(size_t)m * 4 + c];
-                }
-            }
         };
         auto commit = [&](int item, int bi, const Regs &R) {
             const Geo g = geom(item);
@@ -143,23 +134,6 @@ __global__ __launch_bounds__(512, 2) void k_conv32_bf16(ConvBfArgs a)
                     const int jr = (int)__umulhi((uint32_t)(id >> 2), a.magic_wi), x = (id >> 2) - jr * Wi;
                     const int j = jr < top ? jr : (g.r1 - g.rbase) + (jr - top);
                     *reinterpret_cast<vu4 *>(dst + (j * Wl + x + 2) * PIXB + (id & 3) * 16) = zero;
-                }
-            }
-            if (MODE == 1 && a.mask != nullptr) { // ReLU gate bits of the layer below: word[m] bit co = a_prev[m][co] != 0
-                uint32_t *gw = reinterpret_cast<uint32_t *>(dst + tilepix * PIXB);
-#pragma unroll
-                for (int j = 0; j < CV_MP; ++j) {
-                    uint32_t wbits = 0;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const vu4 v = R.m[j * 4 + c];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { // two bf16 per dword; post-ReLU values are >= 0: gate = (x != 0)
-                            wbits |= ((v[e] & 0x7fffu) != 0 ? 1u : 0u) << (8 * c + 2 * e);
-                            wbits |= ((v[e] & 0x7fff0000u) != 0 ? 1u : 0u) << (8 * c + 2 * e + 1);
-                        }
-                    }
-                    gw[min(lt + 256 * j, g.npix - 1)] = wbits;
                 }
             }
         };
@@ -210,13 +184,15 @@ __global__ __launch_bounds__(512, 2) void k_conv32_bf16(ConvBfArgs a)
         }
     }
     const int rowb = Wl * PIXB; // LDS bytes between tile rows
+    f32x16 bias16; // accumulator seed: the first MFMA of a tile takes it as its C operand (no per-tile copies)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bias16[r] = lbias[acc_row_b(r, h)];
     auto compute = [&](int item, int bi) {
         const int b = item / a.S, s = item - b * a.S;
         const int y0 = s * a.RT;
         const int rows = min(a.RT, a.Ho - y0);
         const int npix = rows * a.Wo;
         const char *tile = ldsc + bi * bufbytes;
-        const uint32_t *gatebits = reinterpret_cast<const uint32_t *>(tile + tilepix * PIXB);
         const int ntiles = (npix + 31) >> 5;
         if (cw >= ntiles) return; // wave-uniform
         // this lane's pixel of tile tl: index m in the strip, (yy, xx), and the LDS byte of its top-left tap
@@ -245,47 +221,59 @@ __global__ __launch_bounds__(512, 2) void k_conv32_bf16(ConvBfArgs a)
             int m2, yy2, xx2, off2;
             bool valid2;
             locate(tl + 4 < ntiles ? tl + 4 : tl, m2, valid2, yy2, xx2, off2); // no next tile: re-read this one
-            f32x16 acc;
+            // backward-data: the ReLU gate of the layer below is (a_prev != 0); this lane's 16 channels of its pixel
+            // are 4 x 8 bytes of a_prev, fetched now and used after the MFMAs
+            vu2 gsrc[4];
+            if (MODE == 1 && a.mask != nullptr) {
+                const vu2 *gp = reinterpret_cast<const vu2 *>(a.mask) + ((size_t)(b * a.Ho + y0 + yy) * a.Wo + xx) * 8 + h;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = lbias[acc_row_b(r, h)];
+                for (int g4 = 0; g4 < 4; ++g4) gsrc[g4] = gp[2 * g4];
+            }
+            f32x16 acc;
 #pragma unroll
             for (int i = 0; i < 18; ++i) {
                 if (i < 9) raw[i + 9] = rd(off, i + 9);
                 else raw[i - 9] = rd(off2, i - 9);
                 __builtin_amdgcn_sched_barrier(0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfrag[i], __builtin_bit_cast(bf16x8, raw[i]), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfrag[i], __builtin_bit_cast(bf16x8, raw[i]),
+                                                              i == 0 ? bias16 : acc, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (valid) {
                 const int y = y0 + yy;
-                uint32_t gate = 0xffffffffu;
-                if (MODE == 1 && a.mask) gate = gatebits[m];
-                if (a.out_f32) { // last layer: f32 NCHW for the projection
-                    float *o = reinterpret_cast<float *>(a.out);
+                if (OUT_F32) { // last layer: f32 NCHW for the projection
+                    float *o = reinterpret_cast<float *>(a.out) + ((size_t)(b * 32) * a.Ho + y) * a.Wo + xx;
                     const int chw = a.Ho * a.Wo;
-                    const int o0 = (b * 32 * a.Ho + y) * a.Wo + xx;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int co = acc_row_b(r, h);
                         float v = acc[r];
-                        if (MODE == 0 && a.relu) v = fmaxf(v, 0.0f);
-                        if (MODE == 1) v = ((gate >> co) & 1u) ? v : 0.0f;
-                        o[o0 + co * chw] = v;
+                        if (RELU) v = v > 0.0f ? v : 0.0f;
+                        if (MODE == 1 && a.mask != nullptr) {
+                            const uint32_t d = gsrc[r >> 2][(r >> 1) & 1];
+                            v = ((r & 1) ? (d >> 16) & 0x7fffu : (d & 0x7fffu)) != 0 ? v : 0.0f;
+                        }
+                        o[acc_row_b(r, h) * chw] = v;
                     }
                 } else { // bf16 NHWC: 4 x (4 consecutive channels = 8 bytes) per lane
-                    bf16x4 *o = reinterpret_cast<bf16x4 *>(a.out) + ((size_t)(b * a.Ho + y) * a.Wo + xx) * 8;
+                    vu2 *o = reinterpret_cast<vu2 *>(a.out) + ((size_t)(b * a.Ho + y) * a.Wo + xx) * 8 + h;
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4) {
-                        bf16x4 pk;
+                        vu2 pk;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float v = acc[g4 * 4 + e];
-                            const int co = 8 * g4 + 4 * h + e;
-                            if (MODE == 0 && a.relu) v = fmaxf(v, 0.0f);
-                            if (MODE == 1) v = ((gate >> co) & 1u) ? v : 0.0f;
-                            pk[e] = (__bf16)v;
+                        for (int d = 0; d < 2; ++d) {
+                            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+                            typedef float f32x2 __attribute__((ext_vector_type(2)));
+                            const bf16x2 two = __builtin_convertvector(f32x2{acc[g4 * 4 + 2 * d], acc[g4 * 4 + 2 * d + 1]}, bf16x2);
+                            uint32_t bits = __builtin_bit_cast(uint32_t, two);
+                            if (RELU) // bf16 pairs as signed 16-bit integers: negative values (sign bit) -> 0
+                                bits = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, bits), s16x2{0, 0}));
+                            if (MODE == 1 && a.mask != nullptr) { // keep where a_prev != 0: x * min(a_prev bits, 1)
+                                const u16x2 keep = __builtin_elementwise_min(__builtin_bit_cast(u16x2, gsrc[g4][d] & 0x7fff7fffu), u16x2{1, 1}); // -0 counts as 0
+                                bits = __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, bits) * keep));
+                            }
+                            pk[d] = bits;
                         }
-                        o[2 * g4 + h] = pk;
+                        o[2 * g4] = pk;
                     }
                 }
             }
@@ -337,18 +325,17 @@ int cu_count_bf()
     return v;
 }
 
-template <int MODE>
-int launch_conv_bf16(ConvBfArgs &a, const char *name, hipStream_t s)
+template <int MODE, bool RELU, bool OUT_F32>
+int launch_conv_bf16_t(ConvBfArgs &a, const char *name, hipStream_t s)
 {
     using namespace augcl;
     const int Wi = a.Wi;
     const int Wl = MODE ? Wi + 2 : Wi;
-    // LDS per output row: Wl pixel slots of 80 B (+ 4 B gate word per output pixel); 2 halo rows
-    const int per_row = Wl * PIXB + (MODE ? a.Wo * 4 : 0);
+    // LDS per output row: Wl pixel slots of 80 B; 2 halo rows
+    const int per_row = Wl * PIXB;
     int rt = (kBufBytes - 2 * Wl * PIXB - 2 * PIXB - 16) / per_row;
-    // a strip is one round of loader loads: (RT+2)*Wi pixels <= 64*CV_U, RT*Wo gate pixels <= 256*CV_MP
+    // a strip is one round of loader loads: (RT+2)*Wi pixels <= 64*CV_U
     rt = std::min(rt, 64 * CV_U / Wi - 2);
-    if (MODE) rt = std::min(rt, 256 * CV_MP / a.Wo);
     if (rt < 1) return augcl::fail(AUGCL_E_UNSUPPORTED, "%s: image row too wide for LDS (W=%d)", name, Wi);
     if (rt > a.Ho) rt = a.Ho;
     a.S = (a.Ho + rt - 1) / rt;
@@ -361,15 +348,22 @@ int launch_conv_bf16(ConvBfArgs &a, const char *name, hipStream_t s)
     a.magic_wi = (uint32_t)(0x100000000ull / (unsigned)Wi) + 1u;
     a.magic_wo = (uint32_t)(0x100000000ull / (unsigned)a.Wo) + 1u;
     const int tilepix = (a.RT + 2) * Wl + (MODE ? 2 : 0);
-    const int gatew = MODE ? ((a.RT * a.Wo + 3) & ~3) : 0;
-    const int bufbytes = tilepix * PIXB + gatew * 4;
+    const int bufbytes = tilepix * PIXB;
     const size_t lds = (size_t)std::max(2 * bufbytes, bufbytes + WST_BYTES) + 32 * 4;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv32_bf16<MODE>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv32_bf16<MODE, RELU, OUT_F32>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return augcl::fail(AUGCL_E_LAUNCH, "%s: cannot set dynamic LDS %zu: %s", name, lds, hipGetErrorString(e));
     const int grid = a.n_items < cus ? a.n_items : cus;
-    hipLaunchKernelGGL(k_conv32_bf16<MODE>, dim3(grid), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((k_conv32_bf16<MODE, RELU, OUT_F32>), dim3(grid), dim3(512), lds, s, a);
     return augcl::check_launch(name);
+}
+
+template <int MODE>
+int launch_conv_bf16(ConvBfArgs &a, const char *name, hipStream_t s)
+{
+    if (MODE == 1) return launch_conv_bf16_t<1, false, false>(a, name, s);
+    if (a.relu) return a.out_f32 ? launch_conv_bf16_t<0, true, true>(a, name, s) : launch_conv_bf16_t<0, true, false>(a, name, s);
+    return a.out_f32 ? launch_conv_bf16_t<0, false, true>(a, name, s) : launch_conv_bf16_t<0, false, false>(a, name, s);
 }
 } // namespace
 
