@@ -69,6 +69,7 @@ _SIGS = {
     "augcl_random_grayscale_f32": [_P, _P, _I, _I, _I, _I, _P, _P],
     "augcl_splice_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _F, _F, _P],
     "augcl_adam_f32": [_P, _P, _P, _P, _SZ, _D, _D, _D, _D, _c.c_int64, _D, _P],
+    "augcl_adam_f32_devstep": [_P, _P, _P, _P, _SZ, _D, _D, _D, _D, _P, _D, _P],
     "augcl_ema_f32": [_P, _P, _SZ, _D, _P],
     "augcl_enc_bf16_conv_first_forward": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
     "augcl_enc_bf16_conv32_forward": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],

@@ -31,6 +31,9 @@ class AugCL(RAD):
         self.critic_weak = pretrained_agent.critic
         self._weak_group = pretrained_agent.critic_group
         self.critic_weak_optimizer = pretrained_agent.critic_optimizer
+        if self._graph is not None:  # graphs captured before the hand-off reference the old weak critic
+            self.critic_weak_optimizer.make_capturable()
+            self._graph.update(graphs={}, static=None, seen=0)
 
     def update_critic(self, obs_aug, obs_shift, action, reward, next_obs, not_done, L=None, step=None):
         target_Q = self.calculate_target_Q(next_obs=next_obs, reward=reward, not_done=not_done)
@@ -47,13 +50,20 @@ class AugCL(RAD):
     def soft_update_critic_target(self):
         self._soft_update_from(self._weak_group)  # the target tracks the weak critic (augcl.py:58-67)
 
-    def update(self, replay_buffer, L, step):
-        obs, action, reward, next_obs, not_done = replay_buffer.sample()
+    def _optimizers(self):
+        return [self.critic_optimizer, self.actor_optimizer, self.critic_weak_optimizer]
+
+    def _front_end(self, obs, action, reward, next_obs, not_done, out=None):
+        """augcl.py:70-72"""
         obs_shift = augmentations.random_shift(obs)
         obs_aug = self.apply_aug(obs.clone() if self._aug_mutates() else obs)  # on the UN-shifted obs (augcl.py:72)
+        return obs_shift, obs_aug, action, reward, next_obs, not_done
+
+    def _learn(self, t, L, step, do_actor, do_target):
+        obs_shift, obs_aug, action, reward, next_obs, not_done = t
         self.update_critic(obs_shift=obs_shift, obs_aug=obs_aug, action=action, reward=reward, next_obs=next_obs,
                            not_done=not_done, L=L, step=step)
-        if step % self.actor_update_freq == 0:
+        if do_actor:
             self.update_actor_and_alpha(obs_aug, L, step)
-        if step % self.critic_target_update_freq == 0:
+        if do_target:
             self.soft_update_critic_target()

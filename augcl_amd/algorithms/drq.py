@@ -36,13 +36,18 @@ class DrQ(SAC):
             self._log(L, f"train_critic/Q2_variance_k={self.k}", var(q2s), step)
         self.critic_optimizer.backward_step(critic_loss)  # zero_grad / backward / step
 
-    def update(self, replay_buffer, L, step):
-        obs, action, reward, next_obs, not_done = replay_buffer.sample()
+    def _front_end(self, obs, action, reward, next_obs, not_done, out=None):
+        """drq.py:69-74: K shifted copies of obs, M of next_obs"""
         obs_list = [augmentations.random_shift(obs) for _ in range(self.k)]
         next_obs_list = [augmentations.random_shift(next_obs) for _ in range(self.m)]
+        return (action, reward, not_done, *obs_list, *next_obs_list)
+
+    def _learn(self, t, L, step, do_actor, do_target):
+        action, reward, not_done = t[:3]
+        obs_list, next_obs_list = list(t[3:3 + self.k]), list(t[3 + self.k:])
         self.update_critic(obs_list=obs_list, action=action, reward=reward, next_obs_list=next_obs_list,
                            not_done=not_done, L=L, step=step)
-        if step % self.actor_update_freq == 0:
+        if do_actor:
             self.update_actor_and_alpha(obs_list[0], L, step)
-        if step % self.critic_target_update_freq == 0:
+        if do_target:
             self.soft_update_critic_target()

@@ -15,4 +15,11 @@ def make_agent(obs_shape, action_shape, args):
         cls = algorithm[args.algorithm]
     except KeyError:
         raise KeyError(f"algorithm {args.algorithm!r} is not on the accelerated path; have {sorted(algorithm)}") from None
-    return cls(obs_shape, action_shape, args)
+    agent = cls(obs_shape, action_shape, args)
+    try:  # extension flag (absent from the reference's arguments.py): replay update() as captured hipGraphs
+        want_graph = bool(args.hip_graph)
+    except (AttributeError, KeyError):
+        want_graph = False
+    if want_graph:
+        agent.enable_hip_graphs()
+    return agent

@@ -24,12 +24,6 @@ class RAD(SAC):
     def _aug_mutates(self):
         return any(k == "color_jitter" for k in self.aug_funcs)
 
-    def update(self, replay_buffer, L, step):
-        obs, action, reward, next_obs, not_done = replay_buffer.sample()
-        obs = self.apply_aug(obs)
-        next_obs = self.apply_aug(next_obs)
-        self.update_critic(obs, action, reward, next_obs, not_done, L, step)
-        if step % self.actor_update_freq == 0:
-            self.update_actor_and_alpha(obs, L, step)
-        if step % self.critic_target_update_freq == 0:
-            self.soft_update_critic_target()
+    def _front_end(self, obs, action, reward, next_obs, not_done, out=None):
+        """rad.py:31-35: the augmentation chain on obs and on next_obs"""
+        return self.apply_aug(obs), action, reward, self.apply_aug(next_obs), not_done

@@ -48,6 +48,7 @@ class SAC(object):
         self._hp = dict(actor_lr=args.actor_lr, actor_beta=args.actor_beta, critic_lr=args.critic_lr,
                         critic_beta=args.critic_beta, alpha_lr=args.alpha_lr, alpha_beta=args.alpha_beta)
         self._build_groups()
+        self._graph = None
         self.train()
         self.critic_target.train()
 
@@ -168,11 +169,86 @@ class SAC(object):
     def soft_update_critic_target(self):
         self._soft_update_from(self.critic_group)
 
+    # ---- update() = front end (sampling + augmentation, eager) + learn (losses / backward / optimisers) ------
+    def _front_end(self, obs, action, reward, next_obs, not_done, out=None):
+        """What update() does to the sampled batch before any network runs.  Returns the tuple of tensors
+        `_learn` consumes; `out` (graph mode) = the static tensors a previous call returned, to be refilled."""
+        return obs, action, reward, next_obs, not_done
+
+    def _learn(self, t, L, step, do_actor, do_target):
+        obs, action, reward, next_obs, not_done = t
+        self.update_critic(obs, action, reward, next_obs, not_done, L, step)
+        if do_actor:
+            self.update_actor_and_alpha(obs, L, step)
+        if do_target:
+            self.soft_update_critic_target()
+
     def update(self, replay_buffer, L, step):
         """sac.py:155-164"""
-        obs, action, reward, next_obs, not_done = replay_buffer.sample()
-        self.update_critic(obs, action, reward, next_obs, not_done, L, step)
-        if step % self.actor_update_freq == 0:
-            self.update_actor_and_alpha(obs, L, step)
-        if step % self.critic_target_update_freq == 0:
-            self.soft_update_critic_target()
+        batch = replay_buffer.sample()
+        do_actor = step % self.actor_update_freq == 0
+        do_target = step % self.critic_target_update_freq == 0
+        if self._graph is not None:
+            return self._graph_update(batch, L, step, do_actor, do_target)
+        self._learn(self._front_end(*batch), L, step, do_actor, do_target)
+
+    # ---- hipGraph mode ---------------------------------------------------------------------------------------
+    def _optimizers(self):
+        return [self.critic_optimizer, self.actor_optimizer]
+
+    def enable_hip_graphs(self, warmup=3):
+        """Capture `_learn` (every network pass, backward, the all-reduce, Adam and the target EMA) in hipGraphs --
+        one per (actor step?, target step?, logging?) variant -- and replay them: one launch per update() instead
+        of ~300.  The front end (replay sampling, augmentation with its per-call Philox offsets) stays eager and
+        writes into the graphs' static input tensors.  The first `warmup` updates run eagerly (lazy workspaces,
+        hipBLASLt heuristics).  Step counts live on the device (FlatAdam.make_capturable, Adam(capturable=True))."""
+        if self._graph is not None:
+            return
+        for opt in self._optimizers():
+            opt.make_capturable()
+        old = self.log_alpha_optimizer
+        hp = self._hp
+        new = torch.optim.Adam([self.log_alpha], lr=hp["alpha_lr"], betas=(hp["alpha_beta"], 0.999), capturable=True)
+        if old.state_dict()["state"]:
+            new.load_state_dict(old.state_dict())
+            for grp in new.param_groups:
+                grp["capturable"] = True
+        self.log_alpha_optimizer = new
+        self._graph = dict(warmup=int(warmup), seen=0, graphs={}, static=None, pool=None)
+
+    def _graph_update(self, batch, L, step, do_actor, do_target):
+        G = self._graph
+        if G["seen"] < G["warmup"]:
+            G["seen"] += 1
+            return self._learn(self._front_end(*batch), L, step, do_actor, do_target)
+        t = self._front_end(*batch, out=G["static"])
+        if G["static"] is None:
+            G["static"] = tuple(x.clone() if torch.is_tensor(x) else x for x in t)
+        for dst, src in zip(G["static"], t):
+            if torch.is_tensor(src) and dst.data_ptr() != src.data_ptr():
+                dst.copy_(src)
+        key = (bool(do_actor), bool(do_target), L is not None)
+        if key not in G["graphs"]:
+            sink = _LogSink()
+            g = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, pool=G["pool"]):
+                self._learn(G["static"], sink if L is not None else None, step, do_actor, do_target)
+            if G["pool"] is None:
+                G["pool"] = g.pool()
+            G["graphs"][key] = (g, sink)
+        g, sink = G["graphs"][key]
+        g.replay()
+        if L is not None:
+            for k, v in sink.items:
+                L.log(k, v, step)
+
+
+class _LogSink:
+    """Stands in for the Logger while a graph is captured: remembers the (static) tensors that were logged."""
+
+    def __init__(self):
+        self.items = []
+
+    def log(self, key, value, step):
+        self.items.append((key, value))

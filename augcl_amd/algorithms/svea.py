@@ -37,20 +37,26 @@ class SVEA(RAD):
             self._log(L, "train_critic/loss", critic_loss, step)
         self.critic_optimizer.backward_step(critic_loss)  # zero_grad / backward / step
 
-    def update(self, replay_buffer, L, step):
-        obs, action, reward, next_obs, not_done = replay_buffer.sample()
-        obs_both = None
+    def _front_end(self, obs, action, reward, next_obs, not_done, out=None):
+        """svea.py:66-68.  Returns (obs_both | obs, action, reward, next_obs, not_done): with the fused front end
+        the first tensor is the (2B,C,H,W) stack [random_shift(obs); random_conv(random_shift(obs))]."""
         if self._fused_front_end(obs):
             # one pass over the (uint8 or f32) batch: random_shift AND random_conv(random_shift) together, written
             # as the two halves of one (2B,C,H,W) buffer so the critic consumes them without a concatenation copy
-            obs_both = augmentations.shift_conv(obs, stacked=True)
-            obs = obs_both[:obs.shape[0]]
+            first = augmentations.shift_conv(obs, stacked=True, out=None if out is None else out[0])
         else:
-            obs = augmentations.random_shift(obs)
+            first = augmentations.random_shift(obs, out=None if out is None else out[0])
+        return first, action, reward, next_obs, not_done
+
+    def _learn(self, t, L, step, do_actor, do_target):
+        first, action, reward, next_obs, not_done = t
+        B = action.shape[0]
+        obs_both = first if first.shape[0] == 2 * B else None
+        obs = first[:B]
         self.update_critic(obs, action, reward, next_obs, not_done, L, step, obs_both=obs_both)
-        if step % self.actor_update_freq == 0:
+        if do_actor:
             self.update_actor_and_alpha(obs, L, step)
-        if step % self.critic_target_update_freq == 0:
+        if do_target:
             self.soft_update_critic_target()
 
     def _fused_front_end(self, obs):

@@ -110,7 +110,7 @@ def random_conv(x, *, weights=None, out=None):
     return out
 
 
-def shift_conv(obs, pad=4, *, oy=None, ox=None, weights=None, want_shift=True, want_aug=True, stacked=False):
+def shift_conv(obs, pad=4, *, oy=None, ox=None, weights=None, want_shift=True, want_aug=True, stacked=False, out=None):
     """Fused SVEA/AugCL front end (src/algorithms/svea.py:68 + :49): one pass over the (uint8 or
     f32) observation producing random_shift(obs) and random_conv(random_shift(obs)).
     stacked=True returns ONE (2B,C,H,W) tensor: rows [0,B) = shifted, rows [B,2B) = shifted + conv."""
@@ -122,7 +122,8 @@ def shift_conv(obs, pad=4, *, oy=None, ox=None, weights=None, want_shift=True, w
         weights = torch.as_tensor(weights, device=obs.device, dtype=torch.float32).contiguous()
     seed, off, s0 = _next_call()
     if stacked:
-        both = torch.empty((2 * B, C, H, W), dtype=torch.float32, device=obs.device)
+        both = out if out is not None else torch.empty((2 * B, C, H, W), dtype=torch.float32, device=obs.device)
+        assert both.shape == (2 * B, C, H, W) and both.dtype == torch.float32 and both.is_contiguous()
         o_s, o_a = both[:B], both[B:]
     else:
         o_s = torch.empty((B, C, H, W), dtype=torch.float32, device=obs.device) if want_shift else None

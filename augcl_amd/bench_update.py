@@ -33,7 +33,7 @@ class _NullLogger:
 
 
 def run(dev, dist, world, rank, steps=20, warmup=4, B=256, A=6, algo="svea", data_aug="conv", backend=None,
-        precision="f32"):
+        precision="f32", graph=False):
     from . import dist as apdist
     from . import encoder_ops
     from . import utils as au
@@ -51,6 +51,9 @@ def run(dev, dist, world, rank, steps=20, warmup=4, B=256, A=6, algo="svea", dat
         apdist.set_default_reducer(apdist.GradReducer())
     torch.manual_seed(0)  # identical replicas
     agent = make_agent((9, 84, 84), (A,), au.dotdict(algorithm=algo, data_aug=data_aug, aug_params=None, **hp))
+    if graph:  # replay the learning part of update() as captured hipGraphs (SAC.enable_hip_graphs)
+        agent.enable_hip_graphs()
+        warmup = max(warmup, 8)  # 3 eager updates, then one capture per (actor step?, target step?) variant
     buf = _SyntheticReplay(dev, B, A, seed=100 + rank)
     L = None  # no logging inside the timed region (the reference's Logger syncs per scalar)
     for s in range(warmup):
@@ -76,4 +79,5 @@ def run(dev, dist, world, rank, steps=20, warmup=4, B=256, A=6, algo="svea", dat
     return {"grad_steps_per_s": steps / wall, "ms_per_update": wall / steps * 1e3, "samples_per_s": world * B * steps / wall,
             "algo": f"{algo}+{data_aug}", "batch_per_gpu": B, "steps": steps,
             "dtype": "f32" if precision == "f32" else "bf16 conv stack (f32 accumulate, f32 heads/optimizer)",
-            "approx_TFLOP/s_per_gpu": flops * steps / wall / 1e12, "encoder_backend": encoder_ops.BACKEND}
+            "approx_TFLOP/s_per_gpu": flops * steps / wall / 1e12, "encoder_backend": encoder_ops.BACKEND,
+            "hip_graph": bool(graph)}

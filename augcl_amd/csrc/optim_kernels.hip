@@ -14,11 +14,18 @@ namespace augcl {
 //   m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g
 //   p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
 // g is first multiplied by grad_scale (1/world_size after a SUM all-reduce; 1 otherwise).
+// hyper != nullptr: step_size / inv_bc2_sqrt come from device memory (written by k_adam_prep in the same
+// stream), so a captured graph replays with the step count of the replay, not of the capture.
 __global__ __launch_bounds__(256) void k_adam_f32(float4 *__restrict__ p, const float4 *__restrict__ g,
                                                   float4 *__restrict__ m, float4 *__restrict__ v, size_t n4,
                                                   float b1, float one_m_b1, float b2, float one_m_b2,
-                                                  float step_size, float inv_bc2_sqrt, float eps, float grad_scale)
+                                                  float step_size, float inv_bc2_sqrt, float eps, float grad_scale,
+                                                  const float *__restrict__ hyper)
 {
+    if (hyper) {
+        step_size = hyper[0];
+        inv_bc2_sqrt = hyper[1];
+    }
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
         float4 pp = p[i], gg = g[i], mm = m[i], vv = v[i];
         float *P = &pp.x, *G = &gg.x, *M = &mm.x, *V = &vv.x;
@@ -40,16 +47,34 @@ __global__ __launch_bounds__(256) void k_adam_f32_tail(float *__restrict__ p, co
                                                        float *__restrict__ m, float *__restrict__ v, size_t begin,
                                                        size_t n, float b1, float one_m_b1, float b2, float one_m_b2,
                                                        float step_size, float inv_bc2_sqrt, float eps,
-                                                       float grad_scale)
+                                                       float grad_scale, const float *__restrict__ hyper)
 {
     const size_t i = begin + (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    if (hyper) {
+        step_size = hyper[0];
+        inv_bc2_sqrt = hyper[1];
+    }
     const float gr = g[i] * grad_scale;
     const float mm = m[i] * b1 + one_m_b1 * gr;
     const float vv = v[i] * b2 + one_m_b2 * (gr * gr);
     m[i] = mm;
     v[i] = vv;
     p[i] = p[i] - step_size * (mm / (sqrtf(vv) * inv_bc2_sqrt + eps));
+}
+
+// device-side step counter: state = {int64 step; float step_size; float inv_bc2_sqrt}.  ++step, then the same
+// double-precision scalar prep the host variant does.
+__global__ void k_adam_prep(void *state, double lr, double beta1, double beta2)
+{
+    long long *step = reinterpret_cast<long long *>(state);
+    float *hyper = reinterpret_cast<float *>(step + 1);
+    const long long t = *step + 1;
+    *step = t;
+    const double bc1 = 1.0 - pow(beta1, (double)t);
+    const double bc2 = 1.0 - pow(beta2, (double)t);
+    hyper[0] = (float)(lr / bc1);
+    hyper[1] = (float)(1.0 / sqrt(bc2));
 }
 
 // utils.soft_update_params: target <- tau*p + (1-tau)*target   (exact op order, no FMA)
@@ -84,35 +109,59 @@ using namespace augcl;
 
 extern "C" {
 
-int augcl_adam_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n, double lr,
-                   double beta1, double beta2, double eps, int64_t step, double grad_scale, augcl_stream_t stream)
+static int adam_impl(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n, double lr,
+                     double beta1, double beta2, double eps, int64_t step, void *step_state, double grad_scale,
+                     augcl_stream_t stream, const char *name)
 {
-    const char *name = "augcl_adam_f32";
     if (n == 0) return AUGCL_OK;
     AUGCL_REQUIRE(param && grad && exp_avg && exp_avg_sq, "%s: null buffer", name);
-    AUGCL_REQUIRE(step >= 1, "%s: step must be >= 1 (got %lld)", name, (long long)step);
     AUGCL_REQUIRE(aligned16(param) && aligned16(grad) && aligned16(exp_avg) && aligned16(exp_avg_sq),
                   "%s: buffers must be 16-byte aligned", name);
-    // scalar prep in double, like torch.optim.Adam's python side
-    const double bc1 = 1.0 - pow(beta1, (double)step);
-    const double bc2 = 1.0 - pow(beta2, (double)step);
-    const float step_size = (float)(lr / bc1);
-    const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
-    const size_t n4 = n / 4;
     hipStream_t s = as_stream(stream);
+    float step_size = 0.0f, inv_bc2_sqrt = 0.0f;
+    const float *hyper = nullptr;
+    if (step_state) { // device-side step: graph-capturable
+        AUGCL_REQUIRE((reinterpret_cast<uintptr_t>(step_state) & 7u) == 0, "%s: step state must be 8-byte aligned", name);
+        hipLaunchKernelGGL(k_adam_prep, dim3(1), dim3(1), 0, s, step_state, lr, beta1, beta2);
+        hyper = reinterpret_cast<const float *>(reinterpret_cast<const char *>(step_state) + 8);
+    } else {
+        AUGCL_REQUIRE(step >= 1, "%s: step must be >= 1 (got %lld)", name, (long long)step);
+        // scalar prep in double, like torch.optim.Adam's python side
+        const double bc1 = 1.0 - pow(beta1, (double)step);
+        const double bc2 = 1.0 - pow(beta2, (double)step);
+        step_size = (float)(lr / bc1);
+        inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+    }
+    const size_t n4 = n / 4;
     if (n4) {
         const size_t blocks = (n4 + 255) / 256;
         hipLaunchKernelGGL(k_adam_f32, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, s,
                            reinterpret_cast<float4 *>(param), reinterpret_cast<const float4 *>(grad),
                            reinterpret_cast<float4 *>(exp_avg), reinterpret_cast<float4 *>(exp_avg_sq), n4,
                            (float)beta1, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), step_size,
-                           inv_bc2_sqrt, (float)eps, (float)grad_scale);
+                           inv_bc2_sqrt, (float)eps, (float)grad_scale, hyper);
     }
     if (n4 * 4 < n)
         hipLaunchKernelGGL(k_adam_f32_tail, dim3(1), dim3(256), 0, s, param, grad, exp_avg, exp_avg_sq, n4 * 4, n,
                            (float)beta1, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), step_size,
-                           inv_bc2_sqrt, (float)eps, (float)grad_scale);
+                           inv_bc2_sqrt, (float)eps, (float)grad_scale, hyper);
     return augcl::check_launch(name);
+}
+
+int augcl_adam_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n, double lr,
+                   double beta1, double beta2, double eps, int64_t step, double grad_scale, augcl_stream_t stream)
+{
+    return adam_impl(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, step, nullptr, grad_scale, stream,
+                     "augcl_adam_f32");
+}
+
+int augcl_adam_f32_devstep(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n, double lr,
+                           double beta1, double beta2, double eps, void *step_state, double grad_scale,
+                           augcl_stream_t stream)
+{
+    const char *name = "augcl_adam_f32_devstep";
+    AUGCL_REQUIRE(step_state, "%s: null step state", name);
+    return adam_impl(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, 0, step_state, grad_scale, stream, name);
 }
 
 int augcl_ema_f32(float *target, const float *src, size_t n, double tau, augcl_stream_t stream)

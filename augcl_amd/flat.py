@@ -84,8 +84,29 @@ class FlatAdam:
         self.group, self.lr, self.betas, self.eps = group, float(lr), (float(betas[0]), float(betas[1])), float(eps)
         self.exp_avg = torch.zeros_like(group.param)
         self.exp_avg_sq = torch.zeros_like(group.param)
-        self.step_count = 0
+        self._step_count = 0
+        self.step_state = None  # device-side {int64 step, 2 floats}: set by make_capturable()
         self.reducer = reducer  # data-parallel gradient exchange (dist.GradReducer) or None
+
+    @property
+    def step_count(self):
+        if self.step_state is not None:
+            return int(self.step_state[0].item())
+        return self._step_count
+
+    @step_count.setter
+    def step_count(self, v):
+        self._step_count = int(v)
+        if self.step_state is not None:
+            self.step_state[0] = int(v)
+
+    def make_capturable(self):
+        """Keep the step count on the device (augcl_adam_f32_devstep) so that step() can be captured in a
+        hipGraph and replayed: no host scalar is baked into the launch."""
+        if self.step_state is None:
+            st = torch.zeros(2, dtype=torch.int64, device=self.group.param.device)
+            st[0] = self._step_count
+            self.step_state = st
 
     def zero_grad(self, set_to_none=True):
         for p in self.group.params:
@@ -100,7 +121,8 @@ class FlatAdam:
         if any(t is None for t in grads):
             g.grad.zero_()
         views = [g.grad[g.slices[n][0]:g.slices[n][1]].view(g.shapes[n]) for n, t in zip(g.names, grads) if t is not None]
-        torch._foreach_copy_(views, [t for t in grads if t is not None])
+        if views:
+            torch._foreach_copy_(views, [t for t in grads if t is not None])
         self._apply()
 
     def step(self):
@@ -112,10 +134,15 @@ class FlatAdam:
         scale = 1.0
         if self.reducer is not None:
             scale = self.reducer.allreduce_sum_(g.grad)  # returns 1/world_size
-        self.step_count += 1
+        if self.step_state is not None:
+            _lib.call("augcl_adam_f32_devstep", g.param.data_ptr(), g.grad.data_ptr(), self.exp_avg.data_ptr(),
+                      self.exp_avg_sq.data_ptr(), g.numel, self.lr, self.betas[0], self.betas[1], self.eps,
+                      self.step_state.data_ptr(), scale, _lib.current_stream(g.param.device))
+            return
+        self._step_count += 1
         _lib.call("augcl_adam_f32", g.param.data_ptr(), g.grad.data_ptr(), self.exp_avg.data_ptr(),
                   self.exp_avg_sq.data_ptr(), g.numel, self.lr, self.betas[0], self.betas[1], self.eps,
-                  self.step_count, scale, _lib.current_stream(g.param.device))
+                  self._step_count, scale, _lib.current_stream(g.param.device))
 
     def state_dict(self):
         return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "lr": self.lr,

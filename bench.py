@@ -226,8 +226,12 @@ def main():
         try:
             from augcl_amd import bench_update
             n_upd = max(10, args.steps // 20)
-            res["sac"] = bench_update.run(dev, dist, world, rank, steps=n_upd)  # f32: the parity path
-            res["sac"]["bf16_mode"] = bench_update.run(dev, dist, world, rank, steps=n_upd, precision="bf16")
+            # update() replayed from captured hipGraphs (SAC.enable_hip_graphs); the eager figure beside it
+            res["sac"] = bench_update.run(dev, dist, world, rank, steps=n_upd, graph=True)  # f32: the parity path
+            res["sac"]["eager_ms_per_update"] = bench_update.run(dev, dist, world, rank, steps=n_upd)["ms_per_update"]
+            res["sac"]["bf16_mode"] = bench_update.run(dev, dist, world, rank, steps=n_upd, precision="bf16", graph=True)
+            res["sac"]["bf16_mode"]["eager_ms_per_update"] = bench_update.run(
+                dev, dist, world, rank, steps=n_upd, precision="bf16")["ms_per_update"]
         except ImportError:
             res["sac"] = None
 

@@ -140,6 +140,12 @@ int augcl_shift_conv_f32(const float *in, float *out_shift, float *out_aug,
 int augcl_adam_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n,
                    double lr, double beta1, double beta2, double eps, int64_t step, double grad_scale,
                    augcl_stream_t stream);
+/* Same step with the step count kept ON THE DEVICE: step_state = 16 bytes {int64 step; float scratch[2]}, 8-byte
+ * aligned, zero-initialised by the caller.  The call increments the count in stream order and derives the bias
+ * corrections from it, so it can be captured in a hipGraph and replayed (no host scalar is baked in). */
+int augcl_adam_f32_devstep(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n,
+                           double lr, double beta1, double beta2, double eps, void *step_state, double grad_scale,
+                           augcl_stream_t stream);
 
 /* ---- target-network update: utils.soft_update_params (src/utils.py:76-78), called from
  * SAC.soft_update_critic_target (src/algorithms/sac.py:148-153):

@@ -217,3 +217,53 @@ def test_full_batch_update_runs_all_algorithms(cuda):
             agent.update(FakeBuffer(batch), L, step)
         assert all(np.isfinite(v) for v in L.rows.values()), (algo, L.rows)
         assert not torch.equal(before, agent.critic_group.param)
+
+
+@pytest.mark.parametrize("algo,data_aug,A", [("svea", "conv", 6), ("drq", "identity", 2), ("augcl", "overlay", 3)])
+def test_hip_graph_update_matches_eager(cuda, algo, data_aug, A):
+    """update() replayed from captured hipGraphs (SAC.enable_hip_graphs: device-side Adam step counts, eager front
+    end writing into the graph's static inputs) walks the same trajectory as the eager path: same seeds, same
+    batches, 10 steps with logging on and off, every (actor step?, target step?) variant."""
+    from augcl_amd import augmentations as aug
+    B = 16
+    g = torch.Generator(device=cuda).manual_seed(3)
+    batches = [(torch.randint(0, 256, (B, 9, 84, 84), device=cuda, generator=g).float(),
+                torch.rand(B, A, device=cuda, generator=g) * 2 - 1, torch.rand(B, 1, device=cuda, generator=g),
+                torch.randint(0, 256, (B, 9, 84, 84), device=cuda, generator=g).float(), torch.ones(B, 1, device=cuda))
+               for _ in range(3)]
+
+    class Ring:
+        def __init__(self):
+            self.i = 0
+
+        def sample(self, n=None, idxs=None):
+            self.i += 1
+            return tuple(t.clone() for t in batches[self.i % 3])
+
+    results = []
+    for graph in (False, True):
+        args = au.dotdict(algorithm=algo, data_aug=data_aug, aug_params=None, **so.DEFAULTS)
+        torch.manual_seed(11)
+        aug.manual_seed(7)
+        aug.set_overlay_source(aug.SyntheticOverlaySource(seed=5))
+        try:
+            agent = make_agent(T.OBS, (A,), args)
+            if graph:
+                agent.enable_hip_graphs(warmup=2)
+            L, buf = RecLogger(), Ring()
+            for step in range(10):
+                agent.update(buf, L if step % 3 else None, step)
+            torch.cuda.synchronize()
+        finally:
+            aug.set_overlay_source(None)
+        if graph:
+            assert len(agent._graph["graphs"]) >= 3
+        results.append((agent.critic_group.param.clone(), agent.actor_group.param.clone(), agent.target_group.param.clone(),
+                        agent.log_alpha.detach().clone(), dict(L.rows), agent.critic_optimizer.step_count))
+    e, gr = results
+    assert e[5] == gr[5] == 10
+    for a, b in zip(e[:4], gr[:4]):
+        assert float((a.double() - b.double()).abs().max()) <= 1e-5 * max(1.0, float(a.abs().max()))
+    assert e[4].keys() == gr[4].keys()
+    for k in e[4]:
+        assert abs(e[4][k] - gr[4][k]) <= 1e-4 * max(1.0, abs(e[4][k])), k
