@@ -14,6 +14,21 @@ extern thread_local char g_err[512];
 int fail(int code, const char *fmt, ...);
 int check_launch(const char *what);
 
+// Fixed-order two-level reduction of per-workgroup gradient slabs (backward-weights).  A launcher hands its
+// descriptor to reduce_slabs(): run at once (2 launches), or -- while the whole-stack backward has opened a
+// deferral scope on this thread -- queued, so that ALL layers are reduced by one batched pair of launches.
+struct ReduceDesc {
+    const float *partial; // [nslab][n]
+    float *part2;         // [8][n] scratch
+    float *out_w, *out_b; // out_w[0..n_w), out_b[0..n-n_w)
+    int nslab, n, n_w;
+};
+constexpr int kReduceMaxBatch = 16;
+int reduce_slabs(const ReduceDesc &d, hipStream_t s, const char *what);
+void reduce_defer_begin();
+int reduce_defer_flush(hipStream_t s, const char *what); // ends the scope
+void reduce_defer_abort();                               // ends the scope, drops what was queued
+
 #define AUGCL_REQUIRE(cond, ...)                                 \
     do {                                                         \
         if (!(cond)) return augcl::fail(AUGCL_E_INVALID, __VA_ARGS__); \

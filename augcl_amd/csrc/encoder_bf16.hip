@@ -609,37 +609,6 @@ __global__ __launch_bounds__(512, 2) void k_wgrad32_bf16(WgBfArgs a)
     }
 }
 
-__global__ __launch_bounds__(256) void k_reduce_slabs_bf_l1(const float *__restrict__ partial, int nslab, int n,
-                                                            float *__restrict__ part2)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const int per = (nslab + 7) / 8;
-    const int g0 = blockIdx.y * per, g1 = min(nslab, g0 + per);
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int g = g0;
-    for (; g + 3 < g1; g += 4) {
-        s0 += partial[(size_t)g * n + i];
-        s1 += partial[(size_t)(g + 1) * n + i];
-        s2 += partial[(size_t)(g + 2) * n + i];
-        s3 += partial[(size_t)(g + 3) * n + i];
-    }
-    for (; g < g1; ++g) s0 += partial[(size_t)g * n + i];
-    part2[(size_t)blockIdx.y * n + i] = (s0 + s1) + (s2 + s3);
-}
-
-__global__ __launch_bounds__(256) void k_reduce_slabs_bf_l2(const float *__restrict__ part2, int n,
-                                                            float *__restrict__ out_w, int n_w, float *__restrict__ out_b)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float s = 0.f;
-#pragma unroll
-    for (int y = 0; y < 8; ++y) s += part2[(size_t)y * n + i];
-    if (i < n_w) out_w[i] = s;
-    else out_b[i - n_w] = s;
-}
-
 } // namespace augcl
 
 extern "C" int augcl_enc_bf16_conv32_backward_weights_mfma(const void *act_prev_bf16_nhwc, const void *dz_bf16_nhwc,
@@ -679,8 +648,6 @@ extern "C" int augcl_enc_bf16_conv32_backward_weights_mfma(const void *act_prev_
     if (e != hipSuccess) return augcl::fail(AUGCL_E_LAUNCH, "%s: cannot set dynamic LDS %zu: %s", name, lds, hipGetErrorString(e));
     hipStream_t s = as_stream(stream);
     hipLaunchKernelGGL(k_wgrad32_bf16, dim3(grid), dim3(512), lds, s, a);
-    float *part2 = workspace + (size_t)grid * WGB_SLAB;
-    hipLaunchKernelGGL(k_reduce_slabs_bf_l1, dim3((WGB_SLAB + 255) / 256, 8), dim3(256), 0, s, workspace, grid, WGB_SLAB, part2);
-    hipLaunchKernelGGL(k_reduce_slabs_bf_l2, dim3((WGB_SLAB + 255) / 256), dim3(256), 0, s, part2, WGB_SLAB, dw, 32 * 288, db);
-    return augcl::check_launch(name);
+    if (int rc = augcl::check_launch(name)) return rc;
+    return augcl::reduce_slabs(ReduceDesc{workspace, workspace + (size_t)grid * WGB_SLAB, dw, db, grid, WGB_SLAB, 32 * 288}, s, name);
 }

@@ -731,40 +731,8 @@ __global__ __launch_bounds__(256, (NT <= 3 ? 4 : NT <= 6 ? 2 : 1)) void k_wgrad_
     }
 }
 
-// sum the per-workgroup slabs in a FIXED order, two levels so the 9.4 MB of slabs are read by ~300 workgroups:
-//   level 1: workgroup (x, y) sums slabs y*nslab/RG .. for outputs x*256..; level 2 adds the RG partial rows.
-constexpr int RG = 8;
-
-__global__ __launch_bounds__(256) void k_reduce_slabs_l1(const float *__restrict__ partial, int nslab, int n,
-                                                         float *__restrict__ part2 /* [RG][n] */)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const int per = (nslab + RG - 1) / RG;
-    const int g0 = blockIdx.y * per, g1 = min(nslab, g0 + per);
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int g = g0;
-    for (; g + 3 < g1; g += 4) {
-        s0 += partial[(size_t)g * n + i];
-        s1 += partial[(size_t)(g + 1) * n + i];
-        s2 += partial[(size_t)(g + 2) * n + i];
-        s3 += partial[(size_t)(g + 3) * n + i];
-    }
-    for (; g < g1; ++g) s0 += partial[(size_t)g * n + i];
-    part2[(size_t)blockIdx.y * n + i] = (s0 + s1) + (s2 + s3);
-}
-
-__global__ __launch_bounds__(256) void k_reduce_slabs_l2(const float *__restrict__ part2, int n,
-                                                         float *__restrict__ out_w, int n_w, float *__restrict__ out_b)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float s = 0.f;
-#pragma unroll
-    for (int y = 0; y < RG; ++y) s += part2[(size_t)y * n + i];
-    if (i < n_w) out_w[i] = s;
-    else out_b[i - n_w] = s;
-}
+// the per-workgroup slabs are summed in a FIXED order by encoder_reduce.hip (reduce_slabs)
+constexpr int RG = 8; // rows of its level-1 scratch
 
 } // namespace augcl
 
@@ -966,12 +934,8 @@ static int wgrad32_impl(const float *act_prev, const float *dz, float *dw, float
         if (int rc = set_lds(k_wgrad32<0, false>, lds, name)) return rc;
         hipLaunchKernelGGL((k_wgrad32<0, false>), dim3(grid), dim3(256), lds, s, a);
     }
-    float *part2 = workspace + (size_t)grid * WG_SLAB;
-    hipLaunchKernelGGL(k_reduce_slabs_l1, dim3((WG_SLAB + 255) / 256, RG), dim3(256), 0, s, workspace, grid, WG_SLAB,
-                       part2);
-    hipLaunchKernelGGL(k_reduce_slabs_l2, dim3((WG_SLAB + 255) / 256), dim3(256), 0, s, part2, WG_SLAB, dw, 32 * 288,
-                       db);
-    return augcl::check_launch(name);
+    if (int rc = augcl::check_launch(name)) return rc;
+    return augcl::reduce_slabs(ReduceDesc{workspace, workspace + (size_t)grid * WG_SLAB, dw, db, grid, WG_SLAB, 32 * 288}, s, name);
 }
 
 int augcl_enc_conv32_backward_weights(const float *act_prev, const float *dz, float *dw, float *db, float *workspace,
@@ -1046,8 +1010,8 @@ static int wgrad_first_impl(const float *x, const float *dz, float *dw, float *d
     }
 #undef LAUNCH_WG1
     float *part2 = workspace + (size_t)grid * slab;
-    hipLaunchKernelGGL(k_reduce_slabs_l1, dim3((slab + 255) / 256, RG), dim3(256), 0, s, workspace, grid, slab, part2);
-    hipLaunchKernelGGL(k_reduce_slabs_l2, dim3((slab + 255) / 256), dim3(256), 0, s, part2, slab, dw, 32 * K, db);
+    if (int rc = augcl::check_launch(name)) return rc;
+    if (int rc = augcl::reduce_slabs(ReduceDesc{workspace, part2, dw, db, grid, slab, 32 * K}, s, name)) return rc;
     return augcl::check_launch(name);
 }
 

@@ -58,6 +58,15 @@ int augcl_enc_stack_backward(const void *const *acts_in, const float *const *w, 
     hs[1] = out_hw(H, first_stride); wsz[1] = out_hw(W, first_stride);
     for (int i = 2; i <= n_layers; ++i) { hs[i] = hs[i - 1] - 2; wsz[i] = wsz[i - 1] - 2; }
     int rc;
+    // With a workspace slice per 32-channel layer (ws32_bytes >= (n_layers-1) x the per-layer size) every layer keeps
+    // its slabs until the end and ALL of them are reduced by one batched pair of launches (2 instead of 2 per layer).
+    const size_t per_layer = augcl_enc_wgrad_workspace_bytes(32);
+    const bool batched = n_layers >= 2 && ws32_bytes >= per_layer * (size_t)(n_layers - 1);
+    struct Scope { // the deferral must not outlive this call, whatever path returns
+        bool on;
+        ~Scope() { if (on) augcl::reduce_defer_abort(); }
+    } scope{batched};
+    if (batched) augcl::reduce_defer_begin();
     const void *dz = grad_out; // f32 NCHW (B,32,hs[n],ws[n])
     if (precision == 1) {
         rc = augcl_enc_nchw_f32_to_nhwc_bf16(grad_out, dz_a, B, hs[n_layers], wsz[n_layers], stream);
@@ -66,14 +75,16 @@ int augcl_enc_stack_backward(const void *const *acts_in, const float *const *w, 
     }
     void *nxt = (dz == dz_a) ? dz_b : dz_a;
     for (int i = n_layers - 1; i >= 1; --i) {
+        float *ws_i = batched ? ws32 + (size_t)(i - 1) * (per_layer / sizeof(float)) : ws32;
+        const size_t ws_i_bytes = batched ? per_layer : ws32_bytes;
         if (precision == 0)
-            rc = augcl_enc_conv32_backward_weights((const float *)acts_in[i], (const float *)dz, dw[i], db[i], ws32, ws32_bytes, B,
+            rc = augcl_enc_conv32_backward_weights((const float *)acts_in[i], (const float *)dz, dw[i], db[i], ws_i, ws_i_bytes, B,
                                                    hs[i], wsz[i], stream);
         else if (bf16_wgrad_mfma)
-            rc = augcl_enc_bf16_conv32_backward_weights_mfma(acts_in[i], dz, dw[i], db[i], ws32, ws32_bytes, B, hs[i], wsz[i],
+            rc = augcl_enc_bf16_conv32_backward_weights_mfma(acts_in[i], dz, dw[i], db[i], ws_i, ws_i_bytes, B, hs[i], wsz[i],
                                                              stream);
         else
-            rc = augcl_enc_bf16_conv32_backward_weights(acts_in[i], dz, dw[i], db[i], ws32, ws32_bytes, B, hs[i], wsz[i], stream);
+            rc = augcl_enc_bf16_conv32_backward_weights(acts_in[i], dz, dw[i], db[i], ws_i, ws_i_bytes, B, hs[i], wsz[i], stream);
         if (rc != AUGCL_OK) return rc;
         if (precision == 0)
             rc = augcl_enc_conv32_backward_data((const float *)dz, w[i], (const float *)acts_in[i], (float *)nxt, B, hs[i + 1],
@@ -90,6 +101,11 @@ int augcl_enc_stack_backward(const void *const *acts_in, const float *const *w, 
     else
         rc = augcl_enc_bf16_conv_first_backward_weights((const float *)acts_in[0], dz, dw[0], db[0], ws_first, ws_first_bytes, B,
                                                         C, H, W, first_stride, scale, stream);
+    if (batched) {
+        scope.on = false;
+        const int rc2 = augcl::reduce_defer_flush((hipStream_t)stream, "augcl_enc_stack_backward");
+        if (rc == AUGCL_OK) rc = rc2;
+    }
     return rc;
 }
 

@@ -9,11 +9,12 @@ from . import _lib
 _ws = {}
 
 
-def _workspace(dev, c_in):
-    key = (dev, c_in)
+def _workspace(dev, c_in, count=1):
+    """count > 1: one slice per layer, so the stack backward can reduce every layer's slabs in one batched launch."""
+    key = (dev, c_in, count)
     if key not in _ws:
         n = _lib.load().augcl_enc_wgrad_workspace_bytes(int(c_in))
-        _ws[key] = torch.empty(n // 4, dtype=torch.float32, device=dev)
+        _ws[key] = torch.empty(n // 4 * count, dtype=torch.float32, device=dev)
     return _ws[key]
 
 
@@ -163,7 +164,7 @@ class ConvStackFn(torch.autograd.Function):
         dbs = torch.empty((n_layers, 32), dtype=torch.float32, device=dev)
         dz = torch.empty(2 * ((max_numel + 7) // 8 * 8), dtype=torch.bfloat16 if bf16 else torch.float32, device=dev)
         half = dz.numel() // 2 * dz.element_size()
-        ws32, wsf = _workspace(dev, 32), _workspace(dev, C)
+        ws32, wsf = _workspace(dev, 32, max(1, n_layers - 1)), _workspace(dev, C)
         _lib.call("augcl_enc_stack_backward", _ptr_array([x.data_ptr()] + list(act_ptrs)),
                   _ptr_array([w.data_ptr() for w in weights]), g.data_ptr(), _ptr_array([t.data_ptr() for t in dws]),
                   _ptr_array([dbs[i].data_ptr() for i in range(n_layers)]), dz.data_ptr(), dz.data_ptr() + half,
