@@ -204,9 +204,15 @@ def test_agent_pickle_roundtrip_and_state_dict_names(cuda, tmp_path):
 
 def test_full_batch_update_runs_all_algorithms(cuda):
     """BASELINE configs' batch sizes through the default (RNG-internal, fused) paths: finite losses, nets move."""
-    for algo, data_aug, A, B in (("svea", "conv", 6, 256), ("drq", "identity", 2, 512), ("non_naive_rad", "shift", 1, 128)):
+    from augcl_amd import augmentations as aug
+    aug.set_overlay_source(aug.SyntheticOverlaySource(seed=1))
+    cases = (("svea", "conv", 6, 256), ("drq", "identity", 2, 512), ("non_naive_rad", "shift", 1, 128),
+             ("augcl", "conv-overlay", 6, 1024))  # BASELINE configs 2, 3, 1, 4 (config 4's global batch on one GPU)
+    for algo, data_aug, A, B in cases:
         args = au.dotdict(algorithm=algo, data_aug=data_aug, aug_params=None, **so.DEFAULTS)
         agent = make_agent(T.OBS, (A,), args)
+        if algo == "augcl":  # the curriculum hand-off: weak critic = the pretrained agent's critic
+            agent.load_pretrained_agent(make_agent(T.OBS, (A,), au.dotdict(dict(args, algorithm="non_naive_rad", data_aug="shift"))))
         g = torch.Generator(device=cuda).manual_seed(2)
         batch = (torch.randint(0, 256, (B, 9, 84, 84), device=cuda, generator=g).float(), torch.rand(B, A, device=cuda) * 2 - 1,
                  torch.rand(B, 1, device=cuda), torch.randint(0, 256, (B, 9, 84, 84), device=cuda, generator=g).float(),
@@ -217,6 +223,7 @@ def test_full_batch_update_runs_all_algorithms(cuda):
             agent.update(FakeBuffer(batch), L, step)
         assert all(np.isfinite(v) for v in L.rows.values()), (algo, L.rows)
         assert not torch.equal(before, agent.critic_group.param)
+    aug.set_overlay_source(None)
 
 
 @pytest.mark.parametrize("algo,data_aug,A", [("svea", "conv", 6), ("drq", "identity", 2), ("augcl", "overlay", 3)])
