@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import encoder_ops
+from .. import encoder_ops, head_ops
 
 
 def gaussian_logprob(noise, log_std):
@@ -174,7 +174,12 @@ class Actor(nn.Module):
 
     def forward(self, x, compute_pi=True, compute_log_pi=True, detach=False, features=None):
         x = self.encoder(x, detach, features=features)
-        mu, log_std = self.mlp(x).chunk(2, dim=-1)
+        raw = self.mlp(x)
+        if head_ops._ok(raw) and (compute_pi or not compute_log_pi):
+            # one launch forward / one backward for everything below (same operation order inside)
+            noise = torch.randn_like(raw[:, :raw.shape[1] // 2]) if compute_pi else None
+            return head_ops.gauss_head(raw, noise, self.log_std_min, self.log_std_max, compute_log_pi)
+        mu, log_std = raw.chunk(2, dim=-1)
         log_std = torch.tanh(log_std)
         log_std = self.log_std_min + 0.5 * (self.log_std_max - self.log_std_min) * (log_std + 1)
         if compute_pi:

@@ -13,7 +13,7 @@ import torch
 import torch.nn.functional as F
 
 from .. import dist as apdist
-from .. import flat
+from .. import flat, head_ops
 from . import modules as m
 
 
@@ -108,11 +108,15 @@ class SAC(object):
         with torch.no_grad():
             _, policy_action, log_pi, _ = self.actor(next_obs)
             target_Q1, target_Q2 = self.critic_target(next_obs, policy_action)
+            if head_ops._ok(target_Q1, log_pi, reward, not_done):
+                return head_ops.td_target(target_Q1, target_Q2, log_pi, reward, not_done, self.alpha, self.discount)
             target_V = torch.min(target_Q1, target_Q2) - self.alpha.detach() * log_pi
             return reward + (not_done * self.discount * target_V)
 
     @staticmethod
     def _q_loss(q1, q2, target_Q):
+        if head_ops._ok(q1, q2, target_Q) and not target_Q.requires_grad:
+            return head_ops.q_loss(q1, q2, target_Q)[0]
         return F.mse_loss(q1, target_Q) + F.mse_loss(q2, target_Q)
 
     def _log(self, L, key, value, step):

@@ -2,7 +2,7 @@
 batch and its strongly augmented copy -- against one un-augmented target, weighted alpha / beta."""
 import torch
 
-from .. import augmentations
+from .. import augmentations, head_ops
 from .rad import RAD
 
 
@@ -26,11 +26,16 @@ class SVEA(RAD):
                 obs_aug = self.apply_aug(obs.clone() if self._aug_mutates() else obs)
             obs_both = torch.cat([obs, obs_aug], dim=0)
         q1, q2 = self.critic(obs_both, torch.cat([action, action], dim=0))
-        y2 = torch.cat([target_Q, target_Q], dim=0)
-        se = (q1 - y2).square() + (q2 - y2).square()  # per-sample (Q1-y)^2 + (Q2-y)^2
-        critic_loss_shift = self.svea_alpha * se[:B].mean()  # = alpha * (mse(Q1,y) + mse(Q2,y)) on the shifted half
-        critic_loss_aug = self.svea_beta * se[B:].mean()
-        critic_loss = critic_loss_shift + critic_loss_aug
+        if head_ops._ok(q1, q2, target_Q):
+            # one launch: per-half mse(Q1,y) + mse(Q2,y) and their weighted sum (and one launch backward)
+            critic_loss, segs = head_ops.q_loss(q1, q2, target_Q, (self.svea_alpha, self.svea_beta))
+            critic_loss_shift, critic_loss_aug = (self.svea_alpha * segs[0], self.svea_beta * segs[1]) if L is not None else (None, None)
+        else:
+            y2 = torch.cat([target_Q, target_Q], dim=0)
+            se = (q1 - y2).square() + (q2 - y2).square()  # per-sample (Q1-y)^2 + (Q2-y)^2
+            critic_loss_shift = self.svea_alpha * se[:B].mean()  # = alpha * (mse(Q1,y) + mse(Q2,y)) on the shifted half
+            critic_loss_aug = self.svea_beta * se[B:].mean()
+            critic_loss = critic_loss_shift + critic_loss_aug
         if L is not None:
             self._log(L, "train_critic/shift_loss", critic_loss_shift, step)
             self._log(L, "train_critic/aug_loss", critic_loss_aug, step)

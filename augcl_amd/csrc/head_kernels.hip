@@ -1,0 +1,218 @@
+// head_kernels.hip -- the SAC heads' element-wise tails as single launches (forward and backward):
+//   * the squashed-Gaussian policy head (src/algorithms/modules.py:19-32 gaussian_logprob / squash and
+//     Actor.forward L225-244): ~20 ATen launches forward and ~25 backward in the reference, on (B, A) tensors;
+//   * the TD target (src/algorithms/sac.py:94-101) and the twin-Q MSE loss (sac.py:108-110, svea.py:37-56).
+// Every formula keeps the reference's operation order; compiled with -ffp-contract=off (the reference's separate
+// element-wise kernels never fuse a multiply into an add).  One thread per batch row: A (action dim) is tiny.
+#include "augcl_common.h"
+
+namespace augcl {
+
+struct GaussArgs {
+    const float *raw;   // (B, 2A): [mu | log_std_raw], the policy MLP's output
+    const float *noise; // (B, A) or null (compute_pi = False)
+    float *mu_t, *pi_t, *log_pi, *log_std; // outputs; pi_t / log_pi may be null
+    const float *g_mu_t, *g_pi_t, *g_log_pi, *g_log_std; // backward: incoming gradients (any may be null)
+    float *g_raw;                                        // backward: (B, 2A)
+    int B, A;
+    float lo, k, c; // log_std = lo + k * (tanh(raw) + 1); c = 0.5 * log(2 pi) * A
+};
+
+__global__ __launch_bounds__(256) void k_gauss_head_fwd(GaussArgs a)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= a.B) return;
+    const float *raw = a.raw + (size_t)r * 2 * a.A;
+    float s1 = 0.0f, s2 = 0.0f;
+    for (int j = 0; j < a.A; ++j) {
+        const float m = raw[j];
+        const float t = tanhf(raw[a.A + j]);
+        const float ls = a.lo + a.k * (t + 1.0f);
+        a.log_std[(size_t)r * a.A + j] = ls;
+        a.mu_t[(size_t)r * a.A + j] = tanhf(m);
+        if (a.noise) {
+            const float n = a.noise[(size_t)r * a.A + j];
+            const float p = m + n * expf(ls);
+            const float pt = tanhf(p);
+            a.pi_t[(size_t)r * a.A + j] = pt;
+            s1 += -0.5f * (n * n) - ls;
+            s2 += logf(fmaxf(1.0f - pt * pt, 0.0f) + 1e-6f);
+        }
+    }
+    if (a.noise && a.log_pi) a.log_pi[r] = (s1 - a.c) - s2;
+}
+
+__global__ __launch_bounds__(256) void k_gauss_head_bwd(GaussArgs a)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= a.B) return;
+    const float *raw = a.raw + (size_t)r * 2 * a.A;
+    float *g = a.g_raw + (size_t)r * 2 * a.A;
+    const float glp = a.g_log_pi ? a.g_log_pi[r] : 0.0f;
+    for (int j = 0; j < a.A; ++j) {
+        const size_t e = (size_t)r * a.A + j;
+        const float m = raw[j];
+        const float t = tanhf(raw[a.A + j]);
+        const float ls = a.lo + a.k * (t + 1.0f);
+        const float mt = tanhf(m);
+        float d_m = a.g_mu_t ? a.g_mu_t[e] * (1.0f - mt * mt) : 0.0f;
+        float d_ls = a.g_log_std ? a.g_log_std[e] : 0.0f;
+        if (a.noise) {
+            const float n = a.noise[e];
+            const float sd = expf(ls);
+            const float pt = tanhf(m + n * sd);
+            const float u = 1.0f - pt * pt;
+            // d/d pi_t of -sum log(relu(1 - pi_t^2) + 1e-6) = (u > 0) * 2 pi_t / (u + 1e-6)
+            float g_pt = a.g_pi_t ? a.g_pi_t[e] : 0.0f;
+            if (u > 0.0f) g_pt += (glp / (u + 1e-6f)) * (2.0f * pt);
+            const float d_p = g_pt * u;
+            d_m += d_p;
+            d_ls += (d_p * n) * sd - glp;
+        }
+        g[j] = d_m;
+        g[a.A + j] = (d_ls * a.k) * (1.0f - t * t);
+    }
+}
+
+// target_Q = reward + (not_done * discount) * (min(tq1, tq2) - alpha * log_pi)      (sac.py:94-101)
+__global__ __launch_bounds__(256) void k_td_target(const float *__restrict__ tq1, const float *__restrict__ tq2,
+                                                   const float *__restrict__ log_pi, const float *__restrict__ reward,
+                                                   const float *__restrict__ not_done, const double *__restrict__ alpha,
+                                                   float discount, float *__restrict__ out, int B)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B) return;
+    const float al = (float)alpha[0];
+    const float v = fminf(tq1[i], tq2[i]) - al * log_pi[i];
+    out[i] = reward[i] + (not_done[i] * discount) * v;
+}
+
+// twin-Q loss over S segments of M rows (SVEA: S = 2 halves of one 2B batch against the same M targets):
+//   seg[s] = mean_i (q1-y)^2 + mean_i (q2-y)^2 ;  total = sum_s w[s] * seg[s]
+// one workgroup, fixed-order tree: deterministic.  out = {total, seg[0..S)}
+__global__ __launch_bounds__(256) void k_q_loss_fwd(const float *__restrict__ q1, const float *__restrict__ q2,
+                                                    const float *__restrict__ y, int M, int S, float w0, float w1,
+                                                    float w2, float w3, float *__restrict__ out)
+{
+    __shared__ float red[2][256];
+    const float w[4] = {w0, w1, w2, w3};
+    float total = 0.0f;
+    for (int s = 0; s < S; ++s) {
+        float a1 = 0.0f, a2 = 0.0f;
+        for (int i = threadIdx.x; i < M; i += 256) {
+            const float d1 = q1[(size_t)s * M + i] - y[i], d2 = q2[(size_t)s * M + i] - y[i];
+            a1 += d1 * d1;
+            a2 += d2 * d2;
+        }
+        red[0][threadIdx.x] = a1;
+        red[1][threadIdx.x] = a2;
+        __syncthreads();
+        for (int k = 128; k > 0; k >>= 1) {
+            if ((int)threadIdx.x < k) {
+                red[0][threadIdx.x] += red[0][threadIdx.x + k];
+                red[1][threadIdx.x] += red[1][threadIdx.x + k];
+            }
+            __syncthreads();
+        }
+        const float seg = red[0][0] / (float)M + red[1][0] / (float)M;
+        if (threadIdx.x == 0) out[1 + s] = seg;
+        total += w[s] * seg;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = total;
+}
+
+// d total / d q1[s*M+i] = g * w[s] * 2 (q1 - y) / M     (mse_loss backward, scaled by the segment weight)
+__global__ __launch_bounds__(256) void k_q_loss_bwd(const float *__restrict__ q1, const float *__restrict__ q2,
+                                                    const float *__restrict__ y, const float *__restrict__ g, int M,
+                                                    int S, float w0, float w1, float w2, float w3,
+                                                    float *__restrict__ dq1, float *__restrict__ dq2)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * S) return;
+    const float w[4] = {w0, w1, w2, w3};
+    const int s = i / M;
+    const float yy = y[i - s * M];
+    const float scale = (g[0] * w[s]) * (2.0f / (float)M);
+    dq1[i] = scale * (q1[i] - yy);
+    dq2[i] = scale * (q2[i] - yy);
+}
+
+} // namespace augcl
+
+using namespace augcl;
+
+extern "C" {
+
+int augcl_gauss_head_forward(const float *raw, const float *noise, float *mu_t, float *pi_t, float *log_pi,
+                             float *log_std, int B, int A, double log_std_min, double log_std_max,
+                             augcl_stream_t stream)
+{
+    const char *name = "augcl_gauss_head_forward";
+    AUGCL_REQUIRE(B >= 0 && A >= 1, "%s: bad shape", name);
+    if (B == 0) return AUGCL_OK;
+    AUGCL_REQUIRE(raw && mu_t && log_std && (!noise || pi_t), "%s: null tensor", name);
+    GaussArgs a{};
+    a.raw = raw; a.noise = noise; a.mu_t = mu_t; a.pi_t = pi_t; a.log_pi = log_pi; a.log_std = log_std;
+    a.B = B; a.A = A;
+    a.lo = (float)log_std_min; a.k = (float)(0.5 * (log_std_max - log_std_min));
+    a.c = (float)(0.5 * 1.8378770664093453 /* log(2 pi) */ * (double)A);
+    hipLaunchKernelGGL(k_gauss_head_fwd, dim3((B + 255) / 256), dim3(256), 0, as_stream(stream), a);
+    return augcl::check_launch(name);
+}
+
+int augcl_gauss_head_backward(const float *raw, const float *noise, const float *g_mu_t, const float *g_pi_t,
+                              const float *g_log_pi, const float *g_log_std, float *g_raw, int B, int A,
+                              double log_std_min, double log_std_max, augcl_stream_t stream)
+{
+    const char *name = "augcl_gauss_head_backward";
+    AUGCL_REQUIRE(B >= 0 && A >= 1, "%s: bad shape", name);
+    if (B == 0) return AUGCL_OK;
+    AUGCL_REQUIRE(raw && g_raw, "%s: null tensor", name);
+    GaussArgs a{};
+    a.raw = raw; a.noise = noise; a.g_mu_t = g_mu_t; a.g_pi_t = g_pi_t; a.g_log_pi = g_log_pi; a.g_log_std = g_log_std;
+    a.g_raw = g_raw; a.B = B; a.A = A;
+    a.lo = (float)log_std_min; a.k = (float)(0.5 * (log_std_max - log_std_min));
+    hipLaunchKernelGGL(k_gauss_head_bwd, dim3((B + 255) / 256), dim3(256), 0, as_stream(stream), a);
+    return augcl::check_launch(name);
+}
+
+int augcl_td_target_f32(const float *tq1, const float *tq2, const float *log_pi, const float *reward,
+                        const float *not_done, const double *alpha_dev, double discount, float *out, int B,
+                        augcl_stream_t stream)
+{
+    const char *name = "augcl_td_target_f32";
+    AUGCL_REQUIRE(B >= 0, "%s: bad shape", name);
+    if (B == 0) return AUGCL_OK;
+    AUGCL_REQUIRE(tq1 && tq2 && log_pi && reward && not_done && alpha_dev && out, "%s: null tensor", name);
+    hipLaunchKernelGGL(k_td_target, dim3((B + 255) / 256), dim3(256), 0, as_stream(stream), tq1, tq2, log_pi, reward,
+                       not_done, alpha_dev, (float)discount, out, B);
+    return augcl::check_launch(name);
+}
+
+int augcl_q_loss_forward(const float *q1, const float *q2, const float *y, int M, int S, const double *w, float *out,
+                         augcl_stream_t stream)
+{
+    const char *name = "augcl_q_loss_forward";
+    AUGCL_REQUIRE(M >= 1 && S >= 1 && S <= 4, "%s: bad shape", name);
+    AUGCL_REQUIRE(q1 && q2 && y && w && out, "%s: null tensor", name);
+    float ws[4] = {0, 0, 0, 0};
+    for (int s = 0; s < S; ++s) ws[s] = (float)w[s];
+    hipLaunchKernelGGL(k_q_loss_fwd, dim3(1), dim3(256), 0, as_stream(stream), q1, q2, y, M, S, ws[0], ws[1], ws[2], ws[3], out);
+    return augcl::check_launch(name);
+}
+
+int augcl_q_loss_backward(const float *q1, const float *q2, const float *y, const float *g_total, int M, int S,
+                          const double *w, float *dq1, float *dq2, augcl_stream_t stream)
+{
+    const char *name = "augcl_q_loss_backward";
+    AUGCL_REQUIRE(M >= 1 && S >= 1 && S <= 4, "%s: bad shape", name);
+    AUGCL_REQUIRE(q1 && q2 && y && g_total && w && dq1 && dq2, "%s: null tensor", name);
+    float ws[4] = {0, 0, 0, 0};
+    for (int s = 0; s < S; ++s) ws[s] = (float)w[s];
+    hipLaunchKernelGGL(k_q_loss_bwd, dim3((M * S + 255) / 256), dim3(256), 0, as_stream(stream), q1, q2, y, g_total, M, S,
+                       ws[0], ws[1], ws[2], ws[3], dq1, dq2);
+    return augcl::check_launch(name);
+}
+
+} // extern "C"

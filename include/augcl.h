@@ -147,6 +147,32 @@ int augcl_adam_f32_devstep(float *param, const float *grad, float *exp_avg, floa
                            double lr, double beta1, double beta2, double eps, void *step_state, double grad_scale,
                            augcl_stream_t stream);
 
+/* ---- SAC heads: the element-wise tails of the policy / critic heads as single launches.
+ * Squashed-Gaussian policy head = Actor.forward after its MLP (src/algorithms/modules.py:225-244) with
+ * gaussian_logprob (L19-22) and squash (L25-32): raw (B,2A) = [mu | log_std_raw];
+ *   log_std = min + 0.5 (max-min) (tanh(raw_ls) + 1); pi = mu + noise exp(log_std);
+ *   log_pi = sum(-0.5 noise^2 - log_std) - 0.5 log(2 pi) A - sum log(relu(1 - tanh(pi)^2) + 1e-6);
+ * outputs tanh(mu), tanh(pi), log_pi (B,1), log_std.  noise = NULL: compute_pi = False (mu_t, log_std only).
+ * backward: gradients of the four outputs (NULL = none) -> g_raw (B,2A); recomputes from raw / noise. */
+int augcl_gauss_head_forward(const float *raw, const float *noise, float *mu_t, float *pi_t, float *log_pi,
+                             float *log_std, int B, int A, double log_std_min, double log_std_max,
+                             augcl_stream_t stream);
+int augcl_gauss_head_backward(const float *raw, const float *noise, const float *g_mu_t, const float *g_pi_t,
+                              const float *g_log_pi, const float *g_log_std, float *g_raw, int B, int A,
+                              double log_std_min, double log_std_max, augcl_stream_t stream);
+/* SAC.calculate_target_Q (src/algorithms/sac.py:94-101):
+ *   out = reward + (not_done * discount) * (min(tq1,tq2) - alpha * log_pi); alpha read from a device double. */
+int augcl_td_target_f32(const float *tq1, const float *tq2, const float *log_pi, const float *reward,
+                        const float *not_done, const double *alpha_dev, double discount, float *out, int B,
+                        augcl_stream_t stream);
+/* Twin-Q loss (sac.py:108-110; svea.py:37-56 with S = 2 segments of one 2B batch against the same M targets):
+ *   seg[s] = mse(q1[sM:(s+1)M], y) + mse(q2[...], y); out = {sum_s w[s] seg[s], seg[0..S)}; S <= 4; w on the host.
+ * One workgroup, fixed-order tree sum (deterministic).  backward: dq = g_total * w[s] * 2 (q - y) / M. */
+int augcl_q_loss_forward(const float *q1, const float *q2, const float *y, int M, int S, const double *w, float *out,
+                         augcl_stream_t stream);
+int augcl_q_loss_backward(const float *q1, const float *q2, const float *y, const float *g_total, int M, int S,
+                          const double *w, float *dq1, float *dq2, augcl_stream_t stream);
+
 /* ---- target-network update: utils.soft_update_params (src/utils.py:76-78), called from
  * SAC.soft_update_critic_target (src/algorithms/sac.py:148-153):
  *   target[i] = tau*src[i] + (1-tau)*target[i]   (separate IEEE ops, bit-exact vs torch f32) */

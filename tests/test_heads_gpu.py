@@ -1,0 +1,86 @@
+"""GPU: fused SAC-head launches (augcl_amd/head_ops.py) against the literal ATen chains of the reference
+(src/algorithms/modules.py:19-32, 225-244; sac.py:94-110; svea.py:37-56), values and gradients."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from augcl_amd import head_ops
+from augcl_amd.algorithms import modules as m
+
+pytestmark = pytest.mark.gpu
+
+
+def ref_head(raw, noise, lo, hi):
+    mu, log_std = raw.chunk(2, dim=-1)
+    log_std = torch.tanh(log_std)
+    log_std = lo + 0.5 * (hi - lo) * (log_std + 1)
+    if noise is None:
+        return torch.tanh(mu), None, None, log_std
+    pi = mu + noise * log_std.exp()
+    log_pi = m.gaussian_logprob(noise, log_std)
+    mu, pi, log_pi = m.squash(mu, pi, log_pi)
+    return mu, pi, log_pi, log_std
+
+
+@pytest.mark.parametrize("B,A", [(1, 1), (7, 6), (256, 6), (512, 21)])
+def test_gauss_head_matches_aten_chain(cuda, B, A):
+    g = torch.Generator(device=cuda).manual_seed(B + A)
+    raw0 = torch.randn(B, 2 * A, device=cuda, generator=g) * 2.0
+    raw0[0, 0] = 9.0  # saturated tanh: relu(1 - pi^2) hits its floor
+    noise = torch.randn(B, A, device=cuda, generator=g)
+    # Near tanh saturation the chain is ill-conditioned (1 - tanh(pi)^2 cancels; one ulp of tanh moves the gradient
+    # by ~1e-4 relative), so the yardstick is the same chain in float64: the fused launch must be as close to it
+    # as the f32 ATen chain is.
+    outs = []
+    for mode in ("f64", "aten", "fused"):
+        dt = torch.float64 if mode == "f64" else torch.float32
+        raw = raw0.to(dt).clone().requires_grad_(True)
+        o = head_ops.gauss_head(raw, noise, -10.0, 2.0) if mode == "fused" else ref_head(raw, noise.to(dt), -10.0, 2.0)
+        gs = [torch.randn(t.shape, device=cuda, generator=torch.Generator(device=cuda).manual_seed(i)).to(dt) for i, t in enumerate(o)]
+        sum((t * w).sum() for t, w in zip(o, gs)).backward()
+        outs.append([t.detach().double() for t in o] + [raw.grad.double()])
+    for truth, aten, fused in zip(*outs):
+        scale = max(1.0, float(truth.abs().max()))
+        e_aten, e_fused = float((aten - truth).abs().max()), float((fused - truth).abs().max())
+        assert e_fused <= max(2.0 * e_aten, 2e-6 * scale), (e_fused, e_aten)
+    # only some outputs used (actor loss uses pi and log_pi; the entropy log uses log_std)
+    for use in ([1, 2], [0], [3], [2]):
+        grads = []
+        for fused in (False, True):
+            raw = raw0.clone().requires_grad_(True)
+            o = head_ops.gauss_head(raw, noise, -10.0, 2.0) if fused else ref_head(raw, noise, -10.0, 2.0)
+            sum(o[i].sum() for i in use).backward()
+            grads.append(raw.grad)
+        assert float((grads[0] - grads[1]).abs().max()) <= 2e-4 * max(1.0, float(grads[0].abs().max())), use
+    # compute_pi = False
+    mu_t, pi, lp, ls = head_ops.gauss_head(raw0, None, -10.0, 2.0, False)
+    r = ref_head(raw0, None, -10.0, 2.0)
+    assert pi is None and lp is None and torch.allclose(mu_t, r[0], atol=1e-6) and torch.allclose(ls, r[3], atol=1e-5)
+
+
+def test_td_target_and_q_loss(cuda):
+    g = torch.Generator(device=cuda).manual_seed(5)
+    B = 256
+    tq1, tq2, lp = (torch.randn(B, 1, device=cuda, generator=g) * 30 for _ in range(3))
+    rew, nd = torch.rand(B, 1, device=cuda, generator=g) * 4, (torch.rand(B, 1, device=cuda, generator=g) > 0.1).float()
+    alpha = torch.tensor(np.log(0.1), device=cuda).exp()  # float64 0-dim, like SAC.alpha
+    want = rew + (nd * 0.99 * (torch.min(tq1, tq2) - alpha.detach() * lp))
+    got = head_ops.td_target(tq1, tq2, lp, rew, nd, alpha, 0.99)
+    assert got.shape == (B, 1) and float((got - want).abs().max()) <= 1e-5 * float(want.abs().max())
+
+    y = want
+    for S, w in ((1, (1.0,)), (2, (0.5, 0.5)), (2, (0.3, 0.9))):
+        q0 = torch.randn(S * B, 1, device=cuda, generator=g) * 30
+        res = []
+        for fused in (False, True):
+            q1, q2 = q0.clone().requires_grad_(True), (q0 * 0.9 + 1).detach().requires_grad_(True)
+            if fused:
+                total, segs = head_ops.q_loss(q1, q2, y, w)
+            else:
+                segs = torch.stack([F.mse_loss(q1[s * B:(s + 1) * B], y) + F.mse_loss(q2[s * B:(s + 1) * B], y) for s in range(S)])
+                total = sum(w[s] * segs[s] for s in range(S))
+            (total * 1.7).backward()
+            res.append((total.detach(), segs.detach(), q1.grad, q2.grad))
+        for a, b in zip(*res):
+            assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(a.abs().max())), (S, w)
