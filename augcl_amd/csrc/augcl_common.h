@@ -29,6 +29,10 @@ void reduce_defer_begin();
 int reduce_defer_flush(hipStream_t s, const char *what); // ends the scope
 void reduce_defer_abort();                               // ends the scope, drops what was queued
 
+// first layer fast path (encoder_first.hip): AUGCL_OK / negative error after launching, +1 if the shape is not covered
+int conv_first9_try(const float *in, const float *w, const float *bias, void *out, int B, int C, int Hi, int Wi, int stride,
+                    float scale, int relu, bool out_bf16, hipStream_t s, const char *name);
+
 #define AUGCL_REQUIRE(cond, ...)                                 \
     do {                                                         \
         if (!(cond)) return augcl::fail(AUGCL_E_INVALID, __VA_ARGS__); \

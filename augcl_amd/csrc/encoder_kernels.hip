@@ -837,6 +837,10 @@ static int conv_first_forward_impl(const float *in, const float *w, const float 
                   "%s: bad shape", name);
     if (B == 0) return AUGCL_OK;
     AUGCL_REQUIRE(in && w && out, "%s: null tensor", name);
+    {   // the training loop's shape (9 x 84 x 84, stride 2) has its own pipelined kernel
+        const int rc = augcl::conv_first9_try(in, w, bias, out, B, C, Hi, Wi, stride, scale, relu, out_bf16, as_stream(stream), name);
+        if (rc <= 0) return rc; // launched (or failed); +1 = shape not covered
+    }
     Conv1Args a{};
     a.in = in; a.w = w; a.bias = bias; a.out = out;
     a.B = B; a.C = C; a.Hi = Hi; a.Wi = Wi; a.stride = stride; a.scale = scale; a.relu = relu;
