@@ -104,6 +104,38 @@ __global__ __launch_bounds__(256) void k_splice(const float *__restrict__ x, con
     }
 }
 
+// do_green_screen (src/env/wrappers.py:209-260): a pixel whose HSV (python colorsys arithmetic in DOUBLE, as the
+// reference's per-pixel Python loop computes it) falls in h*360 in [100,185], s*255 in [80,255], v*255 in [70,255]
+// is replaced by the background pixel.  uint8 in, uint8 out: bit-exact.
+__global__ __launch_bounds__(256) void k_green_screen(const uint8_t *__restrict__ x, const uint8_t *__restrict__ bg,
+                                                      uint8_t *__restrict__ out, int n /* H*W */)
+{
+    const size_t f = blockIdx.y; // frame
+    const uint8_t *px = x + f * 3 * n, *pb = bg + f * 3 * n;
+    uint8_t *po = out + f * 3 * n;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < n; p += gridDim.x * 256) {
+        const uint8_t r8 = px[p], g8 = px[n + p], b8 = px[2 * n + p];
+        const double r = r8 / 255.0, g = g8 / 255.0, b = b8 / 255.0;
+        const double maxc = fmax(fmax(r, g), b), minc = fmin(fmin(r, g), b);
+        double h = 0.0, s = 0.0;
+        if (minc != maxc) {
+            const double d = maxc - minc;
+            s = d / maxc;
+            const double rc = (maxc - r) / d, gc = (maxc - g) / d, bc = (maxc - b) / d;
+            if (r == maxc) h = bc - gc;
+            else if (g == maxc) h = 2.0 + rc - bc;
+            else h = 4.0 + gc - rc;
+            h = h / 6.0;
+            h = h - floor(h); // python's  % 1.0
+        }
+        const double hh = h * 360, ss = s * 255, vv = maxc * 255;
+        const bool key = 100 <= hh && hh <= 185 && 80 <= ss && ss <= 255 && 70 <= vv && vv <= 255;
+        po[p] = key ? pb[p] : r8;
+        po[n + p] = key ? pb[n + p] : g8;
+        po[2 * n + p] = key ? pb[2 * n + p] : b8;
+    }
+}
+
 } // namespace augcl
 
 using namespace augcl;
@@ -161,6 +193,18 @@ int augcl_splice_f32(const float *x, const float *imgs, float *out, int B, int f
     const int gx = (n + 255) / 256 < 32 ? (n + 255) / 256 : 32;
     hipLaunchKernelGGL(k_splice, dim3(gx, B * frames), dim3(256), 0, as_stream(stream), x, imgs, out, B, n, cs_mode,
                        hue_thres, sat_thres, val_thres, eps);
+    return augcl::check_launch(name);
+}
+
+int augcl_green_screen_u8(const uint8_t *x, const uint8_t *bg, uint8_t *out, int N, int H, int W, augcl_stream_t stream)
+{
+    const char *name = "augcl_green_screen_u8";
+    AUGCL_REQUIRE(N >= 0 && H > 0 && W > 0, "%s: bad shape", name);
+    if (N == 0) return AUGCL_OK;
+    AUGCL_REQUIRE(x && bg && out, "%s: null tensor", name);
+    const int n = H * W;
+    const int gx = (n + 255) / 256 < 64 ? (n + 255) / 256 : 64;
+    hipLaunchKernelGGL(k_green_screen, dim3(gx, N), dim3(256), 0, as_stream(stream), x, bg, out, n);
     return augcl::check_launch(name);
 }
 

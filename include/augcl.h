@@ -120,6 +120,11 @@ int augcl_random_grayscale_f32(const float *in, float *out, int B, int frames, i
 int augcl_splice_f32(const float *x, const float *imgs, float *out, int B, int frames, int H, int W, int cs_mode,
                      float hue_thres, float sat_thres, float val_thres, float eps, augcl_stream_t stream);
 
+/* ---- eval side: do_green_screen (src/env/wrappers.py:209-260), the video_easy / video_hard background keying the
+ * reference runs as a per-pixel Python loop: x, bg, out = (N,3,H,W) uint8; a pixel whose HSV (double arithmetic,
+ * colorsys formulas) lies in h*360 in [100,185], s*255 in [80,255], v*255 in [70,255] takes the bg pixel. */
+int augcl_green_screen_u8(const uint8_t *x, const uint8_t *bg, uint8_t *out, int N, int H, int W, augcl_stream_t stream);
+
 /* ---- fused SVEA/AugCL front end: src/algorithms/svea.py:68 + :49 (random_shift, then
  * apply_aug=random_conv on the shifted clone) in one pass over the uint8/f32 observation:
  * out_shift = random_shift(in); out_aug = random_conv(out_shift).  Either output may be NULL. */

@@ -246,3 +246,23 @@ def splice_np(x, imgs, hue_thres=0.0, sat_thres=0.0, val_thres=0.6, cs=False, ep
         use = keep
     out = np.where(use[:, None], rgb, ov)
     return (out.reshape(n, c, hh, ww) * np.float32(255.0)).astype(np.float32)
+
+
+def green_screen_np(x, bg):
+    """src/env/wrappers.py:209-260 do_green_screen (+ rgb_to_hsv L209-228), vectorised in float64 exactly as the
+    reference's per-pixel Python arithmetic: keyed pixels (h*360 in [100,185], s*255 in [80,255], v*255 in
+    [70,255]) take the background.  x, bg: (...,3,H,W) uint8."""
+    x = np.asarray(x)
+    bg = np.asarray(bg)
+    r, g, b = (x[..., i, :, :].astype(np.float64) / 255.0 for i in range(3))
+    maxc = np.maximum(np.maximum(r, g), b)
+    minc = np.minimum(np.minimum(r, g), b)
+    eq = minc == maxc
+    d = np.where(eq, 1.0, maxc - minc)
+    s = np.where(eq, 0.0, (maxc - minc) / np.where(maxc == 0, 1.0, maxc))
+    rc, gc, bc = (maxc - r) / d, (maxc - g) / d, (maxc - b) / d
+    h = np.where(r == maxc, bc - gc, np.where(g == maxc, 2.0 + rc - bc, 4.0 + gc - rc))
+    h = np.where(eq, 0.0, (h / 6.0) % 1.0)
+    hh, ss, vv = h * 360, s * 255, maxc * 255
+    key = (100 <= hh) & (hh <= 185) & (80 <= ss) & (ss <= 255) & (70 <= vv) & (vv <= 255)
+    return np.where(key[..., None, :, :], bg, x).astype(np.uint8)

@@ -25,6 +25,12 @@ def golden_aug_extra():
 
 
 @pytest.fixture(scope="session")
+def golden_eval():
+    import numpy as np
+    return np.load(os.path.join(ROOT, "tests", "golden", "eval_golden.npz"))
+
+
+@pytest.fixture(scope="session")
 def cuda():
     import torch
     if not torch.cuda.is_available():

@@ -79,3 +79,17 @@ def replay_stream(seed, n, A, ep_len=7, stack=3, H=H, W=W):
         done = t >= ep_len
         yield list(frames), rs.uniform(-1, 1, size=A).astype(np.float32), float(rs.uniform(0, 4)), list(nxt), done
         frames = None if done else nxt
+
+
+def green_frame_u8(seed, H=100, W=100):
+    """A rendered-frame-like (3,H,W) uint8 image: greenish background (several hues / saturations around the keying
+    thresholds of src/env/wrappers.py:246-248), a non-green 'body', plus noise so that every threshold is crossed."""
+    rs = np.random.RandomState(seed)
+    img = np.empty((3, H, W), np.uint8)
+    img[0] = rs.randint(0, 120, (H, W))
+    img[1] = rs.randint(60, 256, (H, W))
+    img[2] = rs.randint(0, 140, (H, W))
+    img[:, H // 3:2 * H // 3, W // 4:3 * W // 4] = rs.randint(0, 256, (3, H // 3 + (H % 3 > 0) * 0, W // 2)).astype(np.uint8)[:, :2 * H // 3 - H // 3]
+    img[:, :4, :4] = 128  # gray: minc == maxc branch
+    img[:, 4:8, :4] = np.array([0, 255, 0], np.uint8)[:, None, None]  # pure green
+    return img

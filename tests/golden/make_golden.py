@@ -308,6 +308,37 @@ def make_extra():
     print("wrote aug_extra_golden.npz", {k: v.shape for k, v in out.items()})
 
 
+def make_eval():
+    """Eval-side pixel op: wrappers.do_green_screen (src/env/wrappers.py:231-260), the reference's own function run
+    on seeded frames.  gym / dmc2gym are absent (empty placeholders, never called); torchvision's
+    TF.to_pil_image is PIL.Image.fromarray on the HWC view, which is all that function does for a uint8 CHW tensor."""
+    from PIL import Image
+    for n in ["gym", "dmc2gym", "torchvision.transforms.functional"]:
+        sys.modules[n] = types.ModuleType(n)
+    sys.modules["gym"].Wrapper = object
+    sys.modules["gym"].spaces = types.SimpleNamespace(Box=object)
+    sys.modules["torchvision.transforms"].functional = sys.modules["torchvision.transforms.functional"]
+    sys.modules["torchvision.transforms.functional"].to_pil_image = \
+        lambda t: Image.fromarray(np.ascontiguousarray(t.numpy().transpose(1, 2, 0)))
+    sys.path.insert(0, os.path.join(REF, "env"))
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_wrappers", os.path.join(REF, "env", "wrappers.py"))
+    wr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(wr)
+    out = {}
+    for i, (seed, H, W) in enumerate(((41, 100, 100), (42, 84, 84))):
+        x = gi.green_frame_u8(seed, H, W)
+        bg = gi.obs_u8(seed + 100, 1, C=3, H=H, W=W)[0]
+        y = wr.do_green_screen(x.copy(), bg.copy())
+        assert y.shape == x.shape and y.dtype == np.uint8
+        frac = float((y != x).any(axis=0).mean())
+        assert 0.1 < frac < 0.9, frac
+        out[f"gs{i}_out"] = y
+    np.savez_compressed(os.path.join(HERE, "eval_golden.npz"), **out)
+    print("wrote eval_golden.npz", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
     make_aug()
-    make_extra()  # networks / update() goldens: make_golden_sac.py (separate process)
+    make_extra()
+    make_eval()  # networks / update() goldens: make_golden_sac.py (separate process)

@@ -388,3 +388,22 @@ def test_splice_golden_and_oracle(cuda, golden_aug_extra):
         aug.set_overlay_source(None)
     with pytest.raises(FileNotFoundError):
         aug.splice(xd)
+
+
+@pytest.mark.gpu
+def test_green_screen_golden_and_all_colours(cuda, golden_eval):
+    from augcl_amd import eval_ops
+    for i, (seed, H, W) in enumerate(((41, 100, 100), (42, 84, 84))):
+        x = gi.green_frame_u8(seed, H, W)
+        bg = gi.obs_u8(seed + 100, 1, C=3, H=H, W=W)[0]
+        assert np.array_equal(eval_ops.do_green_screen(x, bg), golden_eval[f"gs{i}_out"])
+    # every one of the 2^24 colours once: (N,3,256,256) with r = frame index
+    r = np.arange(256, dtype=np.uint8)
+    x = np.empty((256, 3, 256, 256), np.uint8)
+    x[:, 0] = r[:, None, None]
+    x[:, 1] = r[None, :, None]
+    x[:, 2] = r[None, None, :]
+    bg = np.full_like(x, 7)
+    got = host(eval_ops.green_screen(dev(x, cuda), dev(bg, cuda)))
+    assert np.array_equal(got, orc.green_screen_np(x, bg))
+    assert 0.05 < float((got[:, 0] == 7).mean()) < 0.5

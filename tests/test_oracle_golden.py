@@ -117,3 +117,11 @@ def test_splice_matches_callsite_golden(golden_aug_extra):
     assert np.array_equal(orc.splice_np(x, ov), g["splice_out"])
     assert np.array_equal(orc.splice_np(x, ov, val_thres=0.4), g["splice_easy_out"])
     assert np.array_equal(orc.splice_np(x, ov, hue_thres=3.5, val_thres=0.0, cs=True), g["cs_splice_out"])
+
+
+def test_green_screen_bit_exact(golden_eval):
+    # wrappers.do_green_screen run on seeded frames (tests/golden/make_golden.py: make_eval)
+    for i, (seed, H, W) in enumerate(((41, 100, 100), (42, 84, 84))):
+        x = gi.green_frame_u8(seed, H, W)
+        bg = gi.obs_u8(seed + 100, 1, C=3, H=H, W=W)[0]
+        assert np.array_equal(orc.green_screen_np(x, bg), golden_eval[f"gs{i}_out"])

@@ -274,3 +274,53 @@ def test_hip_graph_update_matches_eager(cuda, algo, data_aug, A):
     assert e[4].keys() == gr[4].keys()
     for k in e[4]:
         assert abs(e[4][k] - gr[4][k]) <= 1e-4 * max(1.0, abs(e[4][k])), k
+
+
+def test_checkpoint_state_roundtrip_and_reference_layout(cuda, tmp_path):
+    """checkpoint.agent_state / load_agent_state: reference parameter names, torch.optim.Adam state layout indexed by
+    position in module.parameters(), and a save -> load into a fresh agent that continues on the same trajectory."""
+    from augcl_amd import checkpoint
+    args = au.dotdict(algorithm="svea", data_aug="conv", aug_params=None, **so.DEFAULTS)
+    B, A = 8, 6
+    g = torch.Generator(device=cuda).manual_seed(4)
+    batch = (torch.randint(0, 256, (B, 9, 84, 84), device=cuda, generator=g).float(), torch.rand(B, A, device=cuda) * 2 - 1,
+             torch.rand(B, 1, device=cuda), torch.randint(0, 256, (B, 9, 84, 84), device=cuda, generator=g).float(),
+             torch.ones(B, 1, device=cuda))
+    from augcl_amd import augmentations as aug
+
+    def run(agent, steps, first):
+        for s in range(first, first + steps):
+            torch.manual_seed(100 + s)
+            aug.manual_seed(200 + s)
+            agent.update(FakeBuffer(batch), None, s)
+
+    torch.manual_seed(1)
+    a1 = make_agent(T.OBS, (A,), args)
+    run(a1, 3, 0)
+    st = checkpoint.agent_state(a1)
+    # reference naming + Adam layout
+    assert "encoder.shared_cnn.layers.2.weight" in st["critic"] and "Q1.trunk.0.weight" in st["critic"] and "mlp.4.bias" in st["actor"]
+    n_critic = len(list(a1.critic.parameters()))
+    assert sorted(st["critic_optimizer"]["state"]) == list(range(n_critic))
+    assert st["critic_optimizer"]["param_groups"][0]["params"] == list(range(n_critic))
+    shared = {id(p) for p in a1.critic.parameters()}
+    moved = [i for i, p in enumerate(a1.actor.parameters()) if id(p) not in shared]
+    assert sorted(st["actor_optimizer"]["state"]) == moved  # the shared CNN has no state in the actor's optimiser
+    assert float(st["critic_optimizer"]["state"][0]["step"]) == 3.0
+    ref_opt = torch.optim.Adam([torch.nn.Parameter(p.detach().cpu().clone()) for p in a1.critic.parameters()], lr=1e-3)
+    ref_opt.load_state_dict(st["critic_optimizer"])  # torch's own Adam accepts it
+
+    path = tmp_path / "agent_state.pt"
+    checkpoint.save(a1, path)
+    torch.manual_seed(2)
+    a2 = make_agent(T.OBS, (A,), args)
+    checkpoint.load(a2, path)
+    for n in ("critic_group", "actor_group", "target_group"):
+        assert torch.equal(getattr(a1, n).param, getattr(a2, n).param), n
+    assert a2.critic_optimizer.step_count == 3 and torch.equal(a1.critic_optimizer.exp_avg, a2.critic_optimizer.exp_avg)
+    assert a2.actor.encoder.shared_cnn.layers[2].weight.data_ptr() == a2.critic.encoder.shared_cnn.layers[2].weight.data_ptr()
+    run(a1, 2, 3)
+    run(a2, 2, 3)
+    for n in ("critic_group", "actor_group", "target_group"):
+        assert torch.equal(getattr(a1, n).param, getattr(a2, n).param), n
+    assert torch.equal(a1.log_alpha, a2.log_alpha)
