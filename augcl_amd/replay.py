@@ -10,9 +10,13 @@ tensor that writes the stacked (B, 3*stack, H, W) batch -- float32 like `tensor_
 uint8 for the fused uint8 front end (`augmentations.shift_conv`) -- straight into HBM.  No per-sample host loop,
 no 2 x B x 63.5 KB PCIe transfer per update.
 
-save/load of the reference's pickled "{start}_{end}.tar" chunks (src/utils.py:156-204) is host bookkeeping
-outside the accelerated path; `state_dict()/load_state_dict()` carry the ring instead.
+`save / requeue_save / load` keep the reference's incremental "{start}_{end}.tar" chunk files and bookkeeping
+(src/utils.py:156-204); a chunk holds plain tensors (the frames its transitions reference, once each, plus their
+index tables) instead of pickled LazyFrames objects, so it opens with `torch.load(weights_only=True)`.
+`state_dict()/load_state_dict()` carry the whole ring.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -71,6 +75,9 @@ class ReplayBuffer(object):
         self.sample_dtype = sample_dtype
         self.idx = 0
         self.full = False
+        self.last_save = 0
+        self.last_requeue_save = 0
+        self.refilled = False
 
     # ---- storing --------------------------------------------------------------------------------
     def _frames_of(self, obs):
@@ -160,6 +167,63 @@ class ReplayBuffer(object):
         return augmentations.random_shift(obs, pad), actions, rewards, augmentations.random_shift(next_obs, pad), not_dones
 
     # ---- persistence ----------------------------------------------------------------------------
+    def __save__(self, save_dir, last_save_idx):
+        """src/utils.py:156-168: transitions [last_save_idx, idx) -> "<start>_<end>.tar"."""
+        if self.idx == last_save_idx:
+            return self.idx
+        a, b = last_save_idx, self.idx
+        seqs = np.unique(np.concatenate([self.obs_seq[a:b].ravel(), self.next_seq[a:b].ravel()]))
+        if seqs.min() < self.frame_seq - self.n_slots:
+            raise _lib.AugclError("replay save: a frame of an unsaved transition was already overwritten")
+        slots = torch.from_numpy(seqs % self.n_slots).to(self.device)
+        payload = dict(frames=self.frames[slots].cpu(), seqs=torch.from_numpy(seqs), obs_seq=torch.from_numpy(self.obs_seq[a:b].copy()),
+                       next_seq=torch.from_numpy(self.next_seq[a:b].copy()), actions=self.actions[a:b].cpu(),
+                       rewards=self.rewards[a:b].cpu(), not_dones=self.not_dones[a:b].cpu())
+        torch.save(payload, os.path.join(save_dir, "%d_%d.tar" % (a, b)))
+        return self.idx
+
+    def save(self, save_dir):
+        self.last_save = self.__save__(save_dir=save_dir, last_save_idx=self.last_save)
+
+    def requeue_save(self, save_dir):
+        self.last_requeue_save = self.__save__(save_dir=save_dir, last_save_idx=self.last_requeue_save)
+
+    def load(self, save_dir, end_step=None, is_requeue_load=True, is_load=True):
+        """src/utils.py:178-204: chunks in order of their start index, each must begin where the buffer stands."""
+        if self.refilled:
+            return
+        chunks = sorted(os.listdir(save_dir), key=lambda x: int(x.split("_")[0]))
+        remap = {}  # frame sequence number in the saved buffer -> here
+        for chunk in chunks:
+            start, end = [int(x) for x in chunk.split(".")[0].split("_")]
+            payload = torch.load(os.path.join(save_dir, chunk), map_location="cpu", weights_only=True)
+            assert self.idx == start, (f"self.idx: {self.idx} DNE start: {start} for save_dir: {save_dir}. "
+                                       f"Current chunk is {chunk}. Chucks: {chunks}.")
+            seqs = payload["seqs"].numpy()
+            new = [i for i, s in enumerate(seqs.tolist()) if s not in remap]
+            if new:
+                first = self.frame_seq
+                for k, i in enumerate(new):
+                    remap[int(seqs[i])] = first + k
+                self.frame_seq += len(new)
+                slots = torch.from_numpy((np.arange(first, first + len(new)) % self.n_slots)).to(self.device)
+                self.frames[slots] = payload["frames"][torch.as_tensor(new)].to(self.device)
+            lut = np.vectorize(remap.__getitem__, otypes=[np.int64])
+            self.obs_seq[start:end] = lut(payload["obs_seq"].numpy())
+            self.next_seq[start:end] = lut(payload["next_seq"].numpy())
+            self.actions[start:end] = payload["actions"].to(self.device)
+            self.rewards[start:end] = payload["rewards"].to(self.device)
+            self.not_dones[start:end] = payload["not_dones"].to(self.device)
+            self.idx = end
+            if end == end_step:
+                break
+        self._ids.clear()
+        self._ids_order.clear()
+        if is_requeue_load:
+            self.last_requeue_save = self.idx
+        if is_load:
+            self.last_save = self.idx
+
     def state_dict(self):
         return dict(frames=self.frames.cpu(), frame_seq=self.frame_seq, obs_seq=self.obs_seq.copy(),
                     next_seq=self.next_seq.copy(), actions=self.actions.cpu(), rewards=self.rewards.cpu(),

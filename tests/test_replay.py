@@ -108,3 +108,46 @@ def test_ring_overwrite_is_detected_and_agent_consumes_samples(cuda):
     np.random.seed(0)
     agent.update(buf, None, 0)
     assert not torch.equal(before, agent.critic_group.param)
+
+
+@pytest.mark.gpu
+def test_chunked_save_and_load_like_the_reference(cuda, tmp_path):
+    """save / requeue_save / load keep the reference's "<start>_<end>.tar" incremental chunks and bookkeeping
+    (src/utils.py:156-204); a buffer refilled from the chunks samples the same batches bit for bit."""
+    import torch
+
+    from augcl_amd.replay import LazyFrames, ReplayBuffer
+    cap = 64
+    rb = ReplayBuffer((9, 84, 84), (A,), cap, B, device=cuda)
+    stream = list(gi.replay_stream(seed=31, n=40, A=A))
+    d = str(tmp_path)
+    for i, (fo, a, r, fn, done) in enumerate(stream):
+        rb.add(LazyFrames(fo), a, r, LazyFrames(fn), done)
+        if i in (14, 29):
+            rb.save(d)
+    rb.save(d)
+    rb.save(d)  # nothing new: no empty chunk
+    assert sorted(os.listdir(d), key=lambda x: int(x.split("_")[0])) == ["0_15.tar", "15_30.tar", "30_40.tar"]
+    assert rb.last_save == 40
+    payload = torch.load(os.path.join(d, "15_30.tar"), weights_only=True)  # plain tensors only
+    assert payload["frames"].dtype == torch.uint8 and payload["frames"].shape[0] == payload["seqs"].numel()
+
+    rb2 = ReplayBuffer((9, 84, 84), (A,), cap, B, device=cuda)
+    rb2.load(d)
+    assert rb2.idx == 40 and rb2.last_save == 40 and rb2.last_requeue_save == 40
+    for seed in (1, 2, 3):
+        np.random.seed(seed)
+        want = rb.sample()
+        np.random.seed(seed)
+        got = rb2.sample()
+        for x, y in zip(want, got):
+            assert torch.equal(x, y)
+    # frames shared between chunks are stored once
+    assert rb2.frame_seq == rb.frame_seq
+    # end_step stops after the chunk that ends there; a gap in the chunk sequence is refused like the reference
+    rb3 = ReplayBuffer((9, 84, 84), (A,), cap, B, device=cuda)
+    rb3.load(d, end_step=30)
+    assert rb3.idx == 30
+    os.remove(os.path.join(d, "0_15.tar"))
+    with pytest.raises(AssertionError):
+        ReplayBuffer((9, 84, 84), (A,), cap, B, device=cuda).load(d)
