@@ -68,6 +68,7 @@ _SIGS = {
     "augcl_cutout_color_f32": [_P, _P, _I, _I, _I, _I, _P, _P, _P],
     "augcl_random_grayscale_f32": [_P, _P, _I, _I, _I, _I, _P, _P],
     "augcl_splice_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _F, _F, _P],
+    "augcl_replay_sample": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "augcl_green_screen_u8": [_P, _P, _P, _I, _I, _I, _P],
     "augcl_gauss_head_forward": [_P, _P, _P, _P, _P, _P, _I, _I, _D, _D, _P],
     "augcl_gauss_head_backward": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _D, _D, _P],

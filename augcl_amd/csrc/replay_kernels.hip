@@ -28,9 +28,66 @@ __global__ __launch_bounds__(256) void k_replay_gather(const uint8_t *__restrict
     }
 }
 
+// The whole ReplayBuffer.sample() in one launch: transition indices idx[B] pick rows of the device-resident tables
+// (slot_tab[cap][2*stack] = ring slots of the obs / next_obs frame stacks, scal[cap][S] = action | reward | not_done)
+// and both stacked batches plus the scalars are written.  Work item q < 2*B*stack*fq: one dword (4 pixels).
+template <typename TOut>
+__global__ __launch_bounds__(256) void k_replay_sample(const uint8_t *__restrict__ frames,
+                                                       const int32_t *__restrict__ slot_tab,
+                                                       const float *__restrict__ scal, const int64_t *__restrict__ idx,
+                                                       TOut *__restrict__ obs, TOut *__restrict__ next_obs,
+                                                       float *__restrict__ scal_out, int B, int stack, int fq, int S)
+{
+    const size_t per = (size_t)B * stack * fq, total = 2 * per;
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (size_t)gridDim.x * 256) {
+        const int which = q >= per;
+        const size_t r = q - which * per;
+        const size_t fi = r / fq; // = b*stack + k
+        const int off = (int)(r - fi * fq);
+        const int b = (int)(fi / stack), k = (int)(fi - (size_t)b * stack);
+        const int slot = slot_tab[idx[b] * (2 * stack) + which * stack + k];
+        const uint32_t v = reinterpret_cast<const uint32_t *>(frames)[(size_t)slot * fq + off];
+        TOut *out = which ? next_obs : obs;
+        if constexpr (sizeof(TOut) == 1)
+            reinterpret_cast<uint32_t *>(out)[r] = v;
+        else
+            reinterpret_cast<float4 *>(out)[r] =
+                make_float4((float)(v & 0xffu), (float)((v >> 8) & 0xffu), (float)((v >> 16) & 0xffu), (float)(v >> 24));
+    }
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < (size_t)B * S; q += (size_t)gridDim.x * 256) {
+        const int b = (int)(q / S), j = (int)(q - (size_t)b * S);
+        // outputs as three contiguous blocks: actions [B][S-2], rewards [B], not_dones [B]
+        const int A = S - 2;
+        scal_out[j < A ? (size_t)b * A + j : (size_t)B * A + (size_t)(j - A) * B + b] = scal[idx[b] * S + j];
+    }
+}
+
 } // namespace augcl
 
 using namespace augcl;
+
+extern "C" int augcl_replay_sample(const uint8_t *frames, const int32_t *slot_tab, const float *scal, const int64_t *idx,
+                                   void *obs, void *next_obs, float *scal_out, int B, int stack, int frame_bytes, int S,
+                                   int out_f32, augcl_stream_t stream)
+{
+    const char *name = "augcl_replay_sample";
+    AUGCL_REQUIRE(B >= 0 && stack > 0 && frame_bytes > 0 && (frame_bytes & 3) == 0 && S >= 0, "%s: bad shape", name);
+    if (B == 0) return AUGCL_OK;
+    AUGCL_REQUIRE(frames && slot_tab && idx && obs && next_obs && (S == 0 || (scal && scal_out)), "%s: null buffer", name);
+    AUGCL_REQUIRE(aligned16(frames) && aligned16(obs) && aligned16(next_obs), "%s: buffers must be 16-byte aligned", name);
+    const int fq = frame_bytes / 4;
+    const size_t total = (size_t)2 * B * stack * fq;
+    const size_t blocks = (total + 255) / 256;
+    const unsigned grid = (unsigned)(blocks < 16384 ? blocks : 16384);
+    hipStream_t s = as_stream(stream);
+    if (out_f32)
+        hipLaunchKernelGGL(k_replay_sample<float>, dim3(grid), dim3(256), 0, s, frames, slot_tab, scal, idx, (float *)obs,
+                           (float *)next_obs, scal_out, B, stack, fq, S);
+    else
+        hipLaunchKernelGGL(k_replay_sample<uint8_t>, dim3(grid), dim3(256), 0, s, frames, slot_tab, scal, idx,
+                           (uint8_t *)obs, (uint8_t *)next_obs, scal_out, B, stack, fq, S);
+    return augcl::check_launch(name);
+}
 
 extern "C" int augcl_replay_gather(const uint8_t *frames, const int32_t *slots, void *out, int B, int stack,
                                    int frame_bytes, int out_f32, augcl_stream_t stream)

@@ -67,11 +67,16 @@ class ReplayBuffer(object):
         self._ids_order = []
         self.obs_seq = np.zeros((self.capacity, self.stack), dtype=np.int64)
         self.next_seq = np.zeros((self.capacity, self.stack), dtype=np.int64)
-        self.actions = torch.empty((self.capacity, *action_shape), dtype=torch.float32, device=self.device)
-        self.rewards = torch.empty((self.capacity, 1), dtype=torch.float32, device=self.device)
-        self.not_dones = torch.empty((self.capacity, 1), dtype=torch.float32, device=self.device)
-        self._scal = torch.empty((1, int(np.prod(action_shape)) + 2), dtype=torch.float32).pin_memory() \
-            if self.device.type == "cuda" else torch.empty((1, int(np.prod(action_shape)) + 2))
+        assert len(action_shape) == 1, "flat action vectors"
+        A = self.A = int(action_shape[0])
+        # device-resident tables sample() gathers from in ONE launch: per transition the ring slots of its two frame
+        # stacks, and action | reward | not_done as one row
+        self.scal = torch.zeros((self.capacity, A + 2), dtype=torch.float32, device=self.device)
+        self.actions, self.rewards, self.not_dones = self.scal[:, :A], self.scal[:, A:A + 1], self.scal[:, A + 1:A + 2]
+        self.slot_tab = torch.zeros((self.capacity, 2 * self.stack), dtype=torch.int32, device=self.device)
+        pin = (lambda t: t.pin_memory()) if self.device.type == "cuda" else (lambda t: t)
+        self._scal = pin(torch.empty((A + 2,), dtype=torch.float32))
+        self._slots = pin(torch.empty((2 * self.stack,), dtype=torch.int32))
         self.sample_dtype = sample_dtype
         self.idx = 0
         self.full = False
@@ -117,13 +122,13 @@ class ReplayBuffer(object):
         self.obs_seq[self.idx] = [self._store_frame(f, by_content) for f in self._frames_of(obs)]
         self.next_seq[self.idx] = [self._store_frame(f, by_content) for f in self._frames_of(next_obs)]
         a = np.asarray(action, dtype=np.float32).reshape(-1)
-        self._scal[0, :a.size] = torch.from_numpy(a)
-        self._scal[0, a.size] = float(reward)
-        self._scal[0, a.size + 1] = float(not done)
-        row = self._scal.to(self.device, non_blocking=False)
-        self.actions[self.idx] = row[0, :a.size].view(self.actions.shape[1:])
-        self.rewards[self.idx] = row[0, a.size]
-        self.not_dones[self.idx] = row[0, a.size + 1]
+        sc = self._scal.numpy()
+        sc[:a.size], sc[a.size], sc[a.size + 1] = a, float(reward), float(not done)
+        sl = self._slots.numpy()
+        sl[:self.stack] = self.obs_seq[self.idx] % self.n_slots
+        sl[self.stack:] = self.next_seq[self.idx] % self.n_slots
+        self.scal[self.idx].copy_(self._scal)  # two small pinned -> HBM row copies per environment step
+        self.slot_tab[self.idx].copy_(self._slots)
         self.idx = (self.idx + 1) % self.capacity
         self.full = self.full or self.idx == 0
 
@@ -146,16 +151,31 @@ class ReplayBuffer(object):
                   self.frame_bytes, 1 if dtype == torch.float32 else 0, _lib.current_stream(self.device))
         return out
 
+    def _sync_tables(self, a=0, b=None):
+        """Refresh the device slot table for transitions [a, b) from the host sequence tables."""
+        b = self.capacity if b is None else b
+        tab = np.concatenate([self.obs_seq[a:b], self.next_seq[a:b]], axis=1) % self.n_slots
+        self.slot_tab[a:b] = torch.from_numpy(tab.astype(np.int32)).to(self.device)
+
     def sample(self, n=None, idxs=None, dtype=None):
-        """src/utils.py:272-280: returns (obs, actions, rewards, next_obs, not_dones) on the device."""
+        """src/utils.py:272-280: returns (obs, actions, rewards, next_obs, not_dones) on the device -- one H2D copy
+        of the drawn indices and one launch (augcl_replay_sample) for all five tensors."""
         if idxs is None:
             idxs = self._get_idxs(n)
-        idxs = np.asarray(idxs)
+        idxs = np.ascontiguousarray(idxs, dtype=np.int64)
         dtype = dtype or self.sample_dtype
-        obs = self._gather(self.obs_seq[idxs], dtype)
-        next_obs = self._gather(self.next_seq[idxs], dtype)
-        it = torch.from_numpy(idxs.astype(np.int64)).to(self.device)
-        return obs, self.actions[it], self.rewards[it], next_obs, self.not_dones[it]
+        if min(self.obs_seq[idxs].min(), self.next_seq[idxs].min()) < self.frame_seq - self.n_slots:
+            raise _lib.AugclError("replay frame ring too small: a sampled transition's frame was overwritten "
+                                  f"(slots={self.n_slots}); raise frame_slack")
+        B, A = idxs.shape[0], self.A
+        it = torch.from_numpy(idxs).to(self.device, non_blocking=True)
+        obs = torch.empty((B, 3 * self.stack, self.h, self.w), dtype=dtype, device=self.device)
+        next_obs = torch.empty_like(obs)
+        sc = torch.empty(B * (A + 2), dtype=torch.float32, device=self.device)
+        _lib.call("augcl_replay_sample", self.frames.data_ptr(), self.slot_tab.data_ptr(), self.scal.data_ptr(), it.data_ptr(),
+                  obs.data_ptr(), next_obs.data_ptr(), sc.data_ptr(), B, self.stack, self.frame_bytes, A + 2,
+                  1 if dtype == torch.float32 else 0, _lib.current_stream(self.device))
+        return (obs, sc[:B * A].view(B, A), sc[B * A:B * A + B].view(B, 1), next_obs, sc[B * A + B:].view(B, 1))
 
     def sample_obs(self, n=None):
         return self._gather(self.obs_seq[self._get_idxs(n)], torch.float32)
@@ -211,6 +231,7 @@ class ReplayBuffer(object):
             lut = np.vectorize(remap.__getitem__, otypes=[np.int64])
             self.obs_seq[start:end] = lut(payload["obs_seq"].numpy())
             self.next_seq[start:end] = lut(payload["next_seq"].numpy())
+            self._sync_tables(start, end)
             self.actions[start:end] = payload["actions"].to(self.device)
             self.rewards[start:end] = payload["rewards"].to(self.device)
             self.not_dones[start:end] = payload["not_dones"].to(self.device)
@@ -233,6 +254,7 @@ class ReplayBuffer(object):
         self.frames.copy_(sd["frames"])
         self.frame_seq, self.idx, self.full = int(sd["frame_seq"]), int(sd["idx"]), bool(sd["full"])
         self.obs_seq[:], self.next_seq[:] = sd["obs_seq"], sd["next_seq"]
+        self._sync_tables()
         self.actions.copy_(sd["actions"])
         self.rewards.copy_(sd["rewards"])
         self.not_dones.copy_(sd["not_dones"])

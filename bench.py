@@ -219,6 +219,7 @@ def main():
         rb.frame_seq = rb.n_slots
         rb.obs_seq[:] = (np.arange(20000)[:, None] + np.arange(3)[None, :]) % rb.n_slots
         rb.next_seq[:] = (rb.obs_seq + 1) % rb.n_slots
+        rb._sync_tables()
         rb.idx, rb.full = 0, True
         BYTES_PER_OBS["replay_sample_f32"] = 2 * OBS_ELEMS * 5
         rate("replay_sample_f32", lambda i: rb.sample())

@@ -249,6 +249,13 @@ int augcl_enc_stack_backward(const void *const *acts_in, const float *const *w, 
  * out[b, 3k:3k+3, :, :] = frames[slot]; out is uint8 (out_f32 = 0) or float32 (the `.float()` of utils.py:208). */
 int augcl_replay_gather(const uint8_t *frames, const int32_t *slots, void *out, int B, int stack, int frame_bytes,
                         int out_f32, augcl_stream_t stream);
+/* The whole sample() (src/utils.py:272-280) in one launch from device-resident tables: idx[B] (int64 transition
+ * indices, the np.random.randint draw) selects rows of slot_tab[cap][2*stack] (ring slots of the obs | next_obs
+ * stacks) and scal[cap][S] (action | reward | not_done); obs / next_obs get the stacked batches (uint8 or float32),
+ * scal_out the scalars as three contiguous blocks: actions [B][S-2], rewards [B], not_dones [B]. */
+int augcl_replay_sample(const uint8_t *frames, const int32_t *slot_tab, const float *scal, const int64_t *idx, void *obs,
+                        void *next_obs, float *scal_out, int B, int stack, int frame_bytes, int S, int out_f32,
+                        augcl_stream_t stream);
 
 #ifdef __cplusplus
 }
