@@ -131,14 +131,29 @@ __global__ __launch_bounds__(512, 2) void k_conv32(ConvArgs a)
     const int Wi = a.Wi;
     const int plane = round4((a.RT + 2) * Wi);
     const int G = MODE ? round4(2 * Wi + 4) : 0;
-    const int mwords = MODE ? round4(a.RT * a.Wo) : 0; // backward-data: ReLU gate bits, one word per strip pixel
-    const int bufw = 2 * G + 32 * plane + mwords;        // words per buffer
-    float *lbias = lds_raw + 2 * bufw;
+    const int bufw = 2 * G + 32 * plane; // words per buffer
+    constexpr int WROW = 292;            // weight staging row pitch (16-byte aligned rows, conflict-free reads)
+    float *lbias = lds_raw + max(2 * bufw, bufw + 32 * WROW);
 
+    // weights: all 512 threads copy the 36 KB into LDS with coalesced 16-byte loads (the region of tile buffer 1,
+    // first written by the loader after the second barrier), then each compute lane picks its 144 out of LDS.
+    // (Gathered straight from global memory they cost ~4 us per launch: 2304 cache lines per wave.)
+    {
+        typedef float wf4 __attribute__((ext_vector_type(4)));
+        float *wst = lds_raw + bufw;
+        const wf4 *w4 = reinterpret_cast<const wf4 *>(a.w);
+        for (int i = tid; i < 32 * 288 / 4; i += 512) {
+            const int row = (4 * i) / 288, col = 4 * i - row * 288;
+            *reinterpret_cast<wf4 *>(wst + row * WROW + col) = w4[i];
+        }
+        if (tid < 32) lbias[tid] = (MODE == 0 && a.bias) ? a.bias[tid] : 0.0f;
+    }
+    __syncthreads();
     float wreg[144];
     if (!loader) {
+        const float *wst = lds_raw + bufw;
         if (MODE == 0) {
-            const float *wp = a.w + (size_t)l31 * 288 + h * 144; // contiguous 144 floats
+            const float *wp = wst + l31 * WROW + h * 144; // contiguous 144 floats
 #pragma unroll
             for (int k = 0; k < 144; k += 4) {
                 const float4 v = *reinterpret_cast<const float4 *>(wp + k);
@@ -149,10 +164,12 @@ __global__ __launch_bounds__(512, 2) void k_conv32(ConvArgs a)
             for (int cil = 0; cil < 16; ++cil)
 #pragma unroll
                 for (int t = 0; t < 9; ++t) // W'[ci=l31][co=cil+16h][ky][kx] = W[co][ci][2-ky][2-kx]
-                    wreg[cil * 9 + t] = a.w[(size_t)(cil + 16 * h) * 288 + l31 * 9 + (8 - t)];
+                    wreg[cil * 9 + t] = wst[(cil + 16 * h) * WROW + l31 * 9 + (8 - t)];
         }
     }
-    if (tid < 32) lbias[tid] = (MODE == 0 && a.bias) ? a.bias[tid] : 0.0f;
+    f32x16 bias16; // accumulator seed: C operand of a tile's first MFMA
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bias16[r] = lbias[acc_row(r, h)];
 
     // stage item `it` into buffer `bi` (loader waves only): wave cw copies channels 8cw .. 8cw+7, four
     // channel pairs back to back => 24 dwordx4 per lane in flight, one exposed latency per item
@@ -172,27 +189,6 @@ __global__ __launch_bounds__(512, 2) void k_conv32(ConvArgs a)
             wave_copy_runs2<3>(src + ci * cs, src + (ci + 1) * cs, dst + ci * plane, dst + (ci + 1) * plane, run, lane,
                                XfId());
         }
-        if (MODE == 1 && a.mask != nullptr) {
-            // ReLU gate of the layer below, packed by the LOADER waves: word[m] bit co = (a_prev[b,co,y0*Wo+m] > 0).
-            // 32 coalesced loads in flight per lane; the compute waves' epilogue then needs one ds_read instead
-            // of 16 dependent global loads per tile (which exposed ~2 us of latency per tile).
-            uint32_t *mw = reinterpret_cast<uint32_t *>(lds_raw + bi * bufw + 2 * G + 32 * plane);
-            const int npix = rows * a.Wo;
-            const int chw = a.Ho * a.Wo;
-            const float *mp = a.mask + (size_t)b * 32 * chw + (size_t)y0 * a.Wo;
-            for (int m = cw * 64 + lane; m < npix; m += 256) {
-                uint32_t w = 0;
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    float v[16];
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) v[k] = mp[(size_t)(16 * half + k) * chw + m];
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) w |= (v[k] > 0.0f ? 1u : 0u) << (16 * half + k);
-                }
-                mw[m] = w;
-            }
-        }
     };
 
     int it = 0;
@@ -210,7 +206,6 @@ __global__ __launch_bounds__(512, 2) void k_conv32(ConvArgs a)
             const int npix = rows * a.Wo;
             const int r0 = MODE ? max(0, y0 - P) : y0;
             const float *lds = lds_raw + (it & 1) * bufw + G;
-            const uint32_t *maskw = reinterpret_cast<const uint32_t *>(lds_raw + (it & 1) * bufw + 2 * G + 32 * plane);
             // ---- M-tiles of 32 consecutive strip pixels, round-robin over the 4 compute waves
             const int ntiles = (npix + 31) >> 5;
             for (int tile = cw; tile < ntiles; tile += 4) {
@@ -226,9 +221,16 @@ __global__ __launch_bounds__(512, 2) void k_conv32(ConvArgs a)
                     rowok[k] = MODE == 0 || ((unsigned)(y0 + yy + k - P) < (unsigned)a.Hi);
                     colok[k] = MODE == 0 || ((unsigned)(xx + k - P) < (unsigned)Wi);
                 }
-                f32x16 acc;
+                // backward-data: the ReLU gate of the layer below is (a_prev > 0) at this lane's 16 outputs -- the same
+                // addresses it will store to.  Issued NOW, consumed after the 144 MFMAs: the latency is free.
+                const int chw = a.Ho * a.Wo; // 32-bit offsets: the host checks B*32*Ho*Wo < 2^31
+                const int o0 = (b * 32 * a.Ho + (y0 + yy)) * a.Wo + xx + 4 * h * chw;
+                float gv[16];
+                if (MODE == 1 && a.mask != nullptr) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = lbias[acc_row(r, h)];
+                    for (int r = 0; r < 16; ++r) gv[r] = a.mask[o0 + ((r & 3) + 8 * (r >> 2)) * chw];
+                }
+                f32x16 acc;
                 // explicit software pipeline: the 9 taps of channel cil+1 are in flight while the 9 MFMAs of
                 // channel cil issue (one wave per SIMD must never wait on a just-issued ds_read)
                 float xa[9], xb[9];
@@ -245,7 +247,7 @@ __global__ __launch_bounds__(512, 2) void k_conv32(ConvArgs a)
                     for (int t = 0; t < 9; ++t) {
                         float xv = xa[t];
                         if (MODE == 1) xv = (rowok[t / 3] && colok[t % 3]) ? xv : 0.0f;
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[cil * 9 + t], xv, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[cil * 9 + t], xv, (cil == 0 && t == 0) ? bias16 : acc, 0, 0, 0);
                     }
                     if (cil + 2 < NC) {
                         const float *p2 = base + (cil + 2) * plane;
@@ -262,18 +264,14 @@ __global__ __launch_bounds__(512, 2) void k_conv32(ConvArgs a)
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (valid && (ABL != 3 || acc[0] == 12345.678f)) {
-                    const int y = y0 + yy;
-                    const int chw = a.Ho * a.Wo; // 32-bit offsets: the host checks B*32*Ho*Wo < 2^31
-                    const int o0 = (b * 32 * a.Ho + y) * a.Wo + xx + 4 * h * chw;
-                    const uint32_t gate = (MODE == 1 && a.mask) ? (maskw[m] >> (4 * h)) : 0xffffffffu;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int o = o0 + ((r & 3) + 8 * (r >> 2)) * chw;
                         float v = acc[r];
                         if (MODE == 0) {
-                            if (a.relu) v = fmaxf(v, 0.0f);
-                        } else {
-                            v = ((gate >> ((r & 3) + 8 * (r >> 2))) & 1u) ? v : 0.0f;
+                            if (a.relu) v = v > 0.0f ? v : 0.0f;
+                        } else if (a.mask != nullptr) {
+                            v = gv[r] > 0.0f ? v : 0.0f;
                         }
                         a.out[o] = v;
                     }
@@ -802,7 +800,8 @@ int augcl_enc_conv32_forward(const float *in, const float *w, const float *bias,
     a.RT = pick_rt(a.Ho, 32 * Wi, 2, kBufLds, &a.S);
     AUGCL_REQUIRE(a.RT > 0, "%s: image row too wide for LDS (W=%d)", name, Wi);
     a.n_items = B * a.S;
-    const size_t lds = (2 * (size_t)32 * (((a.RT + 2) * Wi + 3) & ~3) + 32) * 4;
+    const size_t bufw = (size_t)32 * (((a.RT + 2) * Wi + 3) & ~3);
+    const size_t lds = (std::max(2 * bufw, bufw + 32 * 292) + 32) * 4; // two tile buffers, or one + the weight staging
     if (int rc = set_lds(k_conv32<0>, lds, name)) return rc;
     hipLaunchKernelGGL(k_conv32<0>, dim3(grid_for(a.n_items, 1)), dim3(512), lds, as_stream(stream), a);
     return augcl::check_launch(name);
@@ -820,10 +819,14 @@ int augcl_enc_conv32_backward_data(const float *dz, const float *w, const float 
     a.in = dz; a.w = w; a.bias = nullptr; a.mask = act_prev; a.out = dact;
     a.B = B; a.Hi = Ho; a.Wi = Wo; a.Ho = Ho + 2; a.Wo = Wo + 2; a.relu = 0;
     const int G = (2 * Wo + 4 + 3) & ~3;
-    a.RT = pick_rt(a.Ho, 32 * Wo + a.Wo, 2, kBufLds - 8 * G - 64, &a.S);
+    AUGCL_REQUIRE(aligned16(w), "%s: weights must be 16-byte aligned", name);
+    // (strip heights: the even split of pick_rt measured better over the 10 layer sizes than minimising the number of
+    // 4-wave tile rounds per image -- fewer, larger strips starve the loader/compute pipeline)
+    a.RT = pick_rt(a.Ho, 32 * Wo, 2, kBufLds - 8 * G - 64, &a.S);
     AUGCL_REQUIRE(a.RT > 0, "%s: image row too wide for LDS (W=%d)", name, Wo);
     a.n_items = B * a.S;
-    const size_t lds = (2 * ((size_t)32 * (((a.RT + 2) * Wo + 3) & ~3) + 2 * G + ((a.RT * a.Wo + 3) & ~3)) + 32) * 4;
+    const size_t bufw = (size_t)32 * (((a.RT + 2) * Wo + 3) & ~3) + 2 * G;
+    const size_t lds = (std::max(2 * bufw, bufw + 32 * 292) + 32) * 4;
     if (int rc = set_lds(k_conv32<1>, lds, name)) return rc;
     hipLaunchKernelGGL(k_conv32<1>, dim3(grid_for(a.n_items, 1)), dim3(512), lds, as_stream(stream), a);
     return augcl::check_launch(name);

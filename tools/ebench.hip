@@ -53,8 +53,8 @@ static void launch_conv(const float *in, const float *w, const float *bias, cons
 {
     ConvArgs a{}; a.in = in; a.w = w; a.bias = bias; a.mask = mask; a.out = out; a.B = B; a.Hi = Hi; a.Wi = Wi; a.relu = 1;
     size_t lds;
-    if (MODE == 0) { a.Ho = Hi - 2; a.Wo = Wi - 2; a.RT = pick_rt(a.Ho, 32 * Wi, 2, kBufLds, &a.S); lds = (2 * (size_t)32 * (((a.RT + 2) * Wi + 3) & ~3) + 32) * 4; }
-    else { a.Ho = Hi + 2; a.Wo = Wi + 2; const int G = (2 * Wi + 4 + 3) & ~3; a.RT = pick_rt(a.Ho, 32 * Wi + a.Wo, 2, kBufLds - 8 * G - 64, &a.S); lds = (2 * ((size_t)32 * (((a.RT + 2) * Wi + 3) & ~3) + 2 * G + ((a.RT * a.Wo + 3) & ~3)) + 32) * 4; }
+    if (MODE == 0) { a.Ho = Hi - 2; a.Wo = Wi - 2; a.RT = pick_rt(a.Ho, 32 * Wi, 2, kBufLds, &a.S); const size_t bw = (size_t)32 * (((a.RT + 2) * Wi + 3) & ~3); lds = (std::max(2 * bw, bw + 32 * 292) + 32) * 4; }
+    else { a.Ho = Hi + 2; a.Wo = Wi + 2; const int G = (2 * Wi + 4 + 3) & ~3; a.RT = pick_rt(a.Ho, 32 * Wi, 2, kBufLds - 8 * G - 64, &a.S); const size_t bw = (size_t)32 * (((a.RT + 2) * Wi + 3) & ~3) + 2 * G; lds = (std::max(2 * bw, bw + 32 * 292) + 32) * 4; }
     a.n_items = B * a.S;
     set_lds(k_conv32<MODE, ABL>, lds, "x");
     hipLaunchKernelGGL((k_conv32<MODE, ABL>), dim3(grid_for(a.n_items, per_cu)), dim3(512), lds, 0, a);
