@@ -114,6 +114,30 @@ def cpu_baseline(target_s):
                       f"{dt:.1f} s, OpenMP {cores} threads on {model}"}
 
 
+def graph_collectives_ok(dist, dev, torch):
+    """Multi-rank pre-flight for the hipGraph leg: can this build capture an RCCL all-reduce and replay it?  Every
+    rank captures (recording only -- nothing can block), the ranks agree on the outcome EAGERLY, and only then is the
+    graph replayed, so a rank whose capture failed never leaves the others waiting inside a collective."""
+    world = dist.get_world_size()
+    t = torch.ones(4096, device=dev)
+    dist.all_reduce(t)  # communicator up, outside any capture
+    torch.cuda.synchronize()
+    g, ok = torch.cuda.CUDAGraph(), 1
+    try:
+        with torch.cuda.graph(g):
+            dist.all_reduce(t)
+    except Exception as e:  # noqa: BLE001
+        print(f"[bench] rank {dist.get_rank()}: all-reduce capture failed ({e!r}); update() will run eagerly", file=sys.stderr)
+        ok = 0
+    flag = torch.tensor([ok], device=dev, dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 0:
+        return False
+    g.replay()
+    torch.cuda.synchronize()
+    return abs(float(t[0].item()) - float(world) * float(world)) < 1e-3
+
+
 def main():
     args = parse()
     import torch
@@ -227,12 +251,15 @@ def main():
         try:
             from augcl_amd import bench_update
             n_upd = max(10, args.steps // 20)
-            # update() replayed from captured hipGraphs (SAC.enable_hip_graphs); the eager figure beside it
-            res["sac"] = bench_update.run(dev, dist, world, rank, steps=n_upd, graph=True)  # f32: the parity path
-            res["sac"]["eager_ms_per_update"] = bench_update.run(dev, dist, world, rank, steps=n_upd)["ms_per_update"]
-            res["sac"]["bf16_mode"] = bench_update.run(dev, dist, world, rank, steps=n_upd, precision="bf16", graph=True)
-            res["sac"]["bf16_mode"]["eager_ms_per_update"] = bench_update.run(
-                dev, dist, world, rank, steps=n_upd, precision="bf16")["ms_per_update"]
+            # update() replayed from captured hipGraphs (SAC.enable_hip_graphs); the eager figure beside it.
+            # With several ranks the graphs contain the gradient all-reduce: checked by a pre-flight first.
+            use_graph = dist is None or graph_collectives_ok(dist, dev, torch)
+            res["sac"] = bench_update.run(dev, dist, world, rank, steps=n_upd, graph=use_graph)  # f32: the parity path
+            res["sac"]["bf16_mode"] = bench_update.run(dev, dist, world, rank, steps=n_upd, precision="bf16", graph=use_graph)
+            if use_graph:
+                res["sac"]["eager_ms_per_update"] = bench_update.run(dev, dist, world, rank, steps=n_upd)["ms_per_update"]
+                res["sac"]["bf16_mode"]["eager_ms_per_update"] = bench_update.run(
+                    dev, dist, world, rank, steps=n_upd, precision="bf16")["ms_per_update"]
         except ImportError:
             res["sac"] = None
 
