@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/augcl.h"
@@ -28,6 +29,23 @@ int reduce_slabs(const ReduceDesc &d, hipStream_t s, const char *what);
 void reduce_defer_begin();
 int reduce_defer_flush(hipStream_t s, const char *what); // ends the scope
 void reduce_defer_abort();                               // ends the scope, drops what was queued
+
+// Strips per image for the 32-channel conv kernels: the launchers take the fewest strips that fit LDS, split evenly.
+// For a few of the encoder's layer widths one to four MORE strips measured 5-14 % faster (tools/tune_strips.py, B = 256
+// and 512 on 256 CUs: the 32-pixel tiles of a strip are dealt to 4 compute waves, and some heights waste most of a
+// round); everything else keeps the default.  kind: 0 f32 forward, 1 f32 backward-data, 2 bf16 forward, 3 bf16
+// backward-data; W = width of the kernel's INPUT tensor.  AUGCL_EXTRA_STRIPS overrides (the tuning tool).
+inline int extra_strips(int kind, int W)
+{
+    if (const char *e = getenv("AUGCL_EXTRA_STRIPS")) return atoi(e);
+    switch (kind) {
+    case 0: return W == 41 ? 4 : W == 37 ? 2 : 0;
+    case 1: return W == 39 ? 1 : W == 33 ? 2 : W == 31 ? 1 : W == 23 ? 4 : 0;
+    case 2: return W == 41 ? 2 : W == 39 ? 4 : 0;
+    case 3: return W == 39 ? 2 : W == 33 ? 2 : 0;
+    }
+    return 0;
+}
 
 // first layer fast path (encoder_first.hip): AUGCL_OK / negative error after launching, +1 if the shape is not covered
 int conv_first9_try(const float *in, const float *w, const float *bias, void *out, int B, int C, int Hi, int Wi, int stride,

@@ -342,6 +342,7 @@ int launch_conv_bf16_t(ConvBfArgs &a, const char *name, hipStream_t s)
     // keep every CU busy: at least 2 items per CU when the batch allows it
     const int cus = cu_count_bf();
     while ((long)a.B * a.S < 2L * cus && a.S < a.Ho) ++a.S;
+    a.S = std::min(a.Ho, a.S + augcl::extra_strips(MODE ? 3 : 2, Wi)); // measured per layer width
     a.RT = (a.Ho + a.S - 1) / a.S;
     a.S = (a.Ho + a.RT - 1) / a.RT;
     a.n_items = a.B * a.S;

@@ -748,15 +748,16 @@ constexpr int kWg1PerCu = 4;
 constexpr int kBufLds = 78 * 1024; // one of the two tile buffers of a double-buffered, one-per-CU workgroup
 
 int pick_rt(int Ho, int words_per_row_pair /* LDS words per output row (all planes) */, int extra_rows,
-            int max_lds_bytes, int *S)
+            int max_lds_bytes, int *S, int extra = 0)
 {
     // largest RT with (RT + extra_rows) * words <= budget, then balance the strips
     int rt = max_lds_bytes / 4 / words_per_row_pair - extra_rows;
     if (rt < 1) return 0;
     if (rt > Ho) rt = Ho;
-    const int s = (Ho + rt - 1) / rt;
+    int s = (Ho + rt - 1) / rt;
+    s = std::min(Ho, s + extra); // measured per layer width: augcl::extra_strips
     rt = (Ho + s - 1) / s;
-    *S = s;
+    *S = (Ho + rt - 1) / rt;
     return rt;
 }
 
@@ -797,7 +798,7 @@ int augcl_enc_conv32_forward(const float *in, const float *w, const float *bias,
     ConvArgs a{};
     a.in = in; a.w = w; a.bias = bias; a.mask = nullptr; a.out = out;
     a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ho = Hi - 2; a.Wo = Wi - 2; a.relu = relu;
-    a.RT = pick_rt(a.Ho, 32 * Wi, 2, kBufLds, &a.S);
+    a.RT = pick_rt(a.Ho, 32 * Wi, 2, kBufLds, &a.S, augcl::extra_strips(0, Wi));
     AUGCL_REQUIRE(a.RT > 0, "%s: image row too wide for LDS (W=%d)", name, Wi);
     a.n_items = B * a.S;
     const size_t bufw = (size_t)32 * (((a.RT + 2) * Wi + 3) & ~3);
@@ -822,7 +823,7 @@ int augcl_enc_conv32_backward_data(const float *dz, const float *w, const float 
     AUGCL_REQUIRE(aligned16(w), "%s: weights must be 16-byte aligned", name);
     // (strip heights: the even split of pick_rt measured better over the 10 layer sizes than minimising the number of
     // 4-wave tile rounds per image -- fewer, larger strips starve the loader/compute pipeline)
-    a.RT = pick_rt(a.Ho, 32 * Wo, 2, kBufLds - 8 * G - 64, &a.S);
+    a.RT = pick_rt(a.Ho, 32 * Wo, 2, kBufLds - 8 * G - 64, &a.S, augcl::extra_strips(1, Wo));
     AUGCL_REQUIRE(a.RT > 0, "%s: image row too wide for LDS (W=%d)", name, Wo);
     a.n_items = B * a.S;
     const size_t bufw = (size_t)32 * (((a.RT + 2) * Wo + 3) & ~3) + 2 * G;
