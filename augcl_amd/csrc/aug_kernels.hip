@@ -493,32 +493,11 @@ __device__ __forceinline__ void hue_shift(float &r, float &g, float &b, float hu
 // frame, NQ quads of 4 pixels per thread and channel (<= 60 data VGPRs), so the only LDS traffic is the
 // NT/64 partial sums of the contrast mean.  Every load of a thread is issued up front (3*NQ dwordx4 in
 // flight), several workgroups fit per CU, and HBM sees one read and one write per element.
-template <int NT, int NQ, int WPS>
-__global__ __launch_bounds__(NT, WPS) void k_color_jitter_reg(float *__restrict__ inout, int n /* H*W, %4==0 */,
-                                                         const int32_t *__restrict__ idx, int n_idx, JitterParams p)
+// The jitter ops on a register-resident frame (NQ quads per thread and channel); `red` = NT/64 doubles of LDS.
+template <int NT, int NQ>
+__device__ __forceinline__ void jitter_frame_ops(float4 (&px)[3][NQ], const JitterParams &p, double *red, int n, int n4,
+                                                 int tid)
 {
-    __shared__ double red[NT / 64];
-    const int frame = blockIdx.x;
-    const int tid = threadIdx.x;
-    if (idx != nullptr) {
-        int hit = 0;
-        for (int k = tid; k < n_idx; k += NT) hit |= (idx[k] == frame);
-        if (!__syncthreads_or(hit)) return;
-    }
-    float4 *__restrict__ g = reinterpret_cast<float4 *>(inout + (size_t)frame * 3 * n);
-    const int n4 = n / 4;
-    float4 px[3][NQ];
-#pragma unroll
-    for (int j = 0; j < NQ; ++j) {
-        const int q = tid + j * NT;
-        if (q < n4) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) px[c][j] = g[c * n4 + q];
-        } else {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) px[c][j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    }
     if (p.scale != 1.0f) {
         const bool is255 = p.scale == 255.0f;
 #pragma unroll
@@ -577,19 +556,109 @@ __global__ __launch_bounds__(NT, WPS) void k_color_jitter_reg(float *__restrict_
             }
         }
     }
+    if (p.scale != 1.0f) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                float4 &v = px[c][j];
+                v.x = v.x * p.scale; v.y = v.y * p.scale; v.z = v.z * p.scale; v.w = v.w * p.scale;
+            }
+    }
+}
+
+template <int NT, int NQ, int WPS>
+__global__ __launch_bounds__(NT, WPS) void k_color_jitter_reg(float *__restrict__ inout, int n /* H*W, %4==0 */,
+                                                         const int32_t *__restrict__ idx, int n_idx, JitterParams p)
+{
+    __shared__ double red[NT / 64];
+    const int frame = blockIdx.x;
+    const int tid = threadIdx.x;
+    if (idx != nullptr) {
+        int hit = 0;
+        for (int k = tid; k < n_idx; k += NT) hit |= (idx[k] == frame);
+        if (!__syncthreads_or(hit)) return;
+    }
+    float4 *__restrict__ g = reinterpret_cast<float4 *>(inout + (size_t)frame * 3 * n);
+    const int n4 = n / 4;
+    float4 px[3][NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        const int q = tid + j * NT;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) px[c][j] = q < n4 ? g[c * n4 + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    jitter_frame_ops<NT, NQ>(px, p, red, n, n4, tid);
 #pragma unroll
     for (int j = 0; j < NQ; ++j) {
         const int q = tid + j * NT;
         if (q < n4) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                float4 v = px[c][j];
-                if (p.scale != 1.0f) {
-                    v.x = v.x * p.scale; v.y = v.y * p.scale; v.z = v.z * p.scale; v.w = v.w * p.scale;
-                }
-                g[c * n4 + q] = v;
+            for (int c = 0; c < 3; ++c) g[c * n4 + q] = px[c][j];
+        }
+    }
+}
+
+// Persistent, software-pipelined form of the same kernel (one 16-wave workgroup per CU walks frames f, f+G, f+2G..):
+// the NEXT frame's 3*NQ loads are issued before the current frame's arithmetic and the current frame's stores drain
+// under the next frame's, so a CU's load / compute / store phases overlap instead of running back to back (with one
+// workgroup per CU and one frame per workgroup they cannot: 87 registers allow only 5 waves per SIMD).
+template <int NT, int NQ>
+__global__ __launch_bounds__(NT, 4) void k_color_jitter_pipe(float *__restrict__ inout, int n, int nframes,
+                                                             const int32_t *__restrict__ idx, int n_idx, JitterParams p)
+{
+    __shared__ double red[NT / 64];
+    const int tid = threadIdx.x;
+    const int n4 = n / 4;
+    auto is_hit = [&](int frame) -> bool { // block-uniform
+        if (frame >= nframes) return false;
+        if (idx == nullptr) return true;
+        int hit = 0;
+        for (int k = tid; k < n_idx; k += NT) hit |= (idx[k] == frame);
+        return __syncthreads_or(hit) != 0;
+    };
+    auto next_hit = [&](int frame) -> int { // first touched frame of this workgroup at or after `frame`, or -1
+        for (; frame < nframes; frame += gridDim.x)
+            if (is_hit(frame)) return frame;
+        return -1;
+    };
+    auto load = [&](int frame, float4 (&px)[3][NQ]) {
+        const float4 *__restrict__ g = reinterpret_cast<const float4 *>(inout + (size_t)frame * 3 * n);
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            const int q = min(tid + j * NT, n4 - 1); // clamped: every lane loads something real (masked at the store)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) px[c][j] = g[c * n4 + q];
+        }
+    };
+    int cur = next_hit(blockIdx.x);
+    if (cur < 0) return;
+    float4 px[3][NQ], pn[3][NQ];
+    load(cur, px);
+    while (cur >= 0) {
+        const int nxt = next_hit(cur + gridDim.x);
+        if (nxt >= 0) load(nxt, pn);
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) // lanes past the frame must not disturb the contrast mean
+            if (tid + j * NT >= n4) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) px[c][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        jitter_frame_ops<NT, NQ>(px, p, red, n, n4, tid);
+        float4 *__restrict__ g = reinterpret_cast<float4 *>(inout + (size_t)cur * 3 * n);
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            const int q = tid + j * NT;
+            if (q < n4) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) g[c * n4 + q] = px[c][j];
             }
         }
+#pragma unroll
+        for (int j = 0; j < NQ; ++j)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) px[c][j] = pn[c][j];
+        cur = nxt;
     }
 }
 
@@ -881,9 +950,19 @@ int augcl_color_jitter_f32(float *inout, int B, int frames, int H, int W, const 
         return augcl::fail(AUGCL_E_UNSUPPORTED, "%s: a %dx%d RGB frame (%zu B) exceeds the 160 KiB LDS of a CU", name, H,
                            W, smem);
     if (B == 0 || (idx != nullptr && n_idx == 0)) return AUGCL_OK;
-    if (n / 4 <= 1024 * 2) { // 84x84 (1764 quads): register-resident, two 16-wave workgroups per CU
-        hipLaunchKernelGGL((k_color_jitter_reg<1024, 2, 4>), dim3(B * frames), dim3(1024), 0, as_stream(stream), inout, n,
-                           idx, n_idx, p);
+    if (n / 4 <= 1024 * 2) { // 84x84 (1764 quads): register-resident; persistent + pipelined once every CU has >1 frame
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            int v = 0;
+            if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+        }
+        const int nframes = B * frames;
+        if (nframes > cus && getenv("AUGCL_JITTER_NOPIPE") == nullptr)
+            hipLaunchKernelGGL((k_color_jitter_pipe<1024, 2>), dim3(cus), dim3(1024), 0, as_stream(stream), inout, n, nframes,
+                               idx, n_idx, p);
+        else
+            hipLaunchKernelGGL((k_color_jitter_reg<1024, 2, 4>), dim3(nframes), dim3(1024), 0, as_stream(stream), inout, n,
+                               idx, n_idx, p);
         LAUNCH_CHECK(name);
     }
     if (n / 4 <= 1024 * 3) { // 100x100 (2500 quads)
