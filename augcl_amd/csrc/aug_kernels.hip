@@ -498,15 +498,23 @@ template <int NT, int NQ>
 __device__ __forceinline__ void jitter_frame_ops(float4 (&px)[3][NQ], const JitterParams &p, double *red, int n, int n4,
                                                  int tid)
 {
-    if (p.scale != 1.0f) {
-        const bool is255 = p.scale == 255.0f;
+    if (p.scale == 255.0f) { // uniform branches: a per-element select would execute the IEEE division as well
 #pragma unroll
         for (int c = 0; c < 3; ++c)
 #pragma unroll
             for (int j = 0; j < NQ; ++j) {
                 float *v = &px[c][j].x;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = is255 ? div255(v[e]) : v[e] / p.scale;
+                for (int e = 0; e < 4; ++e) v[e] = div255(v[e]);
+            }
+    } else if (p.scale != 1.0f) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                float *v = &px[c][j].x;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] / p.scale;
             }
     }
     for (int s = 0; s < 4; ++s) {
