@@ -72,6 +72,8 @@ _SIGS = {
     "augcl_green_screen_u8": [_P, _P, _P, _I, _I, _I, _P],
     "augcl_gauss_head_forward": [_P, _P, _P, _P, _P, _P, _I, _I, _D, _D, _P],
     "augcl_gauss_head_backward": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _D, _D, _P],
+    "augcl_ln_tanh_forward": [_P, _P, _P, _P, _I, _I, _D, _P],
+    "augcl_ln_tanh_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _D, _P],
     "augcl_td_target_f32": [_P, _P, _P, _P, _P, _P, _D, _P, _I, _P],
     "augcl_q_loss_forward": [_P, _P, _P, _I, _I, _P, _P, _P],
     "augcl_q_loss_backward": [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P],

@@ -137,6 +137,10 @@ class RLProjection(nn.Module):
         self.apply(weight_init)
 
     def forward(self, x):
+        lin, ln = self.projection[0], self.projection[1]
+        if head_ops._ok(x) and ln.weight.is_cuda and self.out_dim <= 256:
+            # Linear (hipBLASLt) then LayerNorm + tanh as one launch forward / two backward
+            return head_ops.ln_tanh(lin(x), ln.weight, ln.bias, ln.eps)
         return self.projection(x)
 
 

@@ -138,6 +138,119 @@ __global__ __launch_bounds__(256) void k_q_loss_bwd(const float *__restrict__ q1
     dq2[i] = scale * (q2[i] - yy);
 }
 
+// RLProjection's tail (src/algorithms/modules.py:101-111): y = tanh(LayerNorm(x) * gamma + beta), rows of D <= 256.
+// One wave per row (lane-strided, wave tree: deterministic).  rstd / mean are recomputed in backward.
+__global__ __launch_bounds__(256) void k_ln_tanh_fwd(const float *__restrict__ x, const float *__restrict__ gamma,
+                                                     const float *__restrict__ beta, float *__restrict__ y, int B, int D,
+                                                     float eps)
+{
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= B) return;
+    const float *xr = x + (size_t)row * D;
+    float v[4], s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int j = lane + 64 * k;
+        v[k] = j < D ? xr[j] : 0.0f;
+        s += v[k];
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s / (float)D;
+    float q = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int j = lane + 64 * k;
+        const float d = j < D ? v[k] - mean : 0.0f;
+        q += d * d;
+    }
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    const float rstd = 1.0f / sqrtf(q / (float)D + eps);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int j = lane + 64 * k;
+        if (j < D) y[(size_t)row * D + j] = tanhf(((v[k] - mean) * rstd) * gamma[j] + beta[j]);
+    }
+}
+
+// dx of tanh(LN(x)): g1 = gy (1 - y^2); dxhat = g1 gamma; dx = rstd (dxhat - mean(dxhat) - xhat mean(dxhat xhat)).
+// Also writes g1 and xhat-weighted g1 for the column sums (dgamma = sum_rows g1 xhat, dbeta = sum_rows g1).
+__global__ __launch_bounds__(256) void k_ln_tanh_bwd(const float *__restrict__ x, const float *__restrict__ gamma,
+                                                     const float *__restrict__ y, const float *__restrict__ gy,
+                                                     float *__restrict__ dx, float *__restrict__ g1_out,
+                                                     float *__restrict__ g1x_out, int B, int D, float eps)
+{
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= B) return;
+    const float *xr = x + (size_t)row * D;
+    float v[4], s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int j = lane + 64 * k;
+        v[k] = j < D ? xr[j] : 0.0f;
+        s += v[k];
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s / (float)D;
+    float q = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int j = lane + 64 * k;
+        const float d = j < D ? v[k] - mean : 0.0f;
+        q += d * d;
+    }
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    const float rstd = 1.0f / sqrtf(q / (float)D + eps);
+    float xh[4], dh[4], a = 0.0f, b = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int j = lane + 64 * k;
+        xh[k] = 0.0f;
+        dh[k] = 0.0f;
+        if (j < D) {
+            const size_t e = (size_t)row * D + j;
+            const float yy = y[e];
+            const float g1 = gy[e] * (1.0f - yy * yy);
+            xh[k] = (v[k] - mean) * rstd;
+            dh[k] = g1 * gamma[j];
+            g1_out[e] = g1;
+            g1x_out[e] = g1 * xh[k];
+            a += dh[k];
+            b += dh[k] * xh[k];
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        a += __shfl_xor(a, o, 64);
+        b += __shfl_xor(b, o, 64);
+    }
+    a /= (float)D;
+    b /= (float)D;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int j = lane + 64 * k;
+        if (j < D) dx[(size_t)row * D + j] = rstd * ((dh[k] - a) - xh[k] * b);
+    }
+}
+
+// column sums over the batch, fixed order: dgamma[j] = sum_rows g1x, dbeta[j] = sum_rows g1 (one thread per column pair)
+__global__ __launch_bounds__(256) void k_colsum2(const float *__restrict__ g1, const float *__restrict__ g1x,
+                                                 float *__restrict__ dbeta, float *__restrict__ dgamma, int B, int D)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= 2 * D) return;
+    const float *src = j < D ? g1x : g1;
+    const int c = j < D ? j : j - D;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int r = 0;
+    for (; r + 3 < B; r += 4) {
+        s0 += src[(size_t)r * D + c];
+        s1 += src[(size_t)(r + 1) * D + c];
+        s2 += src[(size_t)(r + 2) * D + c];
+        s3 += src[(size_t)(r + 3) * D + c];
+    }
+    for (; r < B; ++r) s0 += src[(size_t)r * D + c];
+    (j < D ? dgamma : dbeta)[c] = (s0 + s1) + (s2 + s3);
+}
+
 } // namespace augcl
 
 using namespace augcl;
@@ -212,6 +325,30 @@ int augcl_q_loss_backward(const float *q1, const float *q2, const float *y, cons
     for (int s = 0; s < S; ++s) ws[s] = (float)w[s];
     hipLaunchKernelGGL(k_q_loss_bwd, dim3((M * S + 255) / 256), dim3(256), 0, as_stream(stream), q1, q2, y, g_total, M, S,
                        ws[0], ws[1], ws[2], ws[3], dq1, dq2);
+    return augcl::check_launch(name);
+}
+
+int augcl_ln_tanh_forward(const float *x, const float *gamma, const float *beta, float *y, int B, int D, double eps,
+                          augcl_stream_t stream)
+{
+    const char *name = "augcl_ln_tanh_forward";
+    AUGCL_REQUIRE(B >= 0 && D >= 1 && D <= 256, "%s: bad shape (D <= 256)", name);
+    if (B == 0) return AUGCL_OK;
+    AUGCL_REQUIRE(x && gamma && beta && y, "%s: null tensor", name);
+    hipLaunchKernelGGL(k_ln_tanh_fwd, dim3((B + 3) / 4), dim3(256), 0, as_stream(stream), x, gamma, beta, y, B, D, (float)eps);
+    return augcl::check_launch(name);
+}
+
+int augcl_ln_tanh_backward(const float *x, const float *gamma, const float *y, const float *gy, float *dx, float *dgamma,
+                           float *dbeta, float *workspace /* 2*B*D floats */, int B, int D, double eps, augcl_stream_t stream)
+{
+    const char *name = "augcl_ln_tanh_backward";
+    AUGCL_REQUIRE(B >= 1 && D >= 1 && D <= 256, "%s: bad shape (D <= 256)", name);
+    AUGCL_REQUIRE(x && gamma && y && gy && dx && dgamma && dbeta && workspace, "%s: null tensor", name);
+    float *g1 = workspace, *g1x = workspace + (size_t)B * D;
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(k_ln_tanh_bwd, dim3((B + 3) / 4), dim3(256), 0, s, x, gamma, y, gy, dx, g1, g1x, B, D, (float)eps);
+    hipLaunchKernelGGL(k_colsum2, dim3((2 * D + 255) / 256), dim3(256), 0, s, g1, g1x, dbeta, dgamma, B, D);
     return augcl::check_launch(name);
 }
 

@@ -53,6 +53,36 @@ def gauss_head(raw, noise, log_std_min, log_std_max, want_log_pi=True):
     return _GaussHead.apply(raw, noise, log_std_min, log_std_max, want_log_pi)
 
 
+class _LnTanh(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x = x.contiguous()
+        B, D = x.shape
+        y = torch.empty_like(x)
+        _lib.call("augcl_ln_tanh_forward", x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), B, D, float(eps),
+                  _lib.current_stream(x.device))
+        ctx.save_for_backward(x, gamma, y)
+        ctx.eps = float(eps)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, gamma, y = ctx.saved_tensors
+        B, D = x.shape
+        gy = gy.contiguous()
+        dx = torch.empty_like(x)
+        dgb = torch.empty((2, D), dtype=torch.float32, device=x.device)
+        ws = torch.empty(2 * B * D, dtype=torch.float32, device=x.device)
+        _lib.call("augcl_ln_tanh_backward", x.data_ptr(), gamma.data_ptr(), y.data_ptr(), gy.data_ptr(), dx.data_ptr(),
+                  dgb[0].data_ptr(), dgb[1].data_ptr(), ws.data_ptr(), B, D, ctx.eps, _lib.current_stream(x.device))
+        return dx, dgb[0], dgb[1], None
+
+
+def ln_tanh(x, gamma, beta, eps=1e-5):
+    """tanh(LayerNorm(x) * gamma + beta) over the last dimension of a (B, D <= 256) tensor."""
+    return _LnTanh.apply(x, gamma, beta, eps)
+
+
 def td_target(tq1, tq2, log_pi, reward, not_done, alpha, discount):
     """reward + (not_done * discount) * (min(tq1, tq2) - alpha * log_pi); alpha: 0-dim float64 device tensor."""
     B = tq1.shape[0]

@@ -178,6 +178,13 @@ int augcl_q_loss_forward(const float *q1, const float *q2, const float *y, int M
 int augcl_q_loss_backward(const float *q1, const float *q2, const float *y, const float *g_total, int M, int S,
                           const double *w, float *dq1, float *dq2, augcl_stream_t stream);
 
+/* RLProjection's tail (src/algorithms/modules.py:101-111): y = tanh(LayerNorm(x; eps) * gamma + beta) on (B,D) rows,
+ * D <= 256, and its backward (dx, dgamma, dbeta; workspace = 2*B*D floats; fixed-order sums). */
+int augcl_ln_tanh_forward(const float *x, const float *gamma, const float *beta, float *y, int B, int D, double eps,
+                          augcl_stream_t stream);
+int augcl_ln_tanh_backward(const float *x, const float *gamma, const float *y, const float *gy, float *dx, float *dgamma,
+                           float *dbeta, float *workspace, int B, int D, double eps, augcl_stream_t stream);
+
 /* ---- target-network update: utils.soft_update_params (src/utils.py:76-78), called from
  * SAC.soft_update_critic_target (src/algorithms/sac.py:148-153):
  *   target[i] = tau*src[i] + (1-tau)*target[i]   (separate IEEE ops, bit-exact vs torch f32) */

@@ -84,3 +84,24 @@ def test_td_target_and_q_loss(cuda):
             res.append((total.detach(), segs.detach(), q1.grad, q2.grad))
         for a, b in zip(*res):
             assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(a.abs().max())), (S, w)
+
+
+@pytest.mark.parametrize("B,D", [(1, 100), (7, 50), (512, 100), (33, 256)])
+def test_ln_tanh_matches_aten(cuda, B, D):
+    """RLProjection's tail (modules.py:101-111): tanh(LayerNorm(x)) forward and all three gradients."""
+    g = torch.Generator(device=cuda).manual_seed(B * 1000 + D)
+    x0 = torch.randn(B, D, device=cuda, generator=g) * 3.0
+    gamma0 = torch.rand(D, device=cuda, generator=g) + 0.5
+    beta0 = torch.randn(D, device=cuda, generator=g) * 0.1
+    gy = torch.randn(B, D, device=cuda, generator=g)
+    res = []
+    for mode in ("f64", "aten", "fused"):
+        dt = torch.float64 if mode == "f64" else torch.float32
+        x, ga, be = (t.to(dt).clone().requires_grad_(True) for t in (x0, gamma0, beta0))
+        y = head_ops.ln_tanh(x, ga, be, 1e-5) if mode == "fused" else torch.tanh(F.layer_norm(x, (D,), ga, be, 1e-5))
+        (y * gy.to(dt)).sum().backward()
+        res.append([t.detach().double() for t in (y, x.grad, ga.grad, be.grad)])
+    for truth, aten, fused in zip(*res):
+        scale = max(1.0, float(truth.abs().max()))
+        e_aten, e_fused = float((aten - truth).abs().max()), float((fused - truth).abs().max())
+        assert e_fused <= max(3.0 * e_aten, 3e-6 * scale), (e_fused, e_aten)
