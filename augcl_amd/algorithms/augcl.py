@@ -33,7 +33,7 @@ class AugCL(RAD):
         self.critic_weak_optimizer = pretrained_agent.critic_optimizer
         if self._graph is not None:  # graphs captured before the hand-off reference the old weak critic
             self.critic_weak_optimizer.make_capturable()
-            self._graph.update(graphs={}, static=None, seen=0)
+            self._graph.update(graphs={}, static=None, pool=None, seen=0)
 
     def update_critic(self, obs_aug, obs_shift, action, reward, next_obs, not_done, L=None, step=None):
         target_Q = self.calculate_target_Q(next_obs=next_obs, reward=reward, not_done=not_done)

@@ -218,14 +218,17 @@ class SAC(object):
             for grp in new.param_groups:
                 grp["capturable"] = True
         self.log_alpha_optimizer = new
-        self._graph = dict(warmup=int(warmup), seen=0, graphs={}, static=None, pool=None)
+        self._graph = dict(warmup=int(warmup), seen=0, graphs={}, static=None, pool=None, shapes=None)
 
     def _graph_update(self, batch, L, step, do_actor, do_target):
         G = self._graph
         if G["seen"] < G["warmup"]:
             G["seen"] += 1
             return self._learn(self._front_end(*batch), L, step, do_actor, do_target)
+        if G["static"] is not None and tuple(batch[1].shape) != G["shapes"]:
+            G.update(graphs={}, static=None, pool=None)  # another batch size: drop the graphs (and their memory pool)
         t = self._front_end(*batch, out=G["static"])
+        G["shapes"] = tuple(batch[1].shape)
         if G["static"] is None:
             G["static"] = tuple(x.clone() if torch.is_tensor(x) else x for x in t)
         for dst, src in zip(G["static"], t):

@@ -261,12 +261,19 @@ def test_hip_graph_update_matches_eager(cuda, algo, data_aug, A):
             for step in range(10):
                 agent.update(buf, L if step % 3 else None, step)
             torch.cuda.synchronize()
+            snap = (agent.critic_group.param.clone(), agent.actor_group.param.clone(), agent.target_group.param.clone(),
+                    agent.log_alpha.detach().clone(), dict(L.rows), agent.critic_optimizer.step_count)
+            if graph:
+                assert len(agent._graph["graphs"]) >= 3
+                # another batch size: the graphs are recaptured instead of replayed on stale shapes
+                half = tuple(t[:B // 2].clone() for t in batches[0])
+                for step in (10, 11):
+                    agent.update(FakeBuffer(half), None, step)
+                torch.cuda.synchronize()
+                assert agent._graph["shapes"][0] == B // 2 and agent.critic_optimizer.step_count == 12
         finally:
             aug.set_overlay_source(None)
-        if graph:
-            assert len(agent._graph["graphs"]) >= 3
-        results.append((agent.critic_group.param.clone(), agent.actor_group.param.clone(), agent.target_group.param.clone(),
-                        agent.log_alpha.detach().clone(), dict(L.rows), agent.critic_optimizer.step_count))
+        results.append(snap)
     e, gr = results
     assert e[5] == gr[5] == 10
     for a, b in zip(e[:4], gr[:4]):
