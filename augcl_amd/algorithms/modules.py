@@ -104,6 +104,16 @@ class SharedCNN(nn.Module):
         return encoder_ops.conv_stack(x, [c.weight for c in cs], [c.bias for c in cs], first_stride=2,
                                       input_scale=255.0, relu_first=False)
 
+    def forward_with(self, other, x):
+        """No-grad forward of this CNN and of `other` (same architecture, other weights) over the same x in one launch
+        per layer.  Returns (self(x), other(x)) or None when the fused path does not apply."""
+        if torch.is_grad_enabled() or self.num_layers != other.num_layers:
+            return None
+        x = self.layers[0](x)
+        a, b = self.convs(), other.convs()
+        return encoder_ops.conv_stack_dual(x, [c.weight for c in a], [c.bias for c in a], [c.weight for c in b],
+                                           [c.bias for c in b], first_stride=2, input_scale=255.0)
+
 
 class HeadCNN(nn.Module):
     """modules.py:168-181: optional extra (ReLU, Conv) pairs, then Flatten."""

@@ -6,6 +6,7 @@ engine room: parameters of each optimiser group live in one flat buffer (flat.Fl
 optimiser step and the target EMA are single fused HIP launches, the shared CNN runs as one HIP
 autograd node, and gradients can be exchanged data-parallel through one all-reduce per group.
 """
+import os
 from copy import deepcopy
 
 import numpy as np
@@ -15,6 +16,9 @@ import torch.nn.functional as F
 from .. import dist as apdist
 from .. import flat, head_ops
 from . import modules as m
+
+
+DUAL_TARGET_PASS = os.environ.get("AUGCL_DUAL_TARGET", "1") != "0"
 
 
 def _device():
@@ -106,8 +110,15 @@ class SAC(object):
     def calculate_target_Q(self, next_obs, reward, not_done):
         """sac.py:94-101"""
         with torch.no_grad():
-            _, policy_action, log_pi, _ = self.actor(next_obs)
-            target_Q1, target_Q2 = self.critic_target(next_obs, policy_action)
+            fa = ft = None
+            ea, et = self.actor.encoder, self.critic_target.encoder
+            if DUAL_TARGET_PASS and len(list(ea.head_cnn.parameters())) == 0 and len(list(et.head_cnn.parameters())) == 0:
+                # the actor's CNN and the target critic's CNN see the same next_obs: one launch per layer for both
+                both = ea.shared_cnn.forward_with(et.shared_cnn, next_obs)
+                if both is not None:
+                    fa, ft = ea.head_cnn(both[0]), et.head_cnn(both[1])
+            _, policy_action, log_pi, _ = self.actor(next_obs, features=fa)
+            target_Q1, target_Q2 = self.critic_target(next_obs, policy_action, features=ft)
             if head_ops._ok(target_Q1, log_pi, reward, not_done):
                 return head_ops.td_target(target_Q1, target_Q2, log_pi, reward, not_done, self.alpha, self.discount)
             target_V = torch.min(target_Q1, target_Q2) - self.alpha.detach() * log_pi

@@ -48,8 +48,10 @@ inline int extra_strips(int kind, int W)
 }
 
 // first layer fast path (encoder_first.hip): AUGCL_OK / negative error after launching, +1 if the shape is not covered
+// w2 / bias2 != null: two-weight-set forward (B images = two halves over the SAME B/2 inputs)
 int conv_first9_try(const float *in, const float *w, const float *bias, void *out, int B, int C, int Hi, int Wi, int stride,
-                    float scale, int relu, bool out_bf16, hipStream_t s, const char *name);
+                    float scale, int relu, bool out_bf16, hipStream_t s, const char *name, const float *w2 = nullptr,
+                    const float *bias2 = nullptr);
 
 #define AUGCL_REQUIRE(cond, ...)                                 \
     do {                                                         \

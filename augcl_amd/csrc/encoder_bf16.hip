@@ -29,6 +29,9 @@ struct ConvBfArgs {
     void *out;            // bf16 NHWC (B,Ho,Wo,32), or f32 NCHW (B,32,Ho,Wo) when out_f32
     int B, Hi, Wi, Ho, Wo, RT, S, relu, n_items, out_f32;
     uint32_t magic_wi, magic_wo; // floor(2^32 / W) + 1: x / W == umulhi(x, magic) for the pixel counts used here
+    // two-weight-set forward: images [B/2, B) use w2 / bias2; even workgroups serve the first half, odd the second
+    const float *w2, *bias2;
+    int dual;
 };
 
 typedef uint32_t vu4 __attribute__((ext_vector_type(4))); // native vectors: register arrays of them stay in registers
@@ -62,19 +65,23 @@ __global__ __launch_bounds__(512, 2) void k_conv32_bf16(ConvBfArgs a)
     const int tilepix = (a.RT + 2) * Wl + (MODE ? 2 : 0);
     const int bufbytes = tilepix * PIXB;
     float *lbias = reinterpret_cast<float *>(ldsc + max(2 * bufbytes, bufbytes + WST_BYTES));
-    const int first = blockIdx.x, NG = gridDim.x, n = a.n_items;
+    const int grp = a.dual ? (int)(blockIdx.x & 1) : 0, nhalf = a.n_items >> 1;
+    const int first = a.dual ? grp * nhalf + (int)(blockIdx.x >> 1) : (int)blockIdx.x;
+    const int NG = a.dual ? (int)(gridDim.x >> 1) : (int)gridDim.x;
+    const int n = a.dual ? (grp + 1) * nhalf : a.n_items;
 
     // ---- weights: all 512 threads copy the 36 KB of f32 masters into LDS with coalesced 16-byte loads (the region
     // of tile buffer 1, which is first written after the second barrier); the compute waves then pick their
     // MFMA A-fragments out of LDS.  (Per-lane global gathers cost ~4 us per launch: 2304 cache lines per wave.)
     {
         float *wst = reinterpret_cast<float *>(ldsc + bufbytes);
-        const vf4 *w4 = reinterpret_cast<const vf4 *>(a.w);
+        const vf4 *w4 = reinterpret_cast<const vf4 *>(grp ? a.w2 : a.w);
+        const float *bsrc = grp ? a.bias2 : a.bias;
         for (int i = tid; i < 32 * 288 / 4; i += 512) {
             const int row = (4 * i) / 288, col = 4 * i - row * 288;
             *reinterpret_cast<vf4 *>(wst + row * WST_ROW + col) = w4[i];
         }
-        if (tid < 32) lbias[tid] = (MODE == 0 && a.bias) ? a.bias[tid] : 0.0f;
+        if (tid < 32) lbias[tid] = (MODE == 0 && bsrc) ? bsrc[tid] : 0.0f;
     }
     __syncthreads();
 
@@ -354,7 +361,8 @@ int launch_conv_bf16_t(ConvBfArgs &a, const char *name, hipStream_t s)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv32_bf16<MODE, RELU, OUT_F32>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return augcl::fail(AUGCL_E_LAUNCH, "%s: cannot set dynamic LDS %zu: %s", name, lds, hipGetErrorString(e));
-    const int grid = a.n_items < cus ? a.n_items : cus;
+    int grid = a.n_items < cus ? a.n_items : cus;
+    if (a.dual) grid &= ~1; // even / odd workgroups serve the two halves
     hipLaunchKernelGGL((k_conv32_bf16<MODE, RELU, OUT_F32>), dim3(grid), dim3(512), lds, s, a);
     return augcl::check_launch(name);
 }
@@ -400,6 +408,23 @@ int augcl_enc_bf16_conv32_backward_data(const void *dz_bf16_nhwc, const float *w
     a.mask = reinterpret_cast<const uint4 *>(act_prev_bf16_nhwc); a.out = dact_bf16_nhwc;
     a.B = B; a.Hi = Ho; a.Wi = Wo; a.Ho = Ho + 2; a.Wo = Wo + 2; a.relu = 0; a.out_f32 = 0;
     return launch_conv_bf16<1>(a, name, as_stream(stream));
+}
+
+// internal (encoder_stack.cpp): B2 images, the first half with (w, bias), the second with (w2, bias2)
+int augcl_internal_bf16_conv32_forward_dual(const void *in_bf16_nhwc, const float *w, const float *bias, const float *w2,
+                                            const float *bias2, void *out, int B2, int Hi, int Wi, int relu,
+                                            int out_f32_nchw, augcl_stream_t stream)
+{
+    const char *name = "augcl_enc_stack_forward_dual";
+    AUGCL_REQUIRE(B2 >= 2 && (B2 & 1) == 0 && Hi >= 3 && Wi >= 3, "%s: bad shape", name);
+    AUGCL_REQUIRE(in_bf16_nhwc && w && w2 && out, "%s: null tensor", name);
+    AUGCL_REQUIRE(aligned16(in_bf16_nhwc) && aligned16(out) && aligned16(w) && aligned16(w2), "%s: tensors must be 16-byte aligned", name);
+    AUGCL_REQUIRE((size_t)B2 * 32 * Hi * Wi < ((size_t)1 << 31), "%s: tensor too large for 32-bit offsets", name);
+    ConvBfArgs a{};
+    a.in = reinterpret_cast<const uint4 *>(in_bf16_nhwc); a.w = w; a.bias = bias; a.mask = nullptr; a.out = out;
+    a.w2 = w2; a.bias2 = bias2; a.dual = 1;
+    a.B = B2; a.Hi = Hi; a.Wi = Wi; a.Ho = Hi - 2; a.Wo = Wi - 2; a.relu = relu; a.out_f32 = out_f32_nchw;
+    return launch_conv_bf16<0>(a, name, as_stream(stream));
 }
 
 int augcl_enc_nchw_f32_to_nhwc_bf16(const float *in, void *out_bf16_nhwc, int B, int H, int W, augcl_stream_t stream)

@@ -39,6 +39,9 @@ struct First9Args {
     int B, Hi, Ho, Wo, RT, S, n_items;
     float scale;
     uint32_t magic_wo, magic_run_full, magic_run_last; // floor(2^32/d)+1 for d = Wo, chunks per channel run
+    // two-weight-set forward over ONE input batch: image b >= B/2 reads input b - B/2 and uses w2 / bias2
+    const float *w2, *bias2;
+    int dual;
 };
 
 constexpr int F9_U = 12;  // 16-byte chunks per loader lane per strip
@@ -59,7 +62,10 @@ __global__ __launch_bounds__(512, 2) void k_conv_first9(First9Args a)
     const int rows_in_max = 2 * a.RT + 1;
     const int bufwords = (rows_in_max + 1) * ROWF; // + one slack row block (the K pad reads into it)
     float *lbias = ldsf + 2 * bufwords;
-    const int first = blockIdx.x, NG = gridDim.x, n = a.n_items;
+    const int grp = a.dual ? (int)(blockIdx.x & 1) : 0, nhalf = a.n_items >> 1;
+    const int first = a.dual ? grp * nhalf + (int)(blockIdx.x >> 1) : (int)blockIdx.x;
+    const int NG = a.dual ? (int)(gridDim.x >> 1) : (int)gridDim.x;
+    const int n = a.dual ? (grp + 1) * nhalf : a.n_items;
 
     // Both tile buffers start as finite zeros: the K pad (zero weight) reads one row block past the taps, and a
     // short last strip leaves rows the loader never wrote (0 * NaN from stale LDS would poison the MFMA).
@@ -69,8 +75,9 @@ __global__ __launch_bounds__(512, 2) void k_conv_first9(First9Args a)
     // which the loader first writes after the next-but-one barrier.
     {
         float *wst = ldsf + bufwords;
-        for (int i = tid; i < 32 * 81; i += 512) wst[(i / 81) * 85 + (i % 81)] = a.w[i];
-        if (tid < 32) lbias[tid] = a.bias ? a.bias[tid] : 0.0f;
+        const float *wsrc = grp ? a.w2 : a.w, *bsrc = grp ? a.bias2 : a.bias;
+        for (int i = tid; i < 32 * 81; i += 512) wst[(i / 81) * 85 + (i % 81)] = wsrc[i];
+        if (tid < 32) lbias[tid] = bsrc ? bsrc[tid] : 0.0f;
     }
     __syncthreads();
 
@@ -97,7 +104,8 @@ __global__ __launch_bounds__(512, 2) void k_conv_first9(First9Args a)
         };
         auto issue = [&](int item, Regs &R) {
             const Geo g = geom(item);
-            const float *src = a.in + ((size_t)g.b * C * a.Hi + 2 * g.y0) * WI;
+            const int bsrc_img = (a.dual && g.b >= (a.B >> 1)) ? g.b - (a.B >> 1) : g.b; // both halves read the same input
+            const float *src = a.in + ((size_t)bsrc_img * C * a.Hi + 2 * g.y0) * WI;
 #pragma unroll
             for (int u = 0; u < F9_U; ++u) {
                 const int q = min(u * 256 + lt, g.nchunk - 1);
@@ -256,7 +264,8 @@ static int launch_first9_t(First9Args &a, int cus, hipStream_t s, const char *na
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_first9<WI, OUT_BF16, RELU>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return fail(AUGCL_E_LAUNCH, "%s: cannot set dynamic LDS %zu: %s", name, lds, hipGetErrorString(e));
-    const int grid = a.n_items < cus ? a.n_items : cus;
+    int grid = a.n_items < cus ? a.n_items : cus;
+    if (a.dual) grid &= ~1;
     hipLaunchKernelGGL((k_conv_first9<WI, OUT_BF16, RELU>), dim3(grid), dim3(512), lds, s, a);
     return check_launch(name);
 }
@@ -264,12 +273,15 @@ static int launch_first9_t(First9Args &a, int cus, hipStream_t s, const char *na
 // returns AUGCL_OK (or a negative error) after launching, or +1 when the shape is not covered (the caller falls back
 // to the generic kernel)
 int conv_first9_try(const float *in, const float *w, const float *bias, void *out, int B, int C, int Hi, int Wi, int stride,
-                    float scale, int relu, bool out_bf16, hipStream_t s, const char *name)
+                    float scale, int relu, bool out_bf16, hipStream_t s, const char *name, const float *w2,
+                    const float *bias2)
 {
     if (C != 9 || Wi != 84 || stride != 2 || Hi < 3) return 1;
+    if (w2 != nullptr && (B & 1)) return 1;
     if ((reinterpret_cast<uintptr_t>(in) & 15u) != 0 || ((size_t)Hi * Wi) % 4 != 0) return 1;
     First9Args a{};
     a.in = in; a.w = w; a.bias = bias; a.out = out;
+    a.w2 = w2; a.bias2 = bias2; a.dual = w2 != nullptr;
     a.B = B; a.Hi = Hi; a.Ho = (Hi - 3) / 2 + 1; a.Wo = (Wi - 3) / 2 + 1; a.scale = scale;
     // one strip = one round of loads: 9 * (2RT+1) * WI/4 chunks <= 256 * F9_U
     int rt = ((256 * F9_U) / (9 * (Wi / 4)) - 1) / 2;

@@ -51,6 +51,10 @@ struct ConvArgs {
     int B, Hi, Wi, Ho, Wo, RT, S; // S strips per image
     int relu;                     // MODE 0: apply ReLU to the output
     int n_items;                  // B * S
+    // two-weight-set forward (two encoders with the same shapes in one launch): images [B/2, B) use w2 / bias2;
+    // even workgroups serve the first half, odd ones the second, so a workgroup still holds ONE weight set
+    const float *w2, *bias2;
+    int dual;
 };
 
 // ---- global -> LDS staging of contiguous runs ------------------------------------------------------
@@ -141,12 +145,13 @@ __global__ __launch_bounds__(512, 2) void k_conv32(ConvArgs a)
     {
         typedef float wf4 __attribute__((ext_vector_type(4)));
         float *wst = lds_raw + bufw;
-        const wf4 *w4 = reinterpret_cast<const wf4 *>(a.w);
+        const wf4 *w4 = reinterpret_cast<const wf4 *>((a.dual && (blockIdx.x & 1)) ? a.w2 : a.w);
         for (int i = tid; i < 32 * 288 / 4; i += 512) {
             const int row = (4 * i) / 288, col = 4 * i - row * 288;
             *reinterpret_cast<wf4 *>(wst + row * WROW + col) = w4[i];
         }
-        if (tid < 32) lbias[tid] = (MODE == 0 && a.bias) ? a.bias[tid] : 0.0f;
+        const float *bsrc = (a.dual && (blockIdx.x & 1)) ? a.bias2 : a.bias;
+        if (tid < 32) lbias[tid] = (MODE == 0 && bsrc) ? bsrc[tid] : 0.0f;
     }
     __syncthreads();
     float wreg[144];
@@ -192,13 +197,16 @@ __global__ __launch_bounds__(512, 2) void k_conv32(ConvArgs a)
     };
 
     int it = 0;
-    const int first = blockIdx.x;
-    if (loader && first < a.n_items && ABL != 1) stage(first, 0);
+    const int grp = a.dual ? (int)(blockIdx.x & 1) : 0, nhalf = a.n_items >> 1;
+    const int first = a.dual ? grp * nhalf + (int)(blockIdx.x >> 1) : (int)blockIdx.x;
+    const int NG = a.dual ? (int)(gridDim.x >> 1) : (int)gridDim.x;
+    const int n_end = a.dual ? (grp + 1) * nhalf : a.n_items;
+    if (loader && first < n_end && ABL != 1) stage(first, 0);
     __syncthreads();
-    for (int item = first; item < a.n_items; item += gridDim.x, ++it) {
-        const int next = item + gridDim.x;
+    for (int item = first; item < n_end; item += NG, ++it) {
+        const int next = item + NG;
         if (loader) {
-            if (next < a.n_items && ABL != 1) stage(next, (it + 1) & 1);
+            if (next < n_end && ABL != 1) stage(next, (it + 1) & 1);
         } else {
             const int b = item / a.S, s = item - b * a.S;
             const int y0 = s * a.RT;
@@ -786,16 +794,17 @@ int grid_for(int n_items, int per_cu)
 
 extern "C" {
 
-int augcl_enc_conv32_forward(const float *in, const float *w, const float *bias, float *out, int B, int Hi, int Wi,
-                             int relu, augcl_stream_t stream)
+static int conv32_forward_impl(const float *in, const float *w, const float *bias, const float *w2, const float *bias2,
+                               float *out, int B, int Hi, int Wi, int relu, augcl_stream_t stream, const char *name)
 {
-    const char *name = "augcl_enc_conv32_forward";
     AUGCL_REQUIRE(B >= 0 && Hi >= 3 && Wi >= 3, "%s: bad shape", name);
     if (B == 0) return AUGCL_OK;
     AUGCL_REQUIRE(in && w && out, "%s: null tensor", name);
-    AUGCL_REQUIRE(aligned16(w), "%s: weights must be 16-byte aligned", name);
+    AUGCL_REQUIRE(aligned16(w) && aligned16(w2), "%s: weights must be 16-byte aligned", name);
+    AUGCL_REQUIRE(w2 == nullptr || (B & 1) == 0, "%s: a two-weight-set batch must be even", name);
     AUGCL_REQUIRE((size_t)B * 32 * Hi * Wi < ((size_t)1 << 31), "%s: tensor too large for 32-bit offsets", name);
     ConvArgs a{};
+    a.w2 = w2; a.bias2 = bias2; a.dual = w2 != nullptr;
     a.in = in; a.w = w; a.bias = bias; a.mask = nullptr; a.out = out;
     a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ho = Hi - 2; a.Wo = Wi - 2; a.relu = relu;
     a.RT = pick_rt(a.Ho, 32 * Wi, 2, kBufLds, &a.S, augcl::extra_strips(0, Wi));
@@ -804,8 +813,24 @@ int augcl_enc_conv32_forward(const float *in, const float *w, const float *bias,
     const size_t bufw = (size_t)32 * (((a.RT + 2) * Wi + 3) & ~3);
     const size_t lds = (std::max(2 * bufw, bufw + 32 * 292) + 32) * 4; // two tile buffers, or one + the weight staging
     if (int rc = set_lds(k_conv32<0>, lds, name)) return rc;
-    hipLaunchKernelGGL(k_conv32<0>, dim3(grid_for(a.n_items, 1)), dim3(512), lds, as_stream(stream), a);
+    int grid = grid_for(a.n_items, 1);
+    if (a.dual) grid &= ~1; // even / odd workgroups serve the two halves
+    hipLaunchKernelGGL(k_conv32<0>, dim3(grid), dim3(512), lds, as_stream(stream), a);
     return augcl::check_launch(name);
+}
+
+int augcl_enc_conv32_forward(const float *in, const float *w, const float *bias, float *out, int B, int Hi, int Wi,
+                             int relu, augcl_stream_t stream)
+{
+    return conv32_forward_impl(in, w, bias, nullptr, nullptr, out, B, Hi, Wi, relu, stream, "augcl_enc_conv32_forward");
+}
+
+// internal (encoder_stack.cpp): B2 images, the first half with (w, bias), the second with (w2, bias2)
+int augcl_internal_conv32_forward_dual(const float *in, const float *w, const float *bias, const float *w2,
+                                       const float *bias2, float *out, int B2, int Hi, int Wi, int relu,
+                                       augcl_stream_t stream)
+{
+    return conv32_forward_impl(in, w, bias, w2, bias2, out, B2, Hi, Wi, relu, stream, "augcl_enc_stack_forward_dual");
 }
 
 int augcl_enc_conv32_backward_data(const float *dz, const float *w, const float *act_prev, float *dact, int B,

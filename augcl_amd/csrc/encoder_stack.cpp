@@ -43,6 +43,44 @@ int augcl_enc_stack_forward(const float *x, const float *const *w, const float *
     return AUGCL_OK;
 }
 
+int augcl_internal_conv32_forward_dual(const float *in, const float *w, const float *bias, const float *w2,
+                                       const float *bias2, float *out, int B2, int Hi, int Wi, int relu,
+                                       augcl_stream_t stream);
+int augcl_internal_bf16_conv32_forward_dual(const void *in_bf16_nhwc, const float *w, const float *bias, const float *w2,
+                                            const float *bias2, void *out, int B2, int Hi, int Wi, int relu,
+                                            int out_f32_nchw, augcl_stream_t stream);
+
+// Two encoders with identical shapes over the SAME input batch, one launch per layer (no-grad passes: the actor's CNN and
+// the target critic's CNN over next_obs in SAC.calculate_target_Q).  acts_out[i] holds 2B images: [0,B) from set A,
+// [B,2B) from set B.  Even workgroups serve set A, odd ones set B (a workgroup keeps one weight set in registers).
+// Returns AUGCL_E_UNSUPPORTED for shapes without a pipelined first-layer kernel: the caller then runs two passes.
+int augcl_enc_stack_forward_dual(const float *x, const float *const *wA, const float *const *bA, const float *const *wB,
+                                 const float *const *bB, void *const *acts_out, int n_layers, int B, int C, int H, int W,
+                                 int first_stride, float scale, int precision, augcl_stream_t stream)
+{
+    const char *name = "augcl_enc_stack_forward_dual";
+    AUGCL_REQUIRE(x && wA && bA && wB && bB && acts_out && n_layers >= 2 && B >= 1, "%s: bad argument", name);
+    const int B2 = 2 * B;
+    int rc = augcl::conv_first9_try(x, wA[0], bA[0], acts_out[0], B2, C, H, W, first_stride, scale, 1, precision == 1,
+                                    (hipStream_t)stream, name, wB[0], bB[0]);
+    if (rc > 0) return augcl::fail(AUGCL_E_UNSUPPORTED, "%s: first-layer shape (%d,%d,%d) stride %d not covered", name, C, H, W, first_stride);
+    if (rc != AUGCL_OK) return rc;
+    int h = out_hw(H, first_stride), ww = out_hw(W, first_stride);
+    for (int i = 1; i < n_layers; ++i) {
+        const int relu = i < n_layers - 1;
+        if (precision == 0)
+            rc = augcl_internal_conv32_forward_dual((const float *)acts_out[i - 1], wA[i], bA[i], wB[i], bB[i],
+                                                    (float *)acts_out[i], B2, h, ww, relu, stream);
+        else
+            rc = augcl_internal_bf16_conv32_forward_dual(acts_out[i - 1], wA[i], bA[i], wB[i], bB[i], acts_out[i], B2, h, ww,
+                                                         relu, i == n_layers - 1 ? 1 : 0, stream);
+        if (rc != AUGCL_OK) return rc;
+        h -= 2;
+        ww -= 2;
+    }
+    return AUGCL_OK;
+}
+
 // acts_in[i] = input of layer i (acts_in[0] = x raw f32; i >= 1: post-ReLU activation, f32 NCHW or bf16 NHWC);
 // grad_out = f32 NCHW gradient of the last layer's output; dz_a / dz_b = two scratch buffers, each large enough for
 // the largest activation (layer 0's output) in the mode's element type; dw[i] / db[i] receive the gradients.

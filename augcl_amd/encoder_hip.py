@@ -108,6 +108,32 @@ def _ptr_array(ptrs):
     return (_lib.ctypes.c_void_p * len(ptrs))(*ptrs)
 
 
+def conv_stack_dual(x, weights_a, biases_a, weights_b, biases_b, first_stride, input_scale, precision):
+    """Two conv stacks with the same shapes (different weights) over the SAME input, no gradients: one launch per layer
+    for both (augcl_enc_stack_forward_dual).  Returns a (2B,32,h,w) f32 tensor -- rows [0,B) from set A, [B,2B) from
+    set B -- or None when the shape is not covered (the caller runs two ordinary passes)."""
+    n_layers = len(weights_a)
+    B, C, H, W = x.shape
+    if n_layers < 2 or C != 9 or W != 84 or first_stride != 2 or not x.is_contiguous():
+        return None
+    dev = x.device
+    bf16 = precision == "bf16"
+    adt = torch.bfloat16 if bf16 else torch.float32
+    hs, wsz = [_out_hw(H, first_stride)], [_out_hw(W, first_stride)]
+    for _ in range(1, n_layers):
+        hs.append(hs[-1] - 2)
+        wsz.append(wsz[-1] - 2)
+    numel = [2 * B * 32 * h * w_ for h, w_ in zip(hs, wsz)]
+    out = torch.empty((2 * B, 32, hs[-1], wsz[-1]), dtype=torch.float32, device=dev)
+    big = (max(numel[:-1]) + 7) // 8 * 8
+    arena = torch.empty(2 * big, dtype=adt, device=dev)  # two ping-pong buffers
+    ptrs = [arena.data_ptr() + (i & 1) * big * arena.element_size() for i in range(n_layers - 1)] + [out.data_ptr()]
+    d = lambda ts: _ptr_array([t.detach().data_ptr() for t in ts])  # noqa: E731
+    _lib.call("augcl_enc_stack_forward_dual", x.data_ptr(), d(weights_a), d(biases_a), d(weights_b), d(biases_b),
+              _ptr_array(ptrs), n_layers, B, C, H, W, first_stride, input_scale, 1 if bf16 else 0, _lib.current_stream(dev))
+    return out
+
+
 class ConvStackFn(torch.autograd.Function):
     """The SharedCNN stack through the whole-stack C entry points: ONE FFI call per forward, one per backward, one
     activation arena per pass.  precision "f32" = parity path (f32 NCHW activations, f32 MFMA), "bf16" = performance

@@ -41,6 +41,21 @@ def _conv_stack_torch(x, weights, biases, first_stride, input_scale, relu_first)
     return h
 
 
+def conv_stack_dual(x, weights_a, biases_a, weights_b, biases_b, first_stride=2, input_scale=255.0):
+    """No-grad forward of TWO stacks with identical shapes over the same input in one launch per layer; returns the two
+    outputs, or None when the fused path does not cover the case (HIP backend, 9 x H x 84 input, stride 2)."""
+    if BACKEND != "hip" or not x.is_cuda or len(weights_a) != len(weights_b) or len(weights_a) < 2:
+        return None
+    if any(a.shape != b.shape for a, b in zip(weights_a, weights_b)) or x.dtype != torch.float32:
+        return None
+    from . import encoder_hip
+    out = encoder_hip.conv_stack_dual(x, weights_a, biases_a, weights_b, biases_b, first_stride, float(input_scale), PRECISION)
+    if out is None:
+        return None
+    B = x.shape[0]
+    return out[:B], out[B:]
+
+
 def conv_stack(x, weights, biases, first_stride=2, input_scale=255.0, relu_first=False):
     """x: (B,C,H,W) f32 (0..255 when input_scale=255).  Returns the last conv's output (no final ReLU)."""
     if BACKEND == "torch":

@@ -250,6 +250,14 @@ int augcl_enc_stack_backward(const void *const *acts_in, const float *const *w, 
                              size_t ws_first_bytes, int n_layers, int B, int C, int H, int W, int first_stride,
                              float scale, int precision, int bf16_wgrad_mfma, augcl_stream_t stream);
 
+/* Two encoders with identical shapes over the SAME input batch in one launch per layer (no-grad passes: the actor's CNN
+ * and the target critic's CNN over next_obs, src/algorithms/sac.py:94-101).  acts_out[i] holds 2B images: [0,B) from
+ * weight set A, [B,2B) from set B; the last layer writes f32 NCHW (2B,32,h,w).  AUGCL_E_UNSUPPORTED when the first-layer
+ * shape has no pipelined kernel (9 x H x 84, stride 2): run two augcl_enc_stack_forward passes instead. */
+int augcl_enc_stack_forward_dual(const float *x, const float *const *wA, const float *const *bA, const float *const *wB,
+                                 const float *const *bB, void *const *acts_out, int n_layers, int B, int C, int H, int W,
+                                 int first_stride, float scale, int precision, augcl_stream_t stream);
+
 /* ---- device-resident replay sampling: ReplayBuffer.sample -> tensor_buffer_samples / _encode_obses /
  * LazyFrames._force (src/utils.py:206-214, 234-240, 272-280, 293-299).  `frames` is a uint8 ring of RGB frames
  * (frame_bytes = 3*H*W each) in HBM; slots[b*stack + k] names the k-th frame of sample b's stack.

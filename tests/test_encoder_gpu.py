@@ -146,3 +146,30 @@ def test_bf16_perf_mode_tracks_f32(cuda, B, gate_safe):
             assert _l2(bg[i].grad.cpu(), br[i].grad) <= 2e-2, f"db layer {i}"
         else:
             assert float(g @ r / (g.norm() * r.norm())) > 0.95, f"dW layer {i} direction"
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+@pytest.mark.parametrize("B", [1, 6, 256])
+def test_dual_stack_forward_equals_two_passes(cuda, B, precision):
+    """augcl_enc_stack_forward_dual: two weight sets over the same input in one launch per layer give exactly what two
+    separate forward passes give (same kernels, same arithmetic per image)."""
+    rs = np.random.RandomState(B)
+    x = torch.from_numpy(rs.randint(0, 256, (B, 9, 84, 84)).astype(np.float32)).to(cuda)
+    mk = lambda seed: ([torch.from_numpy((np.random.RandomState(seed + i).standard_normal((32, 9 if i == 0 else 32, 3, 3)) * 0.1).astype(np.float32)).to(cuda) for i in range(11)],  # noqa: E731
+                       [torch.from_numpy((np.random.RandomState(seed + 50 + i).standard_normal(32) * 0.05).astype(np.float32)).to(cuda) for i in range(11)])
+    (wa, ba), (wb, bb) = mk(100), mk(200)
+    encoder_ops.set_precision(precision)
+    try:
+        with torch.no_grad():
+            both = encoder_ops.conv_stack_dual(x, wa, ba, wb, bb)
+            one_a = encoder_ops.conv_stack(x, wa, ba)
+            one_b = encoder_ops.conv_stack(x, wb, bb)
+        torch.cuda.synchronize()
+    finally:
+        encoder_ops.set_precision("f32")
+    assert both is not None
+    assert torch.equal(both[0], one_a) and torch.equal(both[1], one_b)
+    # shapes without the pipelined first layer fall back (None), they do not fail
+    with torch.no_grad():
+        assert encoder_ops.conv_stack_dual(torch.rand(2, 3, 40, 40, device=cuda), [w[:, :3].contiguous() if i == 0 else w for i, w in enumerate(wa)], ba,
+                                           [w[:, :3].contiguous() if i == 0 else w for i, w in enumerate(wb)], bb) is None
