@@ -163,6 +163,8 @@ class ReplayBuffer(object):
         if idxs is None:
             idxs = self._get_idxs(n)
         idxs = np.ascontiguousarray(idxs, dtype=np.int64)
+        if idxs.size and (idxs.min() < 0 or idxs.max() >= (self.capacity if self.full else max(self.idx, 1))):
+            raise IndexError("replay sample: transition index outside the filled part of the buffer")
         dtype = dtype or self.sample_dtype
         if min(self.obs_seq[idxs].min(), self.next_seq[idxs].min()) < self.frame_seq - self.n_slots:
             raise _lib.AugclError("replay frame ring too small: a sampled transition's frame was overwritten "
