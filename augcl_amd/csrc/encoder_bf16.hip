@@ -66,7 +66,7 @@ __global__ __launch_bounds__(512, 2) void k_conv32_bf16(ConvBfArgs a)
     const int bufbytes = tilepix * PIXB;
     float *lbias = reinterpret_cast<float *>(ldsc + max(2 * bufbytes, bufbytes + WST_BYTES));
     const int grp = a.dual ? (int)(blockIdx.x & 1) : 0, nhalf = a.n_items >> 1;
-    const int first = a.dual ? grp * nhalf + (int)(blockIdx.x >> 1) : (int)blockIdx.x;
+    const int first = a.dual ? grp * nhalf + (int)(blockIdx.x >> 1) : xcd_slot((int)blockIdx.x, (int)gridDim.x);
     const int NG = a.dual ? (int)(gridDim.x >> 1) : (int)gridDim.x;
     const int n = a.dual ? (grp + 1) * nhalf : a.n_items;
 
@@ -526,7 +526,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad32_bf16(WgBfArgs a)
         vu4 *dzl = da + apix * 4;
         for (int c = nz + lt; c < zpix * 4; c += 256) dzl[c] = vu4{0u, 0u, 0u, 0u}; // zero the padded pixels
     };
-    const int first = blockIdx.x, G = gridDim.x, n = a.n_items;
+    const int G = gridDim.x, n = a.n_items, first = xcd_slot((int)blockIdx.x, G);
     // The two roles run DIFFERENT code with the same barrier sequence (1 + one per item + 6): the branch is
     // wave-uniform, and keeping the accumulators and the prefetch registers in separate branches keeps their
     // live ranges apart (together they would not fit the register file).
