@@ -63,7 +63,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_first9(First9Args a)
     const int bufwords = (rows_in_max + 1) * ROWF; // + one slack row block (the K pad reads into it)
     float *lbias = ldsf + 2 * bufwords;
     const int grp = a.dual ? (int)(blockIdx.x & 1) : 0, nhalf = a.n_items >> 1;
-    const int first = a.dual ? grp * nhalf + (int)(blockIdx.x >> 1) : (int)blockIdx.x;
+    const int first = a.dual ? grp * nhalf + (int)(blockIdx.x >> 1) : xcd_slot((int)blockIdx.x, (int)gridDim.x);
     const int NG = a.dual ? (int)(gridDim.x >> 1) : (int)gridDim.x;
     const int n = a.dual ? (grp + 1) * nhalf : a.n_items;
 

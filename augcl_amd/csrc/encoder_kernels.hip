@@ -198,7 +198,7 @@ __global__ __launch_bounds__(512, 2) void k_conv32(ConvArgs a)
 
     int it = 0;
     const int grp = a.dual ? (int)(blockIdx.x & 1) : 0, nhalf = a.n_items >> 1;
-    const int first = a.dual ? grp * nhalf + (int)(blockIdx.x >> 1) : (int)blockIdx.x;
+    const int first = a.dual ? grp * nhalf + (int)(blockIdx.x >> 1) : xcd_slot((int)blockIdx.x, (int)gridDim.x);
     const int NG = a.dual ? (int)(gridDim.x >> 1) : (int)gridDim.x;
     const int n_end = a.dual ? (grp + 1) * nhalf : a.n_items;
     if (loader && first < n_end && ABL != 1) stage(first, 0);
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(256, 1) void k_wgrad32(WgradArgs a)
 
     WgPrefetch pf;
     int it = 0;
-    const int first = blockIdx.x;
+    const int first = xcd_slot((int)blockIdx.x, (int)gridDim.x); // neighbouring strips on one XCD (halo rows hit in L2)
     if (first < a.n_items) {
         issue(first, pf);
         commit(first, 0, pf);
