@@ -24,7 +24,7 @@ class AugclError(RuntimeError):
 def build(force=False, verbose=False):
     """Compile libaugcl_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
     csrc = os.path.join(_PKG, "csrc")
-    cmd = ["make", "-C", csrc] + (["-B"] if force else [])
+    cmd = ["make", "-j4", "-C", csrc] + (["-B"] if force else [])  # hipcc per file: 4 jobs fit the build container
     r = subprocess.run(cmd, capture_output=True, text=True)
     if verbose or r.returncode != 0:
         print(r.stdout + r.stderr)
