@@ -126,9 +126,9 @@ __global__ __launch_bounds__(256) void k_random_shift(const TIn *__restrict__ in
     Quad<W, TIn> q;
     q.load(src, base);
     if constexpr (sizeof(TOut) == 1)
-        *reinterpret_cast<uint32_t *>(dst) = q.packed(x4 + dx - base);
+        store_nt(reinterpret_cast<uint32_t *>(dst), q.packed(x4 + dx - base));
     else
-        *reinterpret_cast<float4 *>(dst) = q.get(x4 + dx - base);
+        store_nt(reinterpret_cast<float *>(dst), q.get(x4 + dx - base));
 }
 
 // any shape / alignment: one element per thread (correctness fallback, not tuned)
@@ -259,7 +259,7 @@ __device__ __forceinline__ void conv_compute_store(const ConvSmem<H, W, R> &sm, 
         float4 res = make_float4(sigmoid255(acc[o][0].x), sigmoid255(acc[o][0].y), sigmoid255(acc[o][1].x),
                                  sigmoid255(acc[o][1].y));
         if (ABL == 1) res = make_float4(acc[o][0].x, acc[o][0].y, acc[o][1].x, acc[o][1].y);
-        *reinterpret_cast<float4 *>(out_frame + ((size_t)o * H + (y0 + ry)) * W + x4) = res;
+        store_nt(out_frame + ((size_t)o * H + (y0 + ry)) * W + x4, res);
     }
 }
 
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(NT) void k_conv(const TIn *__restrict__ in, float *
             const int ys = y0 - 1 + rr;
             float4 q = raw[k].get(SHIFT ? x4 + dx - clampi(x4 + dx, 0, W - 4) : 0);
             if (SHIFT && out_shift != nullptr && ys >= y0 && ys < y0 + R)
-                *reinterpret_cast<float4 *>(out_shift + ((size_t)(fidx * 3 + ch) * H + ys) * W + x4) = q;
+                store_nt(out_shift + ((size_t)(fidx * 3 + ch) * H + ys) * W + x4, q);
             q.x = div255(q.x);
             q.y = div255(q.y);
             q.z = div255(q.z);
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(256) void k_random_overlay(const float *__restrict_
         o.y = (one_minus_alpha * div255(x.y) + c.y) * 255.0f;
         o.z = (one_minus_alpha * div255(x.z) + c.z) * 255.0f;
         o.w = (one_minus_alpha * div255(x.w) + c.w) * 255.0f;
-        reinterpret_cast<float4 *>(out)[idx] = o;
+        store_nt(out + 4 * (size_t)idx, o);
     }
 }
 

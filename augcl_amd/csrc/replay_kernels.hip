@@ -23,8 +23,8 @@ __global__ __launch_bounds__(256) void k_replay_gather(const uint8_t *__restrict
         if constexpr (sizeof(TOut) == 1)
             reinterpret_cast<uint32_t *>(out)[q] = v;
         else
-            reinterpret_cast<float4 *>(out)[q] =
-                make_float4((float)(v & 0xffu), (float)((v >> 8) & 0xffu), (float)((v >> 16) & 0xffu), (float)(v >> 24));
+            store_nt(reinterpret_cast<float *>(out) + 4 * q,
+                     make_float4((float)(v & 0xffu), (float)((v >> 8) & 0xffu), (float)((v >> 16) & 0xffu), (float)(v >> 24)));
     }
 }
 
@@ -51,8 +51,8 @@ __global__ __launch_bounds__(256) void k_replay_sample(const uint8_t *__restrict
         if constexpr (sizeof(TOut) == 1)
             reinterpret_cast<uint32_t *>(out)[r] = v;
         else
-            reinterpret_cast<float4 *>(out)[r] =
-                make_float4((float)(v & 0xffu), (float)((v >> 8) & 0xffu), (float)((v >> 16) & 0xffu), (float)(v >> 24));
+            store_nt(reinterpret_cast<float *>(out) + 4 * r,
+                     make_float4((float)(v & 0xffu), (float)((v >> 8) & 0xffu), (float)((v >> 16) & 0xffu), (float)(v >> 24)));
     }
     for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < (size_t)B * S; q += (size_t)gridDim.x * 256) {
         const int b = (int)(q / S), j = (int)(q - (size_t)b * S);
