@@ -38,27 +38,28 @@ __global__ __launch_bounds__(256) void k_replay_sample(const uint8_t *__restrict
                                                        TOut *__restrict__ obs, TOut *__restrict__ next_obs,
                                                        float *__restrict__ scal_out, int B, int stack, int fq, int S)
 {
-    const size_t per = (size_t)B * stack * fq, total = 2 * per;
-    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (size_t)gridDim.x * 256) {
-        const int which = q >= per;
-        const size_t r = q - which * per;
-        const size_t fi = r / fq; // = b*stack + k
-        const int off = (int)(r - fi * fq);
-        const int b = (int)(fi / stack), k = (int)(fi - (size_t)b * stack);
-        const int slot = slot_tab[idx[b] * (2 * stack) + which * stack + k];
-        const uint32_t v = reinterpret_cast<const uint32_t *>(frames)[(size_t)slot * fq + off];
-        TOut *out = which ? next_obs : obs;
+    // blockIdx.y = one frame of one stack: (which tensor, sample b, frame k) -- the table lookups are per workgroup and
+    // on the scalar unit; blockIdx.x walks the frame's dwords (no per-element division).
+    const int f = blockIdx.y, per = B * stack;
+    const int which = f >= per;
+    const int fi = f - which * per; // = b*stack + k
+    const int b = fi / stack, k = fi - b * stack;
+    const int slot = slot_tab[idx[b] * (2 * stack) + which * stack + k];
+    const uint32_t *__restrict__ src = reinterpret_cast<const uint32_t *>(frames) + (size_t)slot * fq;
+    TOut *out = which ? next_obs : obs;
+    for (int off = blockIdx.x * 256 + threadIdx.x; off < fq; off += gridDim.x * 256) {
+        const uint32_t v = src[off];
+        const size_t r = (size_t)fi * fq + off;
         if constexpr (sizeof(TOut) == 1)
-            reinterpret_cast<uint32_t *>(out)[r] = v;
+            store_nt(reinterpret_cast<uint32_t *>(out) + r, v);
         else
             store_nt(reinterpret_cast<float *>(out) + 4 * r,
                      make_float4((float)(v & 0xffu), (float)((v >> 8) & 0xffu), (float)((v >> 16) & 0xffu), (float)(v >> 24)));
     }
-    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < (size_t)B * S; q += (size_t)gridDim.x * 256) {
-        const int b = (int)(q / S), j = (int)(q - (size_t)b * S);
-        // outputs as three contiguous blocks: actions [B][S-2], rewards [B], not_dones [B]
-        const int A = S - 2;
-        scal_out[j < A ? (size_t)b * A + j : (size_t)B * A + (size_t)(j - A) * B + b] = scal[idx[b] * S + j];
+    if (blockIdx.x == 0 && which == 0 && k == 0) { // one workgroup per sample copies its scalars
+        const int A = S - 2; // outputs as three contiguous blocks: actions [B][S-2], rewards [B], not_dones [B]
+        for (int j = threadIdx.x; j < S; j += 256)
+            scal_out[j < A ? (size_t)b * A + j : (size_t)B * A + (size_t)(j - A) * B + b] = scal[idx[b] * S + j];
     }
 }
 
@@ -76,9 +77,8 @@ extern "C" int augcl_replay_sample(const uint8_t *frames, const int32_t *slot_ta
     AUGCL_REQUIRE(frames && slot_tab && idx && obs && next_obs && (S == 0 || (scal && scal_out)), "%s: null buffer", name);
     AUGCL_REQUIRE(aligned16(frames) && aligned16(obs) && aligned16(next_obs), "%s: buffers must be 16-byte aligned", name);
     const int fq = frame_bytes / 4;
-    const size_t total = (size_t)2 * B * stack * fq;
-    const size_t blocks = (total + 255) / 256;
-    const unsigned grid = (unsigned)(blocks < 16384 ? blocks : 16384);
+    AUGCL_REQUIRE((size_t)2 * B * stack <= 65535, "%s: batch too large for one launch", name);
+    const dim3 grid((fq + 255) / 256 < 8 ? (fq + 255) / 256 : 8, 2 * B * stack);
     hipStream_t s = as_stream(stream);
     if (out_f32)
         hipLaunchKernelGGL(k_replay_sample<float>, dim3(grid), dim3(256), 0, s, frames, slot_tab, scal, idx, (float *)obs,
