@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void k_affine_gather(const float *__restrict__
         int sy = ay * y + by * x + cy, sx = ax * y + bx * x + cx;
         sy = sy < 0 ? 0 : (sy >= Hin ? Hin - 1 : sy); // host validates the coefficients; stay in bounds regardless
         sx = sx < 0 ? 0 : (sx >= Win ? Win - 1 : sx);
-        dst[j] = src[sy * Win + sx];
+        __builtin_nontemporal_store(src[sy * Win + sx], &dst[j]);
     }
 }
 
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void k_cutout_color(const float *__restrict__ 
     for (int j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
         const int y = j / W, x = j - y * W;
         const bool inside = y >= h1 && y < 2 * h1 && x >= w1 && x < 2 * w1;
-        out[(size_t)plane * n + j] = inside ? col : in[(size_t)plane * n + j];
+        __builtin_nontemporal_store(inside ? col : in[(size_t)plane * n + j], &out[(size_t)plane * n + j]);
     }
 }
 
@@ -60,9 +60,9 @@ __global__ __launch_bounds__(256) void k_random_grayscale(const float *__restric
     for (int j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) {
         const float r = u8wrap(src[j] * 255.0f), g = u8wrap(src[n + j] * 255.0f), bl = u8wrap(src[2 * n + j] * 255.0f);
         const float gray = u8wrap((r * 0.2989f + g * 0.587f) + bl * 0.114f);
-        dst[j] = (m ? gray : r) / 255.0f;
-        dst[n + j] = (m ? gray : g) / 255.0f;
-        dst[2 * n + j] = (m ? gray : bl) / 255.0f;
+        __builtin_nontemporal_store((m ? gray : r) / 255.0f, &dst[j]);
+        __builtin_nontemporal_store((m ? gray : g) / 255.0f, &dst[n + j]);
+        __builtin_nontemporal_store((m ? gray : bl) / 255.0f, &dst[2 * n + j]);
     }
 }
 
@@ -98,9 +98,9 @@ __global__ __launch_bounds__(256) void k_splice(const float *__restrict__ x, con
         const bool keep = h > ht && sat > st && mx > vt;
         bool use_rgb = keep;
         if (cs_mode) use_rgb = (h > 0.0f && sat > st && mx > 0.6f) || !keep;
-        dst[p] = (use_rgb ? r : ov[p]) * 255.0f;
-        dst[n + p] = (use_rgb ? g : ov[n + p]) * 255.0f;
-        dst[2 * n + p] = (use_rgb ? b : ov[2 * n + p]) * 255.0f;
+        __builtin_nontemporal_store((use_rgb ? r : ov[p]) * 255.0f, &dst[p]);
+        __builtin_nontemporal_store((use_rgb ? g : ov[n + p]) * 255.0f, &dst[n + p]);
+        __builtin_nontemporal_store((use_rgb ? b : ov[2 * n + p]) * 255.0f, &dst[2 * n + p]);
     }
 }
 
