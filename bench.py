@@ -172,14 +172,17 @@ def main():
     B, R = args.batch, args.ring
     g = torch.Generator(device=dev)
     g.manual_seed(1000 + rank)
-    ring_u8 = [torch.randint(0, 256, (B, 9, 84, 84), dtype=torch.uint8, device=dev, generator=g) for _ in range(R)]
-    ring_f32 = [t.float() for t in ring_u8]
+    # every input ring must exceed the 256 MiB Infinity Cache on its own: the outputs are written with non-temporal
+    # stores and no longer evict the inputs (an 8-deep uint8 ring = 130 MB stayed cache-resident and read 35 % "faster")
+    R8 = max(R, 40)
+    ring_u8 = [torch.randint(0, 256, (B, 9, 84, 84), dtype=torch.uint8, device=dev, generator=g) for _ in range(R8)]
+    ring_f32 = [t.float() for t in ring_u8[:R]]
     outs = [torch.empty((B, 9, 84, 84), dtype=torch.float32, device=dev) for _ in range(R)]
     outs2 = [torch.empty((B, 9, 84, 84), dtype=torch.float32, device=dev) for _ in range(2)]
     weights = torch.randn((B, 81), device=dev, generator=g)
     oy = torch.randint(0, 9, (B,), dtype=torch.int32, device=dev, generator=g)
     ox = torch.randint(0, 9, (B,), dtype=torch.int32, device=dev, generator=g)
-    overlay = torch.rand((B, 3, 84, 84), device=dev, generator=g)
+    overlays = [torch.rand((B, 3, 84, 84), device=dev, generator=g) for _ in range(16)]  # 16 x 21.7 MB: not cache-resident
     stream = torch.cuda.current_stream(dev).cuda_stream
     call = _lib.call
     p = _lib.ptr
@@ -224,11 +227,11 @@ def main():
 
         rate("random_shift_f32", lambda i: call("augcl_random_shift_f32", p(ring_f32[i % R]), p(outs[i % R]), B, 9, 84, 84, 4,
                                                 p(oy), p(ox), 0, 0, 0, stream))
-        rate("random_shift_u8_f32", lambda i: call("augcl_random_shift_u8_f32", p(ring_u8[i % R]), p(outs[i % R]), B, 9, 84,
+        rate("random_shift_u8_f32", lambda i: call("augcl_random_shift_u8_f32", p(ring_u8[i % R8]), p(outs[i % R]), B, 9, 84,
                                                    84, 4, p(oy), p(ox), 0, 0, 0, stream))
-        rate("random_overlay_f32", lambda i: call("augcl_random_overlay_f32", p(ring_f32[i % R]), p(overlay), p(outs[i % R]),
+        rate("random_overlay_f32", lambda i: call("augcl_random_overlay_f32", p(ring_f32[i % R]), p(overlays[i % 16]), p(outs[i % R]),
                                                   B, 3, 84, 84, 0.5, stream))
-        rate("shift_conv_u8_f32", lambda i: call("augcl_shift_conv_u8_f32", p(ring_u8[i % R]), p(outs[i % R]),
+        rate("shift_conv_u8_f32", lambda i: call("augcl_shift_conv_u8_f32", p(ring_u8[i % R8]), p(outs[i % R]),
                                                  p(outs2[i % 2]), B, 3, 84, 84, 4, p(oy), p(ox), p(weights), 0, 0, 0, stream))
         order = (_lib.ctypes.c_int32 * 4)(1, 2, 3, 0)
         order_p = _lib.ctypes.cast(order, _lib.ctypes.c_void_p)
