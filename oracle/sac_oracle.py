@@ -127,13 +127,74 @@ def synth_state(seed, shapes, gate_safe=True):
     return out
 
 
+def _orthogonal(rs, rows, cols, gain=1.0):
+    """nn.init.orthogonal_ restated without LAPACK (modules.py:52-66 calls it for every Linear and for the centre
+    tap of every Conv2d): a (rows, cols) matrix with orthonormal rows (rows <= cols) or columns (rows > cols) times
+    gain, from a seeded normal matrix by modified Gram-Schmidt with one re-orthogonalisation pass, float64."""
+    n, k = max(rows, cols), min(rows, cols)
+    a = rs.standard_normal((n, k))
+    q = np.zeros((n, k))
+    for j in range(k):
+        v = a[:, j].copy()
+        for _ in range(2):
+            v -= q[:, :j] @ (q[:, :j].T @ v)
+        q[:, j] = v / np.linalg.norm(v)
+    return gain * (q if rows > cols else q.T)
+
+
+def real_init_state(seed, shapes):
+    """The reference's ACTUAL initial state (weight_init, modules.py:52-66), seeded and box-independent: Linear =
+    orthogonal weight, zero bias; Conv2d = all taps zero except the centre one, which is an orthogonal (out, in) matrix
+    times the ReLU gain sqrt(2), zero bias; LayerNorm = (1, 0)."""
+    rs = np.random.RandomState(seed)
+    out = {}
+    for name in sorted(shapes):
+        shp = shapes[name]
+        if name.endswith("projection.1.weight"):
+            v = np.ones(shp)
+        elif name.endswith(".bias"):
+            v = np.zeros(shp)
+        elif len(shp) == 4:
+            v = np.zeros(shp)
+            v[:, :, shp[2] // 2, shp[3] // 2] = _orthogonal(rs, shp[0], shp[1], math.sqrt(2.0))
+        else:
+            v = _orthogonal(rs, shp[0], shp[1])
+        out[name] = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32))
+    return out
+
+
 # ------------------------------------------------------------------ networks (functional)
-def cnn_forward(p, x, hp):
+class _GatedReLU(torch.autograd.Function):
+    """ReLU whose gate is given from outside: y = z * gate, dz = dy * gate (see `_relu`)."""
+
+    @staticmethod
+    def forward(ctx, z, gate):
+        ctx.save_for_backward(gate)
+        return z * gate
+
+    @staticmethod
+    def backward(ctx, g):
+        (gate,) = ctx.saved_tensors
+        return g * gate, None
+
+
+def _relu(h, gates, key, i):
+    """torch.relu, or -- when `gates` (a dict of lists of 0/1 tensors) has an entry for this ReLU -- the same function
+    with the on/off decision taken from outside.  ReLU's derivative jumps at 0: a pre-activation within float32
+    rounding of zero can gate differently in two correct float32 evaluations, and one such flip moves the gradients
+    below it by ~1/sqrt(#samples).  The large-batch parity tests hand the float64 referee the gates of the
+    implementation under test, so that what is left to compare is arithmetic (tests/test_referee_gpu.py)."""
+    if gates is None or key not in gates:
+        return torch.relu(h)
+    return _GatedReLU.apply(h, gates[key][i].to(device=h.device, dtype=h.dtype))
+
+
+def cnn_forward(p, x, hp, gates=None):
     h = x / 255.0
     ids = conv_layer_ids(hp["num_shared_layers"])
     for li, idx in enumerate(ids):
         if li > 0:
-            h = torch.relu(h)
+            h = _relu(h, gates, "cnn", li - 1)
         h = F.conv2d(h, p[f"encoder.shared_cnn.layers.{idx}.weight"], p[f"encoder.shared_cnn.layers.{idx}.bias"],
                      stride=2 if li == 0 else 1)
     for li in range(hp["num_head_layers"]):
@@ -142,8 +203,8 @@ def cnn_forward(p, x, hp):
     return h.flatten(1)
 
 
-def encode(p, x, hp, detach=False):
-    h = cnn_forward(p, x, hp)
+def encode(p, x, hp, detach=False, gates=None):
+    h = cnn_forward(p, x, hp, gates)
     if detach:
         h = h.detach()
     h = F.linear(h, p["encoder.projection.projection.0.weight"], p["encoder.projection.projection.0.bias"])
@@ -152,11 +213,11 @@ def encode(p, x, hp, detach=False):
     return torch.tanh(h)
 
 
-def actor_forward(p, x, hp, noise=None, detach=False):
+def actor_forward(p, x, hp, noise=None, detach=False, gates=None):
     """returns mu, pi, log_pi, log_std (modules.py:216-244). noise=None => compute_pi=False."""
-    h = encode(p, x, hp, detach)
-    h = torch.relu(F.linear(h, p["mlp.0.weight"], p["mlp.0.bias"]))
-    h = torch.relu(F.linear(h, p["mlp.2.weight"], p["mlp.2.bias"]))
+    h = encode(p, x, hp, detach, gates)
+    h = _relu(F.linear(h, p["mlp.0.weight"], p["mlp.0.bias"]), gates, "mlp", 0)
+    h = _relu(F.linear(h, p["mlp.2.weight"], p["mlp.2.bias"]), gates, "mlp", 1)
     mu, log_std = F.linear(h, p["mlp.4.weight"], p["mlp.4.bias"]).chunk(2, dim=-1)
     lo, hi = hp["actor_log_std_min"], hp["actor_log_std_max"]
     log_std = lo + 0.5 * (hi - lo) * (torch.tanh(log_std) + 1)
@@ -169,16 +230,16 @@ def actor_forward(p, x, hp, noise=None, detach=False):
     return mu, pi, log_pi, log_std
 
 
-def q_forward(p, q, h, a):
+def q_forward(p, q, h, a, gates=None):
     z = torch.cat([h, a], dim=1)
-    z = torch.relu(F.linear(z, p[f"{q}.trunk.0.weight"], p[f"{q}.trunk.0.bias"]))
-    z = torch.relu(F.linear(z, p[f"{q}.trunk.2.weight"], p[f"{q}.trunk.2.bias"]))
+    z = _relu(F.linear(z, p[f"{q}.trunk.0.weight"], p[f"{q}.trunk.0.bias"]), gates, q, 0)
+    z = _relu(F.linear(z, p[f"{q}.trunk.2.weight"], p[f"{q}.trunk.2.bias"]), gates, q, 1)
     return F.linear(z, p[f"{q}.trunk.4.weight"], p[f"{q}.trunk.4.bias"])
 
 
-def critic_forward(p, x, a, hp, detach=False):
-    h = encode(p, x, hp, detach)
-    return q_forward(p, "Q1", h, a), q_forward(p, "Q2", h, a)
+def critic_forward(p, x, a, hp, detach=False, gates=None):
+    h = encode(p, x, hp, detach, gates)
+    return q_forward(p, "Q1", h, a, gates), q_forward(p, "Q2", h, a, gates)
 
 
 # ------------------------------------------------------------------ Adam (torch.optim.Adam, no amsgrad / wd)
@@ -223,18 +284,25 @@ class OracleAgent:
     """algo in {sac, rad, non_naive_rad, svea, drq, augcl}.  All randomness is passed in:
     `aug(x)` callables for the augmentations and explicit actor noise tensors."""
 
-    def __init__(self, algo, obs_shape, A, actor_state, critic_state, hp=None):
+    def __init__(self, algo, obs_shape, A, actor_state, critic_state, hp=None, dtype=torch.float32, device="cpu"):
+        """dtype=torch.float64 turns the same restatement into the REFEREE of the large-batch parity tests
+        (tests/test_referee_gpu.py): both this oracle in float32 and the HIP path are measured against it.  `device`
+        only says where torch evaluates these plain ATen ops (the referee may borrow the GPU's float64 units to stay
+        inside the test budget at B=1024); nothing of augcl_amd is involved either way."""
         self.algo = algo
         self.hp = dict(DEFAULTS, **(hp or {}))
         self.A = A
-        mk = lambda d: {k: v.clone().requires_grad_(True) for k, v in d.items()}  # noqa: E731
+        self.dtype = dtype
+        self.rec = {}  # gradients / intermediate values of the last update(), for the parity tests
+        mk = lambda d: {k: v.to(device=device, dtype=dtype).clone().requires_grad_(True) for k, v in d.items()}  # noqa: E731
         self.critic = mk(critic_state)
         self.actor = mk({k: v for k, v in actor_state.items() if not is_cnn(k)})
         for k in self.critic:  # actor and critic share the SAME CNN tensors (sac.py:17-32)
             if is_cnn(k):
                 self.actor[k] = self.critic[k]
         self.critic_target = {k: v.detach().clone() for k, v in self.critic.items()}  # deepcopy (sac.py:42)
-        self.log_alpha = torch.tensor(np.log(self.hp["init_temperature"]), dtype=torch.float64, requires_grad=True)
+        self.log_alpha = torch.tensor(np.log(self.hp["init_temperature"]), dtype=torch.float64, device=device,
+                                      requires_grad=True)
         self.target_entropy = -float(A)
         hp_ = self.hp
         self.actor_names = list(actor_shapes(obs_shape, A, hp_).keys())  # nn.Module.parameters() order
@@ -265,10 +333,17 @@ class OracleAgent:
     def _mse2(q1, q2, y):
         return F.mse_loss(q1, y) + F.mse_loss(q2, y)
 
-    def update_actor_and_alpha(self, obs, noise, log):
+    def _critic_step(self, opt, params, loss, tag):
+        opt.zero_grad()
+        loss.backward()
+        self.rec[tag] = {n: params[n].grad.detach().clone() for n in self.critic_names}
+        opt.step()
+
+    def update_actor_and_alpha(self, obs, noise, log, forced=None):
         critic = self.critic
-        _, pi, log_pi, log_std = actor_forward(self.actor, obs, self.hp, noise, detach=True)
-        q1, q2 = critic_forward(critic, obs, pi, self.hp, detach=True)
+        forced = forced or {}
+        _, pi, log_pi, log_std = actor_forward(self.actor, obs, self.hp, noise, detach=True, gates=forced.get("actor"))
+        q1, q2 = critic_forward(critic, obs, pi, self.hp, detach=True, gates=forced.get("actor_q"))
         actor_loss = (self.alpha.detach() * log_pi - torch.min(q1, q2)).mean()
         ent = 0.5 * log_std.shape[1] * (1.0 + np.log(2 * np.pi)) + log_std.sum(dim=-1)
         log["train_actor/loss"] = float(actor_loss.detach())
@@ -277,6 +352,8 @@ class OracleAgent:
         for t in critic.values():
             t.grad = None
         actor_loss.backward()
+        self.rec["actor_grads"] = {n: self.actor[n].grad.detach().clone() for n in self.actor_names
+                                   if self.actor[n].grad is not None}
         # actor_optimizer only owns actor.parameters(); grads that landed on critic-only tensors are dropped
         self.actor_opt.step()
         self.alpha_opt.zero_grad()
@@ -284,6 +361,7 @@ class OracleAgent:
         log["train_alpha/loss"] = float(alpha_loss.detach())
         log["train_alpha/value"] = float(self.alpha.detach())
         alpha_loss.backward()
+        self.rec["log_alpha_grad"] = self.log_alpha.grad.detach().clone()
         self.alpha_opt.step()
 
     def soft_update_target(self, src=None):
@@ -294,73 +372,90 @@ class OracleAgent:
         soft_update(src, self.critic_target, e, self.hp["encoder_tau"])
 
     # -- update() ---------------------------------------------------------------------------
-    def update(self, batch, step, noise_target, noise_actor=None, aug=None, shift=None, shift2=None):
-        """batch = (obs, action, reward, next_obs, not_done) float32 tensors.
-        aug(x): the RAD chain; shift(x)/shift2(x): random_shift with the caller's offsets
-        (shift2 is DrQ's second draw for next_obs)."""
+    def update(self, batch, step, noise_target, noise_actor=None, aug=None, shift=None, shift2=None, forced=None):
+        """batch = (obs, action, reward, next_obs, not_done) tensors of self.dtype.
+        forced: ReLU gates of the gradient-carrying passes taken from outside (see `_relu`): {"critic": [one dict
+        {"cnn": [...], "Q1": [...], "Q2": [...]} per critic pass, in order], "weak": [...] (AugCL's weak critic),
+        "actor": {"mlp": [...]}, "actor_q": {"Q1": [...], "Q2": [...]}}.
+        aug(x): the RAD chain; shift(x)/shift2(x): random_shift with the caller's offsets (shift2 is DrQ's draw
+        for next_obs).  DrQ with K or M > 1 (drq.py:15-65): shift / shift2 are LISTS of K / M callables and
+        noise_target a list of M noise tensors (one actor call per next_obs copy)."""
         obs, action, reward, next_obs, not_done = batch
         log = {}
+        self.rec = {}
         algo = self.algo
+        forced = forced or {}
+        fc = lambda key, i: (forced[key][i] if key in forced else None)  # noqa: E731
         if algo in ("sac", "rad", "non_naive_rad"):
             if algo in ("rad", "non_naive_rad"):
                 obs = aug(obs)
             if algo == "rad":
                 next_obs = aug(next_obs)
             y = self.target_q(next_obs, reward, not_done, noise_target)
-            q1, q2 = critic_forward(self.critic, obs, action, self.hp)
+            q1, q2 = critic_forward(self.critic, obs, action, self.hp, gates=fc("critic", 0))
             loss = self._mse2(q1, q2, y)
             log["train_critic/loss"] = float(loss.detach())
-            self.critic_opt.zero_grad()
-            loss.backward()
-            self.critic_opt.step()
+            self._critic_step(self.critic_opt, self.critic, loss, "critic_grads")
             actor_obs = obs
         elif algo == "svea":
             obs = shift(obs)
             y = self.target_q(next_obs, reward, not_done, noise_target)
-            q1, q2 = critic_forward(self.critic, obs, action, self.hp)
+            q1, q2 = critic_forward(self.critic, obs, action, self.hp, gates=fc("critic", 0))
             l_shift = self.hp["svea_alpha"] * self._mse2(q1, q2, y)
             obs_aug = aug(obs.clone())
-            q1a, q2a = critic_forward(self.critic, obs_aug, action, self.hp)
+            q1a, q2a = critic_forward(self.critic, obs_aug, action, self.hp, gates=fc("critic", 1))
             l_aug = self.hp["svea_beta"] * self._mse2(q1a, q2a, y)
             loss = l_shift + l_aug
             log.update({"train_critic/shift_loss": float(l_shift.detach()), "train_critic/aug_loss": float(l_aug.detach()),
                         "train_critic/loss": float(loss.detach())})
-            self.critic_opt.zero_grad()
-            loss.backward()
-            self.critic_opt.step()
+            self._critic_step(self.critic_opt, self.critic, loss, "critic_grads")
             actor_obs = obs
-        elif algo == "drq":  # K = M = 1 (arguments.py:66-67)
-            obs = shift(obs)
-            next_obs = shift2(next_obs)
-            y = self.target_q(next_obs, reward, not_done, noise_target)
-            q1, q2 = critic_forward(self.critic, obs, action, self.hp)
-            loss = self._mse2(q1, q2, y)
+        elif algo == "drq":
+            K, M = self.hp["drq_k"], self.hp["drq_m"]
+            shifts = list(shift) if isinstance(shift, (list, tuple)) else [shift]
+            shifts2 = list(shift2) if isinstance(shift2, (list, tuple)) else [shift2]
+            noises = list(noise_target) if isinstance(noise_target, (list, tuple)) else [noise_target]
+            assert len(shifts) == K and len(shifts2) == M and len(noises) == M
+            obs_list = [f(obs) for f in shifts]            # drq.py:69-70: all obs copies first, then next_obs copies
+            next_list = [f(next_obs) for f in shifts2]
+            y = 0
+            running = []
+            for no, nz in zip(next_list, noises):           # drq.py:23-30 (running SUM is what gets logged)
+                y = y + self.target_q(no, reward, not_done, nz)
+                running.append(y)
+            y = y / M
+            loss = 0
+            q1s, q2s = [], []
+            for ki, o in enumerate(obs_list):
+                q1, q2 = critic_forward(self.critic, o, action, self.hp, gates=fc("critic", ki))
+                loss = loss + self._mse2(q1, q2, y)
+                q1s.append(q1.detach())
+                q2s.append(q2.detach())
+            var = lambda ts: float(torch.cat(ts, dim=-1).var(dim=-1, unbiased=False).mean()) if len(ts) > 1 else 0.0  # noqa: E731
             log["train_critic/loss"] = float(loss.detach())
-            self.critic_opt.zero_grad()
-            loss.backward()
-            self.critic_opt.step()
-            actor_obs = obs
+            log[f"train_critic/target_Q_variance_m={M}"] = var(running)   # np.var: population variance (drq.py:36-51)
+            log[f"train_critic/Q1_variance_k={K}"] = var(q1s)
+            log[f"train_critic/Q2_variance_k={K}"] = var(q2s)
+            self._critic_step(self.critic_opt, self.critic, loss, "critic_grads")
+            actor_obs = obs_list[0]
         elif algo == "augcl":
             obs_shift = shift(obs)
             obs_aug = aug(obs)  # on the UN-shifted obs (augcl.py:72)
             y = self.target_q(next_obs, reward, not_done, noise_target)
-            q1, q2 = critic_forward(self.critic_weak, obs_shift, action, self.hp)
+            q1, q2 = critic_forward(self.critic_weak, obs_shift, action, self.hp, gates=fc("weak", 0))
             l_weak = self._mse2(q1, q2, y)
-            q1, q2 = critic_forward(self.critic, obs_aug, action, self.hp)
+            q1, q2 = critic_forward(self.critic, obs_aug, action, self.hp, gates=fc("critic", 0))
             l_strong = self._mse2(q1, q2, y)
             log["train_critic_weak/loss"] = float(l_weak.detach())
             log["train_critic_strong/loss"] = float(l_strong.detach())
-            self.critic_weak_opt.zero_grad()
-            l_weak.backward()
-            self.critic_weak_opt.step()
-            self.critic_opt.zero_grad()
-            l_strong.backward()
-            self.critic_opt.step()
+            self._critic_step(self.critic_weak_opt, self.critic_weak, l_weak, "weak_grads")
+            self._critic_step(self.critic_opt, self.critic, l_strong, "critic_grads")
             actor_obs = obs_aug
         else:
             raise KeyError(algo)
+        self.rec["target_Q"] = y.detach().clone()
         if step % self.hp["actor_update_freq"] == 0:
-            self.update_actor_and_alpha(actor_obs, noise_actor, log)
+            self.update_actor_and_alpha(actor_obs, noise_actor, log, forced)
         if step % self.hp["critic_target_update_freq"] == 0:
             self.soft_update_target(self.critic_weak if algo == "augcl" else None)
         return log

@@ -40,7 +40,9 @@ CASES = [  # (name, algorithm, data_aug, action_dim)
     ("svea_overlay", "svea", "overlay", 6),
     ("drq_finger", "drq", "identity", 2),              # config 3
     ("augcl_conv_cheetah", "augcl", "conv", 6),        # config 4
+    ("drq_k2m2", "drq", "identity", 2),                # DrQ with K = M = 2 (drq.py:15-65): variance logs live
 ]
+HP_OVERRIDES = {"drq_k2m2": dict(drq_k=2, drq_m=2)}
 
 
 class RecLogger:
@@ -95,7 +97,8 @@ def main(_what="all"):
 
     def run_case(ci, name, algo, data_aug, A, seed):
         res = {}
-        hp = dict(so.DEFAULTS)
+        hp = dict(so.DEFAULTS, **HP_OVERRIDES.get(name, {}))
+        K, M = hp["drq_k"], hp["drq_m"]
         args = ref_utils.dotdict(algorithm=algo, data_aug=data_aug, aug_params=None, **hp)
         actor_state = so.synth_state(seed, so.actor_shapes(OBS, A, hp))
         critic_state = so.synth_state(seed + 1000, so.critic_shapes(OBS, A, hp))
@@ -129,10 +132,17 @@ def main(_what="all"):
         ref_aug._get_data_batch = lambda batch_size: ov_imgs.clone()
 
         noise_rs = np.random.RandomState(seed + 3)
-        noises = [torch.from_numpy(noise_rs.standard_normal((B, A)).astype(np.float32)) for _ in range(2 * K_STEPS)]
+        n_noise = (M + 1) * K_STEPS if algo == "drq" else 2 * K_STEPS  # one actor call per next_obs copy + the actor update
+        noises = [torch.from_numpy(noise_rs.standard_normal((B, A)).astype(np.float32)) for _ in range(n_noise)]
         queue = list(noises)
         torch.randn_like = lambda t, *a, **k: queue.pop(0).clone()
-        used_noise, oys, oxs, oys2, oxs2, cws, qs = [], [], [], [], [], [], []
+        used_noise, oys, oxs, oys2, oxs2, cws, qs, all_draws = [], [], [], [], [], [], [], []
+        # On a GPU `t.cpu()` COPIES; here everything already lives on the CPU, where it returns `t` itself and
+        # `.numpy()` then aliases it -- drq.py:29-33 keeps such views of target_Q and goes on modifying it in place,
+        # so the variance it logs would be computed from aliased (all equal) arrays.  Restore device semantics.
+        real_cpu = torch.Tensor.cpu
+        if algo == "drq" and (K > 1 or M > 1):
+            torch.Tensor.cpu = lambda self, *a, **k: self.clone()
         try:
             for s in range(K_STEPS):
                 step = FIRST_STEP + s
@@ -147,7 +157,14 @@ def main(_what="all"):
                 if uses_shift:
                     oy = torch.randint(0, 9, (B,)).numpy().astype(np.int32)
                     ox = torch.randint(0, 9, (B,)).numpy().astype(np.int32)
-                if algo == "drq" or (algo == "rad" and data_aug == "shift"):
+                if algo == "drq" and (K > 1 or M > 1):
+                    # K draws for obs (the first was replayed above), then M for next_obs: (K+M, 2, B)
+                    draws = [(oy, ox)] + [(torch.randint(0, 9, (B,)).numpy().astype(np.int32),
+                                           torch.randint(0, 9, (B,)).numpy().astype(np.int32)) for _ in range(K + M - 1)]
+                    assert np.array_equal(RandomCrop.last[0], draws[-1][0]) and np.array_equal(RandomCrop.last[1], draws[-1][1])
+                    oy2, ox2 = draws[K]
+                    all_draws.append(np.array(draws))
+                elif algo == "drq" or (algo == "rad" and data_aug == "shift"):
                     oy2 = torch.randint(0, 9, (B,)).numpy().astype(np.int32)
                     ox2 = torch.randint(0, 9, (B,)).numpy().astype(np.int32)
                     assert np.array_equal(RandomCrop.last[0], oy2) and np.array_equal(RandomCrop.last[1], ox2)
@@ -165,6 +182,7 @@ def main(_what="all"):
                 qs.append(np.stack([q1.numpy().ravel(), q2.numpy().ravel()]))
         finally:
             torch.randn_like = real_randn_like
+            torch.Tensor.cpu = real_cpu
             gm.close()
         keys = sorted({k for (_, k) in L.rows})
         logs = np.full((K_STEPS, len(keys)), np.nan)
@@ -180,6 +198,8 @@ def main(_what="all"):
         res[pre + "oy2"], res[pre + "ox2"] = np.stack(oys2), np.stack(oxs2)
         if data_aug == "conv":
             res[pre + "conv_w"] = np.stack(cws)
+        if all_draws:
+            res[pre + "shift_draws"] = np.stack(all_draws)  # (steps, K+M, 2, B)
         res[pre + "q_after"] = np.stack(qs)
         cn = list(so.critic_shapes(OBS, A, hp).keys())
         an = list(so.actor_shapes(OBS, A, hp).keys())

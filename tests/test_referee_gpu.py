@@ -1,0 +1,485 @@
+"""GPU parity where training actually runs: BASELINE's batch sizes (256 / 512 / 1024), the reference's real initial
+state (delta-orthogonal convs, zero bias: src/algorithms/modules.py:52-66) and He-scaled weights -- NOT the gate-safe
+nets of the golden fixtures -- with a float64 referee.
+
+Three evaluations of the same computation: `f64` (oracle/sac_oracle.py run in float64 = the referee), `cpu32` (the same
+oracle in float32 = what the reference computes on a CPU) and `hip` (the product).  Criterion (the one
+tests/test_heads_gpu.py uses for the fused heads): the HIP path must be as close to the referee as the float32 oracle is.
+
+ReLU's gradient is discontinuous at 0, so two correct float32 evaluations can gate a pre-activation that sits within
+rounding of zero differently; one such flip moves the weight gradients below it by ~1/sqrt(#pixels).  The encoder tests
+therefore ALSO (a) locate every gate that differs between HIP and the referee and require its referee pre-activation
+to be ~0, (b) run the HIP backward on the referee's activations and (c) run the referee with HIP's gates forced: with
+identical gates the HIP gradients must match float64 to <= 1e-5 -- the residual is gates and nothing else.
+Results are also written to gpurun_out/referee_*.json when that directory exists."""
+import json
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import test_oracle_golden_sac as T
+from augcl_amd import _lib, encoder_hip, encoder_ops
+from augcl_amd import augmentations as aug
+from augcl_amd import utils as au
+from augcl_amd.algorithms import make_agent
+from oracle import sac_oracle as so
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OBS = T.OBS
+STRICT = 1e-5  # north_star tolerance
+
+
+def rel_l2(a, b):
+    a, b = a.detach().double().cpu().flatten(), b.detach().double().cpu().flatten()
+    return float((a - b).norm() / b.norm().clamp_min(1e-300))
+
+
+def pooled(pairs):
+    """relative L2 over a group of tensors taken as one vector"""
+    num = sum(float((a.detach().double().cpu() - b.detach().double().cpu()).square().sum()) for a, b in pairs)
+    den = sum(float(b.detach().double().cpu().square().sum()) for _, b in pairs)
+    return (num / max(den, 1e-300)) ** 0.5
+
+
+def dump(name, obj):
+    d = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(d):
+        with open(os.path.join(d, f"referee_{name}.json"), "w") as f:
+            json.dump(obj, f, indent=1)
+
+
+_REF_DEV = {}
+
+
+def ref_device(cuda):
+    """Where the float64 referee runs: the GPU's f64 units through plain ATen ops when this torch build has a double
+    convolution there (seconds instead of minutes at B=1024), else the host.  Independent of augcl_amd either way."""
+    if "dev" not in _REF_DEV:
+        try:
+            x = torch.randn(2, 4, 9, 9, dtype=torch.float64, device=cuda, requires_grad=True)
+            w = torch.randn(5, 4, 3, 3, dtype=torch.float64, device=cuda, requires_grad=True)
+            y = F.conv2d(x, w, stride=2)
+            y.sum().backward()
+            ok = torch.allclose(y.detach().cpu(), F.conv2d(x.detach().cpu(), w.detach().cpu(), stride=2), rtol=1e-12, atol=1e-12)
+            _REF_DEV["dev"] = cuda if ok else torch.device("cpu")
+        except Exception:  # noqa: BLE001
+            _REF_DEV["dev"] = torch.device("cpu")
+    return _REF_DEV["dev"]
+
+
+def make_states(init, A, seed):
+    hp = dict(so.DEFAULTS)
+    mk = (lambda s, shp: so.synth_state(s, shp, gate_safe=False)) if init == "he" else so.real_init_state
+    cs = mk(seed, so.critic_shapes(OBS, A, hp))
+    as_ = mk(seed + 1, so.actor_shapes(OBS, A, hp))
+    for k in cs:
+        if so.is_cnn(k):
+            as_[k] = cs[k]
+    return as_, cs
+
+
+# ------------------------------------------------------------------------------------------------ encoder
+class _Gated(torch.autograd.Function):
+    """ReLU with the gate given from outside: y = z * gate, dz = dy * gate."""
+
+    @staticmethod
+    def forward(ctx, z, gate):
+        ctx.save_for_backward(gate)
+        return z * gate
+
+    @staticmethod
+    def backward(ctx, g):
+        (gate,) = ctx.saved_tensors
+        return g * gate, None
+
+
+def ref_stack(x, ws, bs, gates=None):
+    """x/255 -> conv s2 -> [ReLU -> conv]*; returns (output, pre-activations of every ReLU)."""
+    h = x / 255.0
+    pre = []
+    for i, (w, b) in enumerate(zip(ws, bs)):
+        if i:
+            pre.append(h)
+            h = torch.relu(h) if gates is None else _Gated.apply(h, gates[i - 1].to(h.dtype))
+        h = F.conv2d(h, w, b, stride=2 if i == 0 else 1)
+    return h, pre
+
+
+def ref_run(x, ws, bs, gout, dtype, gates=None, device="cpu"):
+    to = lambda t: t.to(device=device, dtype=dtype)  # noqa: E731
+    w = [to(t).clone().requires_grad_(True) for t in ws]
+    b = [to(t).clone().requires_grad_(True) for t in bs]
+    out, pre = ref_stack(to(x), w, b, None if gates is None else [g.to(device) for g in gates])
+    (out * to(gout)).sum().backward()
+    c = lambda t: t.detach().cpu()  # noqa: E731
+    return c(out), [c(t) for t in pre], [c(t.grad) for t in w], [c(t.grad) for t in b]
+
+
+def _ptrs(ts):
+    return (_lib.ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+
+
+def hip_forward(x, ws, bs):
+    """augcl_enc_stack_forward through the C ABI; returns the output of every layer (post-ReLU but the last)."""
+    B, C, H, W = x.shape
+    n = len(ws)
+    hs = [(H - 3) // 2 + 1]
+    for _ in range(1, n):
+        hs.append(hs[-1] - 2)
+    acts = [torch.empty((B, 32, h, h), dtype=torch.float32, device=x.device) for h in hs]
+    _lib.call("augcl_enc_stack_forward", x.data_ptr(), _ptrs(ws), _ptrs(bs), _ptrs(acts), n, B, C, H, W, 2, 255.0, 0,
+              _lib.current_stream(x.device))
+    return acts
+
+
+def hip_backward(x, acts_in, ws, gout):
+    """augcl_enc_stack_backward through the C ABI on GIVEN layer inputs (acts_in[0] = x raw, then post-ReLU maps)."""
+    B, C, H, W = x.shape
+    n = len(ws)
+    dev = x.device
+    dws = [torch.empty_like(w) for w in ws]
+    dbs = [torch.empty(32, dtype=torch.float32, device=dev) for _ in ws]
+    big = (max(t.numel() for t in acts_in[1:]) + 7) // 8 * 8
+    dz = torch.empty(2 * big, dtype=torch.float32, device=dev)
+    ws32, wsf = encoder_hip._workspace(dev, 32, max(1, n - 1)), encoder_hip._workspace(dev, C)
+    _lib.call("augcl_enc_stack_backward", _ptrs(acts_in), _ptrs(ws), gout.data_ptr(), _ptrs(dws), _ptrs(dbs), dz.data_ptr(),
+              dz.data_ptr() + 4 * big, ws32.data_ptr(), ws32.numel() * 4, wsf.data_ptr(), wsf.numel() * 4, n, B, C, H, W, 2,
+              255.0, 0, 0, _lib.current_stream(dev))
+    return dws, dbs
+
+
+@pytest.mark.parametrize("B,init", [(8, "he"), (8, "delta"), (256, "he"), (256, "delta"), (512, "he")])
+def test_encoder_against_f64_referee(cuda, B, init):
+    t0 = time.time()
+    _, cs = make_states(init, 6, 11)
+    ids = so.conv_layer_ids(11)
+    ws = [cs[f"encoder.shared_cnn.layers.{i}.weight"] for i in ids]
+    bs = [cs[f"encoder.shared_cnn.layers.{i}.bias"] for i in ids]
+    rs = np.random.RandomState(1000 + B)
+    x = torch.from_numpy(rs.randint(0, 256, (B, 9, 84, 84)).astype(np.float32))
+    gout = torch.from_numpy(rs.standard_normal((B, 32, 21, 21)).astype(np.float32))
+
+    rdev = ref_device(cuda)
+    out64, pre64, dw64, db64 = ref_run(x, ws, bs, gout, torch.float64, device=rdev)
+    out32, pre32, dw32, db32 = ref_run(x, ws, bs, gout, torch.float32)
+
+    xd, gd = x.to(cuda), gout.to(cuda)
+    wd, bd = [w.to(cuda) for w in ws], [b.to(cuda) for b in bs]
+    acts = hip_forward(xd, wd, bd)
+    rep = {"B": B, "init": init, "referee_device": str(rdev)}
+
+    # (1) forward: continuous, so the plain criterion applies
+    e_hip, e_cpu = rel_l2(acts[-1], out64), rel_l2(out32, out64)
+    rep["fwd"] = {"hip": e_hip, "cpu32": e_cpu}
+    assert e_hip <= max(2.0 * e_cpu, 1e-6), rep["fwd"]
+
+    # (2) gates: HIP stores post-ReLU maps; a gate differs from the referee's only where the referee's
+    #     pre-activation is ~0 (relative to the layer's rms), and only a handful do
+    gates_hip, flips, worst = [], 0, 0.0
+    for a, z in zip(acts[:-1], pre64):
+        g = (a > 0).cpu()
+        gates_hip.append(g)
+        diff = g != (z > 0)
+        n = int(diff.sum())
+        flips += n
+        if n:
+            worst = max(worst, float(z[diff].abs().max() / z.square().mean().sqrt()))
+    n_pre = sum(z.numel() for z in pre64)
+    flips_cpu = sum(int(((a > 0) != (z > 0)).sum()) for a, z in zip(pre32, pre64))
+    rep["gates"] = {"differ": flips, "of": n_pre, "max_|z|/rms_at_differing": worst, "cpu32_differ": flips_cpu}
+    assert worst <= 1e-5 and flips <= 5e-6 * n_pre + 10, rep["gates"]
+
+    # (3) HIP backward on the REFEREE's activations (identical gates): pure arithmetic, must be <= 1e-5
+    acts_ref = [xd] + [torch.relu(z).float().to(cuda) for z in pre64]
+    dws, dbs = hip_backward(xd, acts_ref, wd, gd)
+    torch.cuda.synchronize()
+    rep["bwd_referee_gates"] = {"dW": [rel_l2(a, b) for a, b in zip(dws, dw64)], "db": [rel_l2(a, b) for a, b in zip(dbs, db64)]}
+    assert max(rep["bwd_referee_gates"]["dW"] + rep["bwd_referee_gates"]["db"]) <= STRICT, rep["bwd_referee_gates"]
+
+    # (4) the product path (one autograd node, its own gates) against the referee run with HIP's gates forced
+    wg = [w.clone().requires_grad_(True) for w in wd]
+    bg = [b.clone().requires_grad_(True) for b in bd]
+    out = encoder_ops.conv_stack(xd, wg, bg, first_stride=2, input_scale=255.0)
+    (out * gd).sum().backward()
+    torch.cuda.synchronize()
+    assert torch.equal(out.detach(), acts[-1])
+    _, _, dw64g, db64g = ref_run(x, ws, bs, gout, torch.float64, gates=gates_hip, device=rdev)
+    rep["bwd_hip_gates_forced"] = {"dW": [rel_l2(a.grad, b) for a, b in zip(wg, dw64g)],
+                                   "db": [rel_l2(a.grad, b) for a, b in zip(bg, db64g)]}
+    assert max(rep["bwd_hip_gates_forced"]["dW"] + rep["bwd_hip_gates_forced"]["db"]) <= STRICT, rep["bwd_hip_gates_forced"]
+
+    # (5) un-forced: both float32 evaluations against the referee, per layer and pooled over the stack
+    rep["bwd_free"] = {"hip_dW": [rel_l2(a.grad, b) for a, b in zip(wg, dw64)], "cpu32_dW": [rel_l2(a, b) for a, b in zip(dw32, dw64)],
+                       "hip_pooled": pooled([(a.grad, b) for a, b in zip(wg + bg, dw64 + db64)]),
+                       "cpu32_pooled": pooled(list(zip(dw32 + db32, dw64 + db64)))}
+    rep["seconds"] = time.time() - t0
+    dump(f"encoder_B{B}_{init}", rep)
+    # The plain criterion only means something when BOTH float32 evaluations crossed a fair number of near-zero gates
+    # (each differing gate is a discrete ~1/sqrt(#pixels) event; with 3 on one side and 0 on the other -- B=256 on the
+    # reference's own init -- the ratio says nothing, and (3)/(4) above are the rigorous statement).
+    if min(flips, flips_cpu) >= 5:
+        assert rep["bwd_free"]["hip_pooled"] <= 2.0 * rep["bwd_free"]["cpu32_pooled"] + 1e-6, rep["bwd_free"]
+    assert rep["bwd_free"]["hip_pooled"] <= 1e-2, rep["bwd_free"]
+
+
+# ------------------------------------------------------------------------------------------------ update()
+class RecLogger:
+    def __init__(self):
+        self.rows = {}
+
+    def log(self, key, value, step, n=1):
+        self.rows[key] = float(value.item() if torch.is_tensor(value) else value)
+
+
+CASES = [  # (algo, data_aug, A, B, hp overrides): BASELINE configs 2, 3, 4 (config 4's global batch on one GPU) + DrQ K=M=2
+    ("svea", "conv", 6, 256, {}),
+    ("drq", "identity", 2, 512, {}),
+    ("augcl", "conv-overlay", 6, 1024, {}),
+    ("drq", "identity", 2, 128, dict(drq_k=2, drq_m=2)),
+]
+
+
+def group_of(name):
+    if so.is_cnn(name):
+        return "cnn"
+    if "projection" in name:
+        return "projection"
+    return name.split(".")[0]  # Q1 / Q2 / mlp
+
+
+class GateRecorder:
+    """Forward hooks on the nn.ReLU modules of the product's MLP heads: the on/off decision of every call, in order."""
+
+    def __init__(self):
+        self.calls, self.handles = {}, []
+
+    def watch(self, tag, seq):
+        for i, mod in enumerate(m for m in seq if isinstance(m, torch.nn.ReLU)):
+            self.handles.append(mod.register_forward_hook(
+                lambda _m, _inp, out, key=(tag, i): self.calls.setdefault(key, []).append((out > 0).cpu())))
+
+    def close(self):
+        for h in self.handles:
+            h.remove()
+
+
+@pytest.mark.parametrize("init", ["he", "delta"])
+@pytest.mark.parametrize("algo,data_aug,A,B,hpo", CASES)
+def test_update_against_f64_referee(cuda, monkeypatch, algo, data_aug, A, B, hpo, init):
+    """One full update() (critic, actor + alpha, target EMA) at the configs' batch sizes, on real-init / He-scaled nets.
+    The referee is run twice: FREE (its own ReLU gates) -- reported next to the float32 oracle's deviation, which shows
+    how far two correct float32 evaluations drift apart through a handful of near-zero gates -- and with the gates of
+    the HIP run FORCED, where every logged loss, every gradient tensor and the target network must agree to 1e-5."""
+    t0 = time.time()
+    hp = dict(so.DEFAULTS, **hpo)
+    K, M = (hp["drq_k"], hp["drq_m"]) if algo == "drq" else (1, 1)
+    as_, cs = make_states(init, A, 21)
+    rs = np.random.RandomState(B + A)
+    obs = rs.randint(0, 256, (B, *OBS)).astype(np.float32)
+    nobs = rs.randint(0, 256, (B, *OBS)).astype(np.float32)
+    act = rs.uniform(-1, 1, (B, A)).astype(np.float32)
+    rew = rs.uniform(0, 4, (B, 1)).astype(np.float32)
+    nd = np.ones((B, 1), np.float32)
+    noises = [torch.from_numpy(rs.standard_normal((B, A)).astype(np.float32)) for _ in range(M + 1)]
+    draws = [(rs.randint(0, 9, B).astype(np.int32), rs.randint(0, 9, B).astype(np.int32)) for _ in range(K + M)]
+    cw = rs.standard_normal((B, 3, 3, 3, 3)).astype(np.float32)
+    ov = rs.random_sample((B, 3, 84, 84)).astype(np.float32)
+    tt = torch.from_numpy
+    d_obs, d_nobs = tt(obs).to(cuda), tt(nobs).to(cuda)
+
+    # the augmented batches are produced ONCE by the HIP operators (they have their own parity tests) and handed to
+    # every evaluation, so that what is compared is the update and nothing else
+    def strong(x):
+        for k in data_aug.split("-"):
+            if k == "conv":
+                x = aug.random_conv(x, weights=cw)
+            elif k == "overlay":
+                x = aug.random_overlay(x, imgs=tt(ov).to(cuda))
+        return x
+
+    shifted = [aug.random_shift(d_obs, oy=oy, ox=ox) for oy, ox in draws[:K]]
+    shifted_next = [aug.random_shift(d_nobs, oy=oy, ox=ox) for oy, ox in draws[K:]] if algo == "drq" else []
+    strong_d = strong(shifted[0]) if algo == "svea" else strong(d_obs) if algo == "augcl" else None  # augcl.py:72: un-shifted
+    torch.cuda.synchronize()
+    # inputs of the gradient-carrying critic passes, in the oracle's order
+    critic_inputs = {"svea": [shifted[0], strong_d], "drq": shifted, "augcl": [strong_d]}[algo]
+    weak_inputs = [shifted[0]] if algo == "augcl" else []
+    rdev = ref_device(cuda)
+
+    def oracle_run(dtype, forced=None):
+        dev = rdev if dtype == torch.float64 else torch.device("cpu")
+        c = lambda t: t.detach().to(device=dev, dtype=dtype)  # noqa: E731
+        mk = lambda t: (lambda x: c(t))  # noqa: E731
+        if algo == "drq":
+            kw = dict(shift=[mk(t) for t in shifted], shift2=[mk(t) for t in shifted_next])
+        else:
+            kw = dict(shift=mk(shifted[0]), aug=mk(strong_d))
+        ag = so.OracleAgent(algo, OBS, A, as_, cs, hp=hp, dtype=dtype, device=dev)
+        batch = tuple(c(tt(v)) for v in (obs, act, rew, nobs, nd))
+        nt = [c(n) for n in noises[:M]]
+        log = ag.update(batch, 0, nt if algo == "drq" and M > 1 else nt[0], c(noises[M]), forced=forced, **kw)
+        for d in (ag.critic, ag.actor, ag.critic_target, getattr(ag, "critic_weak", {})):  # results back on the host
+            for k in d:
+                d[k] = d[k].detach().cpu()
+        ag.rec = {k: ({n: t.cpu() for n, t in v.items()} if isinstance(v, dict) else v.cpu()) for k, v in ag.rec.items()}
+        return ag, log
+
+    # ---- the product
+    args = au.dotdict(algorithm=algo, data_aug=data_aug, aug_params=None, **hp)
+
+    def load(agent):
+        csd = {k: v.to(cuda) for k, v in cs.items()}
+        agent.critic.load_state_dict(csd)
+        agent.actor.load_state_dict({k: (csd[k] if so.is_cnn(k) else v.to(cuda)) for k, v in as_.items()})
+        agent.critic_target.load_state_dict(csd)
+        return agent
+
+    if algo == "augcl":
+        agent = make_agent(OBS, (A,), args)
+        agent.load_pretrained_agent(load(make_agent(OBS, (A,), au.dotdict(dict(args, algorithm="non_naive_rad", data_aug="shift")))))
+    else:
+        agent = load(make_agent(OBS, (A,), args))
+    agent.fuse_front_end = False
+
+    # gates of the HIP run, CNN part: the encoder forward through the C ABI on the very tensors update() will see
+    # (per-image results do not depend on how images are batched -- checked below against the features update() used)
+    ids = so.conv_layer_ids(11)
+    cnn_w = [cs[f"encoder.shared_cnn.layers.{i}.weight"].to(cuda) for i in ids]
+    cnn_b = [cs[f"encoder.shared_cnn.layers.{i}.bias"].to(cuda) for i in ids]
+
+    def cnn_gates(x):
+        acts = hip_forward(x, cnn_w, cnn_b)
+        return [(a > 0).cpu() for a in acts[:-1]], acts[-1]
+
+    crit_cnn = [cnn_gates(x) for x in critic_inputs]
+    weak_cnn = [cnn_gates(x) for x in weak_inputs]
+    seen_feat = []
+    watched = [agent.critic.encoder.shared_cnn] + ([agent.critic_weak.encoder.shared_cnn] if algo == "augcl" else [])
+    hooks = [mod.register_forward_hook(lambda _m, _i, out: seen_feat.append(out.detach())) for mod in watched]
+    rec = GateRecorder()
+    rec.watch("Q1", agent.critic.Q1.trunk)
+    rec.watch("Q2", agent.critic.Q2.trunk)
+    rec.watch("mlp", agent.actor.mlp)
+    if algo == "augcl":
+        rec.watch("wQ1", agent.critic_weak.Q1.trunk)
+        rec.watch("wQ2", agent.critic_weak.Q2.trunk)
+
+    calls = {"shift": 0}
+
+    def shift_given(x, pad=4, **kw):
+        i = calls["shift"]
+        calls["shift"] += 1
+        return (shifted + shifted_next)[i].clone()
+
+    import augcl_amd.algorithms.augcl as m_augcl
+    import augcl_amd.algorithms.drq as m_drq
+    import augcl_amd.algorithms.svea as m_svea
+    for mod in (m_svea, m_drq, m_augcl):
+        monkeypatch.setattr(mod.augmentations, "random_shift", shift_given)
+    if hasattr(agent, "aug_funcs"):
+        keys = list(agent.aug_funcs)
+        for k in keys:
+            agent.aug_funcs[k]["func"] = (lambda x, **kw: strong_d.clone()) if k == keys[0] else (lambda x, **kw: x)
+    queue = [n.to(cuda) for n in noises]
+    monkeypatch.setattr(torch, "randn_like", lambda t, *a, **k: queue.pop(0).clone())
+    before = {"critic": agent.critic_group.param.clone(), "actor": agent.actor_group.param.clone()}
+    if algo == "augcl":
+        before["weak"] = agent._weak_group.param.clone()
+
+    class Buf:
+        def sample(self, n=None, idxs=None):
+            return d_obs.clone(), tt(act).to(cuda), tt(rew).to(cuda), d_nobs.clone(), tt(nd).to(cuda)
+
+    L = RecLogger()
+    agent.update(Buf(), L, 0)
+    torch.cuda.synchronize()
+    rec.close()
+    for h in hooks:
+        h.remove()
+    assert not queue
+
+    # the features update() computed are the ones the gates were taken from (bit for bit)
+    want_feats = ([f for _, f in weak_cnn] if algo == "augcl" else []) + [f for _, f in crit_cnn]
+    got = torch.cat([f.reshape(-1, 32, 21, 21) for f in seen_feat])[:sum(f.shape[0] for f in want_feats)]
+    assert torch.equal(got, torch.cat(want_feats)), "encoder features inside update() differ from the C-ABI forward"
+
+    # assemble the gate sets per oracle pass
+    def head_gates(tag, call, rows=None):
+        g = [rec.calls[(tag, i)][call] for i in (0, 1)]
+        return g if rows is None else [t[rows[0]:rows[1]] for t in g]
+
+    n_pass = len(critic_inputs)
+    forced = {"critic": [], "actor": {"mlp": [rec.calls[("mlp", i)][-1] for i in (0, 1)]}}
+    one_call = algo == "svea"  # SVEA's two halves go through the critic as ONE 2B batch
+    for k in range(n_pass):
+        rows = (k * B, (k + 1) * B) if one_call else None
+        call = 0 if one_call else k
+        forced["critic"].append({"cnn": crit_cnn[k][0], "Q1": head_gates("Q1", call, rows), "Q2": head_gates("Q2", call, rows)})
+    forced["actor_q"] = {"Q1": head_gates("Q1", -1), "Q2": head_gates("Q2", -1)}
+    if algo == "augcl":
+        forced["weak"] = [{"cnn": weak_cnn[0][0], "Q1": head_gates("wQ1", 0), "Q2": head_gates("wQ2", 0)}]
+
+    ref_free, log_free = oracle_run(torch.float64)
+    o32, log32 = oracle_run(torch.float32)
+    ref, log64 = oracle_run(torch.float64, forced=forced)
+
+    rep = {"algo": algo, "B": B, "init": init, "hp": hpo, "referee_device": str(rdev), "logs": {}, "tensors": {}, "groups": {}}
+    # ---- every logged quantity against the gate-forced referee
+    for k, want in log64.items():
+        got_v = L.rows[k]
+        scale = max(1.0, abs(want)) + (T.ENT_CONST(A) if k.endswith("mean_entropy") else 0.0)
+        rep["logs"][k] = {"f64_forced": want, "hip": got_v, "f64_free": log_free[k], "cpu32": log32[k]}
+        # 1e-5, or -- for a loss that is itself a cancelling float32 sum, where the float32 oracle sits 1e-5 from its
+        # own float64 twin -- as close as that oracle gets
+        assert abs(got_v - want) <= max(STRICT * scale, 2.0 * abs(log32[k] - log_free[k])), (k, rep["logs"][k])
+
+    # ---- gradients per tensor; Adam's step from HIP's own gradient
+    def collect(group, rec_key, tag, lr):
+        rows = []
+        for n in group.names:
+            a, b = group.slices[n]
+            g64 = ref.rec[rec_key].get(n)
+            if g64 is None:
+                continue
+            g_hip = group.grad[a:b].view(group.shapes[n]).cpu()
+            d_hip = (group.param[a:b] - before[tag][a:b]).view(group.shapes[n]).cpu()
+            # Adam, free of gate noise: the parameter step must be Adam's first step of HIP's own gradient
+            g = g_hip.double()
+            want_step = -lr * g / (g.abs() + 1e-8)
+            p_before = before[tag][a:b].view(group.shapes[n]).cpu().double()  # d_hip = fl(p_after) - p_before: 1 ulp of p
+            assert bool(((d_hip.double() - want_step).abs() <= 4e-6 * lr + 1.2e-7 * p_before.abs()).all()), (tag, n)
+            rows.append((tag, n, g_hip, g64, ref_free.rec[rec_key][n], o32.rec[rec_key][n]))
+        return rows
+
+    rows = collect(agent.critic_group, "critic_grads", "critic", hp["critic_lr"])
+    rows += collect(agent.actor_group, "actor_grads", "actor", hp["actor_lr"])
+    if algo == "augcl":
+        rows += collect(agent._weak_group, "weak_grads", "weak", hp["critic_lr"])
+    groups = {}
+    worst = (0.0, None)
+    for tag, n, g_hip, g64, g_free, g32 in rows:
+        e = rel_l2(g_hip, g64)
+        rep["tensors"][f"{tag}/{n}"] = {"hip_vs_forced": e, "hip_vs_free": rel_l2(g_hip, g_free), "cpu32_vs_free": rel_l2(g32, g_free)}
+        groups.setdefault(f"{tag}/{group_of(n)}", []).append((g_hip, g64, g_free, g32))
+        worst = max(worst, (e, f"{tag}/{n}"))
+    for gname, items in groups.items():
+        rep["groups"][gname] = {"hip_vs_forced": pooled([(i[0], i[1]) for i in items]), "hip_vs_free": pooled([(i[0], i[2]) for i in items]),
+                                "cpu32_vs_free": pooled([(i[3], i[2]) for i in items])}
+    rep["worst_gradient_vs_forced_referee"] = worst
+    # ---- target network after the EMA, log_alpha (float64 scalar)
+    tg = agent.target_group
+    pairs = [(tg.param[tg.slices[n][0]:tg.slices[n][1]].view(tg.shapes[n]).cpu(), ref.critic_target[n]) for n in tg.names]
+    rep["target_vs_forced"] = pooled(pairs)
+    rep["log_alpha"] = {"hip": float(agent.log_alpha.detach()), "f64_forced": float(ref.log_alpha.detach())}
+    rep["seconds"] = time.time() - t0
+    dump(f"update_{algo}_{data_aug}_B{B}_k{K}m{M}_{init}", rep)
+    assert worst[0] <= STRICT, worst
+    assert rep["target_vs_forced"] <= STRICT, rep["target_vs_forced"]
+    assert abs(rep["log_alpha"]["hip"] - rep["log_alpha"]["f64_forced"]) <= 1e-7 * abs(rep["log_alpha"]["f64_forced"]), rep["log_alpha"]
+    # sanity bound on the un-forced comparison (gate noise included): both float32 evaluations stay within 1e-2
+    assert max(g["hip_vs_free"] for g in rep["groups"].values()) <= 1e-2, rep["groups"]

@@ -35,8 +35,8 @@ class FakeBuffer:
         return tuple(t.clone() for t in self.batch)
 
 
-def build_agent(algo, data_aug, A, actor_state, critic_state, cuda):
-    args = au.dotdict(algorithm=algo, data_aug=data_aug, aug_params=None, **so.DEFAULTS)
+def build_agent(algo, data_aug, A, actor_state, critic_state, cuda, hp=None):
+    args = au.dotdict(algorithm=algo, data_aug=data_aug, aug_params=None, **(hp or so.DEFAULTS))
 
     def load(agent):
         cs = {k: v.to(cuda) for k, v in critic_state.items()}
@@ -58,7 +58,7 @@ def build_agent(algo, data_aug, A, actor_state, critic_state, cuda):
 def test_update_matches_reference_golden(cuda, monkeypatch, name, algo, data_aug, A, ci):
     G = np.load(os.path.join(ROOT, "tests", "golden", "sac_golden.npz"))
     actor_state, critic_state, batch, noises, ov = T.make_case(name, algo, data_aug, A, ci)
-    agent = build_agent(algo, data_aug, A, actor_state, critic_state, cuda)
+    agent = build_agent(algo, data_aug, A, actor_state, critic_state, cuda, hp=T.case_hp(name))
     agent.fuse_front_end = False  # explicit parameters go through the un-fused ops (fused == chain is tested elsewhere)
     dbatch = tuple(t.to(cuda) for t in batch)
     buf, L = FakeBuffer(dbatch), RecLogger()
@@ -71,6 +71,10 @@ def test_update_matches_reference_golden(cuda, monkeypatch, name, algo, data_aug
 
     def shift_explicit(x, pad=4, **kw):
         s = state["s"]
+        if f"{name}/shift_draws" in G.files:  # DrQ K, M > 1: K draws for obs, then M for next_obs, in call order
+            oy, ox = G[f"{name}/shift_draws"][s][state["shift_calls"]]
+            state["shift_calls"] += 1
+            return real_shift(x, pad, oy=oy, ox=ox)
         second = state["shift_calls"] == 1 and (algo == "drq" or (algo == "rad" and data_aug == "shift"))
         state["shift_calls"] += 1
         oy = G[f"{name}/oy2" if second else f"{name}/oy"][s]
@@ -99,10 +103,12 @@ def test_update_matches_reference_golden(cuda, monkeypatch, name, algo, data_aug
         agent.update(buf, L, step)
         tol = RTOL0 if s == 0 else RTOL_TRAJ
         for j, k in enumerate(keys):
-            if np.isnan(want[s, j]) or "variance" in k:
+            if np.isnan(want[s, j]):
                 continue
             got = L.rows[(step, k)]
             atol = tol * (T.ENT_CONST(A) + abs(want[s, j])) if k.endswith("mean_entropy") else tol
+            if "variance" in k:  # drq.py:36-61 (population variance over the K / M copies; ~0 on these nets for K)
+                atol = max(atol * abs(want[s, j]), T.variance_atol(want[s, j]))
             assert got == pytest.approx(want[s, j], rel=tol, abs=atol), (s, k)
         with torch.no_grad():
             q1, q2 = agent.critic(dbatch[0], dbatch[1])
@@ -114,6 +120,40 @@ def test_update_matches_reference_golden(cuda, monkeypatch, name, algo, data_aug
         got = so.checksum({k: v.detach().cpu() for k, v in net.named_parameters()}, cn)
         np.testing.assert_allclose(got[:, 1], G[f"{name}/{ck}"][:, 1], rtol=2e-5)
     assert float(agent.log_alpha) == pytest.approx(float(G[f"{name}/log_alpha"][0]), rel=1e-7)
+
+
+def test_networks_match_reference_golden(cuda, monkeypatch):
+    """Module-level goldens minted from the reference's own Critic / Actor (make_golden_sac.py, `nets/*`): Q1, Q2, the
+    critic's parameter gradients, and the actor's (mu, pi, log_pi, log_std), against the HIP agent's modules -- HIP
+    encoder forward AND backward, fused LN+tanh, fused Gaussian head.  (`nets/dx`, the gradient with respect to the
+    image, has no counterpart: nothing on the update path differentiates with respect to pixels.)"""
+    import inputs as gi
+    G = np.load(os.path.join(ROOT, "tests", "golden", "sac_golden.npz"))
+    A, hp = 6, dict(so.DEFAULTS)
+    cs = so.synth_state(31, so.critic_shapes(T.OBS, A, hp))
+    as_ = so.synth_state(32, so.actor_shapes(T.OBS, A, hp))
+    agent = build_agent("sac", "identity", A, as_, cs, cuda)
+    ob, ac, _, _, _ = gi.transition_batch(33, 3, A)
+    x = torch.from_numpy(ob.astype(np.float32)).to(cuda)
+    a = torch.from_numpy(ac).to(cuda)
+    q1, q2 = agent.critic(x, a)
+    (q1.sum() + 2.0 * q2.sum()).backward()
+    np.testing.assert_allclose(q1.detach().cpu().numpy(), G["nets/q1"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(q2.detach().cpu().numpy(), G["nets/q2"], rtol=1e-5, atol=1e-6)
+    names = list(so.critic_shapes(T.OBS, A, hp).keys())
+    got = so.checksum({n: p.grad.cpu() for n, p in agent.critic.named_parameters()}, names)
+    want = G["nets/critic_grad_ck"]
+    np.testing.assert_allclose(got[:, 1], want[:, 1], rtol=1e-5)                # abs-sum of every gradient tensor
+    shapes = so.critic_shapes(T.OBS, A, hp)
+    for n, g_row, w_row in zip(names, got, want):                               # first values, on the tensor's own scale
+        scale = max(np.abs(w_row[2:]).max(), w_row[1] / int(np.prod(shapes[n])))
+        np.testing.assert_allclose(g_row[2:], w_row[2:], rtol=1e-4, atol=1e-4 * scale, err_msg=n)
+    noise = torch.from_numpy(np.random.RandomState(34).standard_normal((3, A)).astype(np.float32)).to(cuda)
+    monkeypatch.setattr(torch, "randn_like", lambda t, *a_, **k: noise.clone())
+    with torch.no_grad():
+        mu, pi, log_pi, log_std = agent.actor(x)
+    for k, v in (("mu", mu), ("pi", pi), ("log_pi", log_pi), ("log_std", log_std)):
+        np.testing.assert_allclose(v.cpu().numpy(), G[f"nets/{k}"], rtol=1e-5, atol=1e-6, err_msg=k)
 
 
 def test_adam_and_ema_kernels_match_torch(cuda):
