@@ -133,15 +133,9 @@ def check(status, what=""):
         raise AugclError(f"{what} failed ({status}): {msg.decode() if msg else '?'}")
 
 
-_DEBUG_SYNC = os.environ.get("AUGCL_DEBUG_SYNC", "0") == "1"  # developer aid: serialise every launch
-
-
 def call(name, *args):
     lib = load()
     check(getattr(lib, name)(*args), name)
-    if _DEBUG_SYNC:
-        import torch
-        torch.cuda.synchronize()
 
 
 def ptr(t):

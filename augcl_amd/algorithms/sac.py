@@ -6,19 +6,16 @@ engine room: parameters of each optimiser group live in one flat buffer (flat.Fl
 optimiser step and the target EMA are single fused HIP launches, the shared CNN runs as one HIP
 autograd node, and gradients can be exchanged data-parallel through one all-reduce per group.
 """
-import os
 from copy import deepcopy
 
 import numpy as np
 import torch
 import torch.nn.functional as F
 
+from .. import augmentations
 from .. import dist as apdist
 from .. import flat, head_ops
 from . import modules as m
-
-
-DUAL_TARGET_PASS = os.environ.get("AUGCL_DUAL_TARGET", "1") != "0"
 
 
 def _device():
@@ -112,7 +109,7 @@ class SAC(object):
         with torch.no_grad():
             fa = ft = None
             ea, et = self.actor.encoder, self.critic_target.encoder
-            if DUAL_TARGET_PASS and len(list(ea.head_cnn.parameters())) == 0 and len(list(et.head_cnn.parameters())) == 0:
+            if len(list(ea.head_cnn.parameters())) == 0 and len(list(et.head_cnn.parameters())) == 0:
                 # the actor's CNN and the target critic's CNN see the same next_obs: one launch per layer for both
                 both = ea.shared_cnn.forward_with(et.shared_cnn, next_obs)
                 if both is not None:
@@ -201,6 +198,8 @@ class SAC(object):
     def update(self, replay_buffer, L, step):
         """sac.py:155-164"""
         batch = replay_buffer.sample()
+        if self._reducer is not None:  # data parallel: augmentation parameters are keyed by the GLOBAL sample index
+            augmentations.set_sample_base(apdist.sample_base(self._reducer, batch[0].shape[0]))
         do_actor = step % self.actor_update_freq == 0
         do_target = step % self.critic_target_update_freq == 0
         if self._graph is not None:

@@ -32,15 +32,13 @@ class _NullLogger:
         pass
 
 
-def run(dev, dist, world, rank, steps=20, warmup=4, B=256, A=6, algo="svea", data_aug="conv", backend=None,
-        precision="f32", graph=False):
+def run(dev, dist, world, rank, steps=20, warmup=4, B=256, A=6, algo="svea", data_aug="conv", precision="f32", graph=False,
+        min_s=0.5):
     from . import dist as apdist
     from . import encoder_ops
     from . import utils as au
     from .algorithms import make_agent
 
-    if backend:
-        encoder_ops.set_backend(backend)
     encoder_ops.set_precision(precision)
     hp = dict(discount=0.99, critic_tau=0.01, encoder_tau=0.05, actor_update_freq=2, critic_target_update_freq=2,
               num_shared_layers=11, num_head_layers=0, num_filters=32, projection_dim=100, hidden_dim=1024,
@@ -49,7 +47,9 @@ def run(dev, dist, world, rank, steps=20, warmup=4, B=256, A=6, algo="svea", dat
               drq_m=1)
     if dist is not None and apdist.default_reducer() is None:
         apdist.set_default_reducer(apdist.GradReducer())
-    torch.manual_seed(0)  # identical replicas
+    # replicas are made identical by the parameter broadcast at construction; everything random AFTER that differs per
+    # rank (actor noise from torch's generator; augmentation parameters are keyed by the global sample index)
+    apdist.seed_all(0, rank)
     agent = make_agent((9, 84, 84), (A,), au.dotdict(algorithm=algo, data_aug=data_aug, aug_params=None, **hp))
     if graph:  # replay the learning part of update() as captured hipGraphs (SAC.enable_hip_graphs)
         agent.enable_hip_graphs()
@@ -59,25 +59,34 @@ def run(dev, dist, world, rank, steps=20, warmup=4, B=256, A=6, algo="svea", dat
     for s in range(warmup):
         agent.update(buf, L, s)
     torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for s in range(steps):
-        agent.update(buf, L, s)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([wall], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
+    walls, step0 = [], warmup
+    while True:  # blocks of exactly `steps` updates between barrier + synchronize, until min_s seconds are timed
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for s in range(step0, step0 + steps):
+            agent.update(buf, L, s)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([wall], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            wall = float(t.item())
+        walls.append(wall)
+        step0 += steps
+        if sum(walls) >= min_s or len(walls) >= 200:
+            break
+    wall = sorted(walls)[len(walls) // 2]
     encoder_ops.set_precision("f32")
     flops = 432e9 * (B / 256)  # ~1.69 GFLOP per sample per (average) step
     return {"grad_steps_per_s": steps / wall, "ms_per_update": wall / steps * 1e3, "samples_per_s": world * B * steps / wall,
+            "ms_per_update_min": min(walls) / steps * 1e3, "ms_per_update_max": max(walls) / steps * 1e3,
+            "repeats": len(walls), "timed_s": sum(walls),
             "algo": f"{algo}+{data_aug}", "batch_per_gpu": B, "steps": steps,
             "dtype": "f32" if precision == "f32" else "bf16 conv stack (f32 accumulate, f32 heads/optimizer)",
-            "approx_TFLOP/s_per_gpu": flops * steps / wall / 1e12, "encoder_backend": encoder_ops.BACKEND,
-            "hip_graph": bool(graph)}
+            "approx_TFLOP/s_per_gpu": flops * steps / wall / 1e12, "encoder_backend": "hip",
+            "hip_graph": bool(graph), "world": world}

@@ -22,9 +22,9 @@ def _adam_to_reference(opt, module):
     g = opt.group
     by_id = {id(p): n for n, p in zip(g.names, g.params)}
     state, params = {}, list(module.parameters())
-    step = opt.step_count
     for i, p in enumerate(params):
         n = by_id.get(id(p))
+        step = opt.tensor_step(n) if n is not None else 0
         if n is None or step == 0:
             continue  # a tensor this optimiser never moves (the shared CNN inside the actor: detach=True)
         a, b = g.slices[n]
@@ -40,7 +40,7 @@ def _adam_from_reference(opt, module, sd):
     params = list(module.parameters())
     opt.exp_avg.zero_()
     opt.exp_avg_sq.zero_()
-    steps = set()
+    steps = {}
     for i, st in sd["state"].items():
         n = by_id.get(id(params[int(i)]))
         if n is None:
@@ -48,10 +48,11 @@ def _adam_from_reference(opt, module, sd):
         a, b = g.slices[n]
         opt.exp_avg[a:b].copy_(torch.as_tensor(st["exp_avg"]).reshape(-1))
         opt.exp_avg_sq[a:b].copy_(torch.as_tensor(st["exp_avg_sq"]).reshape(-1))
-        steps.add(int(float(st["step"])))
-    if len(steps) > 1:
-        raise ValueError(f"per-parameter step counts differ ({sorted(steps)}): one fused Adam step cannot represent that")
-    opt.step_count = steps.pop() if steps else 0
+        steps[n] = int(float(st["step"]))
+    counts = set(steps.values()) | ({0} if len(steps) < len(g.names) and steps else set())
+    opt.step_count = max(counts) if counts else 0
+    if len(counts) > 1:  # parameters that missed gradients: per-tensor counts, stepped in runs (flat.FlatAdam._apply_partial)
+        opt._tensor_steps = {n: steps.get(n, 0) for n in g.names}
 
 
 def agent_state(agent):

@@ -169,7 +169,7 @@ struct ConvSmem {
 
 // x / 255.0f, correctly rounded, in 3 VALU ops instead of the ~10 of the IEEE division
 // sequence: q = x*r; q' = fma(fma(-q,255,x), r, q) with r = RN(1/255).  Verified EXHAUSTIVELY
-// (all 2^31 non-negative finite f32, denormals included; tests/test_div255.c) to equal the IEEE
+// (all 2^31 non-negative finite f32, denormals included; tests/div255_check.c, run by tests/test_div255.py) to equal the IEEE
 // quotient bit for bit; +-inf would turn into NaN in the residual, so it is passed through.
 __device__ __forceinline__ float div255(float x)
 {
@@ -965,7 +965,7 @@ int augcl_color_jitter_f32(float *inout, int B, int frames, int H, int W, const 
             if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
         }
         const int nframes = B * frames;
-        if (nframes > cus && getenv("AUGCL_JITTER_NOPIPE") == nullptr)
+        if (nframes > cus)
             hipLaunchKernelGGL((k_color_jitter_pipe<1024, 2>), dim3(cus), dim3(1024), 0, as_stream(stream), inout, n, nframes,
                                idx, n_idx, p);
         else

@@ -34,10 +34,13 @@ void reduce_defer_abort();                               // ends the scope, drop
 // For a few of the encoder's layer widths one to four MORE strips measured 5-14 % faster (tools/tune_strips.py, B = 256
 // and 512 on 256 CUs: the 32-pixel tiles of a strip are dealt to 4 compute waves, and some heights waste most of a
 // round); everything else keeps the default.  kind: 0 f32 forward, 1 f32 backward-data, 2 bf16 forward, 3 bf16
-// backward-data; W = width of the kernel's INPUT tensor.  AUGCL_EXTRA_STRIPS overrides (the tuning tool).
+// backward-data; W = width of the kernel's INPUT tensor.  (tools/tune_strips.py re-measures the table with a library
+// built with -DAUGCL_TUNING, which is the only build that reads an override from the environment.)
 inline int extra_strips(int kind, int W)
 {
+#ifdef AUGCL_TUNING
     if (const char *e = getenv("AUGCL_EXTRA_STRIPS")) return atoi(e);
+#endif
     switch (kind) {
     case 0: return W == 41 ? 4 : W == 37 ? 2 : 0;
     case 1: return W == 39 ? 1 : W == 33 ? 2 : W == 31 ? 1 : W == 23 ? 4 : 0;

@@ -298,7 +298,9 @@ int conv_first9_try(const float *in, const float *w, const float *bias, void *ou
         if (cost <= best_cost) { best_cost = cost; best = r; }
     }
     a.RT = best;
-    if (const char *e = getenv("AUGCL_F9_RT")) a.RT = std::max(1, std::min(rt, atoi(e))); // developer knob
+#ifdef AUGCL_TUNING // tools/tune_f9.py, tuning build only
+    if (const char *e = getenv("AUGCL_F9_RT")) a.RT = std::max(1, std::min(rt, atoi(e)));
+#endif
     a.S = (a.Ho + a.RT - 1) / a.RT;
     a.n_items = B * a.S;
     const int rows_last = a.Ho - (a.S - 1) * a.RT;

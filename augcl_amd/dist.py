@@ -85,6 +85,29 @@ def init_from_env(backend=None):
     return _default
 
 
+def seed_all(seed, rank=None):
+    """utils.set_seed_everywhere (src/utils.py:90-95) for data-parallel ranks.  Replicas start identical through the
+    parameter broadcast at construction, so what must DIFFER per rank is everything drawn afterwards: the actor's noise
+    (torch's generators), the replay indices (numpy's) -- both seeded with seed + rank -- while the in-kernel
+    augmentation streams keep ONE seed on all ranks and are told apart by the global sample index
+    (`sample_base`: rank r owns samples [r*B, (r+1)*B) of the global batch)."""
+    import numpy as np
+
+    from . import augmentations
+    if rank is None:
+        rank = _default.rank if _default is not None else int(os.environ.get("RANK", "0"))
+    torch.manual_seed(int(seed) + rank)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(int(seed) + rank)
+    np.random.seed((int(seed) + rank) % (2 ** 32))
+    augmentations.manual_seed(seed)
+
+
+def sample_base(reducer, local_batch):
+    """Global index of this rank's first sample: what augmentations.set_sample_base() gets before every front end."""
+    return 0 if reducer is None else reducer.rank * int(local_batch)
+
+
 def set_default_reducer(r):
     global _default
     _default = r

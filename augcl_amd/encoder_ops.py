@@ -1,50 +1,31 @@
-"""conv_stack: the shared conv encoder (x/scale -> conv3x3(stride s) -> [ReLU -> conv3x3]*) as ONE op.
+"""conv_stack: the shared conv encoder (x/scale -> conv3x3(stride s) -> [ReLU -> conv3x3]*) as ONE op on the
+hand-written gfx950 kernels behind the C ABI (augcl_enc_* in include/augcl.h): MFMA implicit-GEMM forward /
+backward-data / backward-weights with fused /255, bias, ReLU and ReLU-mask epilogues; one autograd node for the whole
+stack, activations kept post-ReLU in a per-call arena.  There is no other backend: without the library or a GPU
+tensor the op raises.  (tools/aten_encoder.py swaps an ATen stack in for A/B timing -- outside the package.)
 
-Backends
-  "hip"   (default, the product): hand-written gfx950 kernels behind the C ABI
-          (augcl_enc_* in include/augcl.h): f32 MFMA implicit-GEMM forward / backward-data /
-          backward-weights with fused /255, bias, ReLU and ReLU-mask epilogues; one autograd node
-          for the whole stack, activations kept post-ReLU in a per-call workspace.
-  "torch" developer baseline for A/B timing only (ATen/MIOpen convs on the GPU); selected with
-          AUGCL_ENCODER=torch.  Never a fallback: if the HIP path is selected and the library or a
-          GPU is missing, the op raises.
+Precision: "f32" = parity path (f32 NCHW activations, f32 MFMA); "bf16" = performance mode of BASELINE config 2
+(bf16 NHWC activations, bf16 MFMA, f32 accumulation / master weights / weight gradients), selected per process with
+`set_precision` or per agent with `args.precision`.
 """
-import os
-
 import torch
-import torch.nn.functional as F
 
 from . import _lib
 
-BACKEND = os.environ.get("AUGCL_ENCODER", "hip")
-PRECISION = os.environ.get("AUGCL_PRECISION", "f32")  # "f32" = parity path; "bf16" = performance mode (config 2)
+PRECISION = "f32"
 
 
 def set_precision(name):
     global PRECISION
-    assert name in ("f32", "bf16")
+    if name not in ("f32", "bf16"):
+        raise ValueError(f"precision must be 'f32' or 'bf16', got {name!r}")
     PRECISION = name
-
-
-def set_backend(name):
-    global BACKEND
-    assert name in ("hip", "torch")
-    BACKEND = name
-
-
-def _conv_stack_torch(x, weights, biases, first_stride, input_scale, relu_first):
-    h = x / input_scale if input_scale != 1.0 else x
-    for i, (w, b) in enumerate(zip(weights, biases)):
-        if i > 0 or relu_first:
-            h = torch.relu(h)
-        h = F.conv2d(h, w, b, stride=first_stride if i == 0 else 1)
-    return h
 
 
 def conv_stack_dual(x, weights_a, biases_a, weights_b, biases_b, first_stride=2, input_scale=255.0):
     """No-grad forward of TWO stacks with identical shapes over the same input in one launch per layer; returns the two
-    outputs, or None when the fused path does not cover the case (HIP backend, 9 x H x 84 input, stride 2)."""
-    if BACKEND != "hip" or not x.is_cuda or len(weights_a) != len(weights_b) or len(weights_a) < 2:
+    outputs, or None when the fused path does not cover the case (it needs a 9 x H x 84 input and stride 2)."""
+    if not x.is_cuda or len(weights_a) != len(weights_b) or len(weights_a) < 2:
         return None
     if any(a.shape != b.shape for a, b in zip(weights_a, weights_b)) or x.dtype != torch.float32:
         return None
@@ -58,8 +39,6 @@ def conv_stack_dual(x, weights_a, biases_a, weights_b, biases_b, first_stride=2,
 
 def conv_stack(x, weights, biases, first_stride=2, input_scale=255.0, relu_first=False):
     """x: (B,C,H,W) f32 (0..255 when input_scale=255).  Returns the last conv's output (no final ReLU)."""
-    if BACKEND == "torch":
-        return _conv_stack_torch(x, weights, biases, first_stride, input_scale, relu_first)
     _lib.require_cuda(x, "conv_stack input")
     from . import encoder_hip
     if relu_first:  # HeadCNN stacks (num_head_layers > 0): per-layer path, f32

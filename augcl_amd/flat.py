@@ -46,22 +46,26 @@ class FlatGroup:
                 p.data = self.param[a:b].view(self.shapes[n])
 
     def gather_grads(self):
-        """Copy the parameters' autograd gradients into the flat bucket (one multi-tensor launch)."""
+        """Copy the parameters' autograd gradients into the flat bucket (one multi-tensor launch).  Returns the names
+        of the parameters that have NO gradient (torch.optim.Adam skips those: no moment decay, no step)."""
+        return self.scatter_into_bucket([p.grad for p in self.params])
+
+    def scatter_into_bucket(self, grads):
         g = self
-        views, grads, missing = [], [], False
-        for n, p in zip(g.names, g.params):
-            if p.grad is None:
-                missing = True
-                continue
+        views, srcs, missing = [], [], []
+        for n, t in zip(g.names, grads):
             a, b = g.slices[n]
-            if p.grad.data_ptr() == g.grad[a:b].data_ptr():
+            if t is None:
+                missing.append(n)
+                g.grad[a:b].zero_()  # keeps the data-parallel all-reduce of the whole bucket well defined
+                continue
+            if t.data_ptr() == g.grad[a:b].data_ptr():
                 continue  # already in the bucket
             views.append(g.grad[a:b].view(g.shapes[n]))
-            grads.append(p.grad)
-        if missing:
-            g.grad.zero_()  # a parameter that received no gradient contributes zero (torch.optim.Adam skips it)
-        if grads:
-            torch._foreach_copy_(views, grads)
+            srcs.append(t)
+        if srcs:
+            torch._foreach_copy_(views, srcs)
+        return missing
 
     def segment(self, prefix):
         """[begin, end) of the contiguous run of tensors whose name starts with prefix."""
@@ -85,6 +89,7 @@ class FlatAdam:
         self.exp_avg = torch.zeros_like(group.param)
         self.exp_avg_sq = torch.zeros_like(group.param)
         self._step_count = 0
+        self._tensor_steps = None  # per-tensor step counts, only once some parameter has missed a gradient
         self.step_state = None  # device-side {int64 step, 2 floats}: set by make_capturable()
         self.reducer = reducer  # data-parallel gradient exchange (dist.GradReducer) or None
 
@@ -97,6 +102,7 @@ class FlatAdam:
     @step_count.setter
     def step_count(self, v):
         self._step_count = int(v)
+        self._tensor_steps = None
         if self.step_state is not None:
             self.step_state[0] = int(v)
 
@@ -118,22 +124,49 @@ class FlatAdam:
         weights inside the actor loss, sac.py:119-133) and land in the flat bucket by one multi-tensor copy."""
         g = self.group
         grads = torch.autograd.grad(loss, g.params, allow_unused=True)
-        if any(t is None for t in grads):
-            g.grad.zero_()
-        views = [g.grad[g.slices[n][0]:g.slices[n][1]].view(g.shapes[n]) for n, t in zip(g.names, grads) if t is not None]
-        if views:
-            torch._foreach_copy_(views, [t for t in grads if t is not None])
-        self._apply()
+        self._apply(g.scatter_into_bucket(grads))
 
     def step(self):
-        self.group.gather_grads()
-        self._apply()
+        self._apply(self.group.gather_grads())
 
-    def _apply(self):
+    def tensor_step(self, name):
+        """Adam step count of one parameter (torch.optim.Adam keeps it per parameter)."""
+        return self.step_count if self._tensor_steps is None else self._tensor_steps[name]
+
+    def _apply_partial(self, missing, scale):
+        """Some parameters got no gradient: like torch.optim.Adam, leave those alone (moments, step count, value) and
+        step the others -- one launch per run of neighbouring tensors that share a step count."""
+        g = self.group
+        if self.step_state is not None:
+            raise _lib.AugclError("FlatAdam: parameters without a gradient cannot be skipped inside a captured hipGraph "
+                                  f"(no gradient for {missing[:3]}...)")
+        if self._tensor_steps is None:
+            self._tensor_steps = {n: self._step_count for n in g.names}
+        skip = set(missing)
+        runs = []  # (begin, end, step)
+        for i, n in enumerate(g.names):
+            if n in skip:
+                continue
+            self._tensor_steps[n] += 1
+            a = g.slices[n][0]
+            b = g.slices[g.names[i + 1]][0] if i + 1 < len(g.names) else g.numel  # include the alignment padding
+            if runs and runs[-1][1] == a and runs[-1][2] == self._tensor_steps[n]:
+                runs[-1] = (runs[-1][0], b, runs[-1][2])
+            else:
+                runs.append((a, b, self._tensor_steps[n]))
+        self._step_count = max(self._tensor_steps.values())
+        st = _lib.current_stream(g.param.device)
+        for a, b, k in runs:
+            _lib.call("augcl_adam_f32", g.param.data_ptr() + 4 * a, g.grad.data_ptr() + 4 * a, self.exp_avg.data_ptr() + 4 * a,
+                      self.exp_avg_sq.data_ptr() + 4 * a, b - a, self.lr, self.betas[0], self.betas[1], self.eps, k, scale, st)
+
+    def _apply(self, missing=()):
         g = self.group
         scale = 1.0
         if self.reducer is not None:
             scale = self.reducer.allreduce_sum_(g.grad)  # returns 1/world_size
+        if missing or self._tensor_steps is not None:
+            return self._apply_partial(list(missing), scale)
         if self.step_state is not None:
             _lib.call("augcl_adam_f32_devstep", g.param.data_ptr(), g.grad.data_ptr(), self.exp_avg.data_ptr(),
                       self.exp_avg_sq.data_ptr(), g.numel, self.lr, self.betas[0], self.betas[1], self.eps,

@@ -2,19 +2,17 @@
 augcl_q_loss_*): the squashed-Gaussian policy head (src/algorithms/modules.py:19-32, 225-244), the TD target
 (src/algorithms/sac.py:94-101) and the twin-Q MSE loss (sac.py:108-110, svea.py:37-56).  The reference spends ~110
 small ATen launches per update on these (B, A)-sized tensors; here each is one launch forward and one backward,
-with the reference's operation order inside.  `FUSED = False` (AUGCL_FUSED_HEADS=0) runs the literal ATen chains."""
+with the reference's operation order inside.  Callers keep the literal ATen chain only for tensors these launches do not
+cover (another dtype, e.g. a float64 check of the same module)."""
 import ctypes
-import os
 
 import torch
 
 from . import _lib
 
-FUSED = os.environ.get("AUGCL_FUSED_HEADS", "1") != "0"
-
 
 def _ok(*ts):
-    return FUSED and all(t.is_cuda and t.dtype == torch.float32 for t in ts)
+    return all(t.is_cuda and t.dtype == torch.float32 for t in ts)
 
 
 class _GaussHead(torch.autograd.Function):

@@ -79,6 +79,7 @@ class ReplayBuffer(object):
         self._slots = pin(torch.empty((2 * self.stack,), dtype=torch.int32))
         self.sample_dtype = sample_dtype
         self.idx = 0
+        self._adds = 0
         self.full = False
         self.last_save = 0
         self.last_requeue_save = 0
@@ -131,6 +132,19 @@ class ReplayBuffer(object):
         self.slot_tab[self.idx].copy_(self._slots)
         self.idx = (self.idx + 1) % self.capacity
         self.full = self.full or self.idx == 0
+        # every frame of every LIVE transition must still be in the ring; the oldest live transition is the next one to
+        # be overwritten.  Checked here so that a ring sized for long episodes (one new frame per step) fails at the
+        # step that breaks it -- short episodes / un-shared ndarray observations need a larger frame_slack -- and not
+        # thousands of steps later inside sample().
+        self._adds += 1
+        oldest = self.idx if self.full else 0
+        if min(self.obs_seq[oldest].min(), self.next_seq[oldest].min()) < self.frame_seq - self.n_slots:
+            per = self.frame_seq / self._adds
+            need = int(np.ceil((per - 1.0) * self.capacity)) + 4 * self.stack + 16
+            raise _lib.AugclError(
+                f"replay frame ring too small: this stream stores {per:.2f} new frames per transition, so {self.capacity} "
+                f"live transitions need more than the {self.n_slots} slots of the ring; construct "
+                f"ReplayBuffer(..., frame_slack={need}) or more")
 
     # ---- sampling -------------------------------------------------------------------------------
     def _get_idxs(self, n=None):
@@ -194,8 +208,10 @@ class ReplayBuffer(object):
         if self.idx == last_save_idx:
             return self.idx
         a, b = last_save_idx, self.idx
-        seqs = np.unique(np.concatenate([self.obs_seq[a:b].ravel(), self.next_seq[a:b].ravel()]))
-        if seqs.min() < self.frame_seq - self.n_slots:
+        # after the ring has wrapped (idx < last_save_idx) the reference's slices [a:b] are EMPTY and it still writes the
+        # "<a>_<b>.tar" chunk (src/utils.py:159-167); same here: an empty chunk, which load() accepts
+        seqs = np.unique(np.concatenate([self.obs_seq[a:b].ravel(), self.next_seq[a:b].ravel()])).astype(np.int64)
+        if seqs.size and seqs.min() < self.frame_seq - self.n_slots:
             raise _lib.AugclError("replay save: a frame of an unsaved transition was already overwritten")
         slots = torch.from_numpy(seqs % self.n_slots).to(self.device)
         payload = dict(frames=self.frames[slots].cpu(), seqs=torch.from_numpy(seqs), obs_seq=torch.from_numpy(self.obs_seq[a:b].copy()),
@@ -221,6 +237,11 @@ class ReplayBuffer(object):
             payload = torch.load(os.path.join(save_dir, chunk), map_location="cpu", weights_only=True)
             assert self.idx == start, (f"self.idx: {self.idx} DNE start: {start} for save_dir: {save_dir}. "
                                        f"Current chunk is {chunk}. Chucks: {chunks}.")
+            if end < start:  # a chunk written after the ring wrapped: empty, like the reference's (its slices are empty)
+                self.idx = end
+                if end == end_step:
+                    break
+                continue
             seqs = payload["seqs"].numpy()
             new = [i for i, s in enumerate(seqs.tolist()) if s not in remap]
             if new:

@@ -3,12 +3,18 @@
 grad-steps/sec, walker_walk 84x84x9 batch=256").
 
   python bench.py --gpus N --steps K --warmup W
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+      N > 1 without a launcher: bench.py starts N ranks of itself (one process per GPU, RANK / LOCAL_RANK /
+      WORLD_SIZE / MASTER_* set, rendezvous on 127.0.0.1) BEFORE anything touches the GPU, relays rank 0's
+      JSON line and exits with the ranks' status.
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (the driver's form)
 
 One "step" = one pass of the config-2 augmentation (SVEA's strong augmentation `random_conv`,
 f32 -> f32 drop-in, src/augmentations.py:265-274) over one synthetic batch of B=256 stacked
 84x84x9 observations per GPU, inputs already resident in HBM.  The batch ring is larger than the
 256 MiB Infinity Cache so every step streams from HBM (as freshly sampled replay batches do).
+After W warm-up steps a block of EXACTLY K steps is timed between barrier + synchronize on both
+sides (max over ranks); the block is repeated until >= 0.5 s have been timed in total and the MEDIAN block
+is reported (`repeats`, `timed_s`, min / max beside it) -- K = 20 alone would be a 0.6 ms window.
 `value` = observations/s over all ranks (weak scaling: every rank owns its own B=256 shard; the
 augmentation path has no collective).  Extra keys report the other operators, the fused u8
 front end and SAC grad-steps/s, each measured the same way.  Rank 0 prints ONE JSON line.
@@ -16,6 +22,8 @@ front end and SAC grad-steps/s, each measured the same way.  Rank 0 prints ONE J
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,6 +32,9 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+MFMA_F32_PEAK_TFLOPS = 157.3   # dense f32 MFMA (MI355X_MICROARCH.md)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA
+MIN_TIMED_S = 0.5
 OBS_ELEMS = 9 * 84 * 84
 BYTES_PER_OBS = {  # algorithmic bytes per observation
     "random_conv_f32": 2 * OBS_ELEMS * 4 + 324,
@@ -32,10 +43,12 @@ BYTES_PER_OBS = {  # algorithmic bytes per observation
     "random_overlay_f32": 2 * OBS_ELEMS * 4 + 3 * 84 * 84 * 4,
     "color_jitter_f32": 2 * OBS_ELEMS * 4,
     "shift_conv_u8_f32": OBS_ELEMS * 9,  # u8 in, two f32 outputs
+    "replay_sample_f32": 2 * OBS_ELEMS * 5,  # obs + next_obs: u8 ring in, f32 out
+    "replay_shift_conv_u8_f32": OBS_ELEMS * 9,  # u8 ring in (gathered in-kernel), two f32 outputs
 }
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
@@ -45,12 +58,102 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="headline metric only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline work (s)")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
-def timed(fn, steps, warmup, dist, torch):
-    """warmup, then time exactly `steps` calls: barrier + synchronize on both sides, wall clock;
-    HIP events on the launch stream give the device-side average per launch."""
+# ------------------------------------------------------------------------------------------------ self-launch
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def child_env(base, rank, world, port):
+    """Environment of rank `rank` of `world` on this node (what torchrun would set)."""
+    env = dict(base)
+    env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this pool
+    return env
+
+
+def pick_json_line(text):
+    """The ONE result line of rank 0: the last stdout line that parses as a JSON object."""
+    for ln in reversed(text.splitlines()):
+        ln = ln.strip()
+        if ln.startswith("{") and ln.endswith("}"):
+            try:
+                json.loads(ln)
+                return ln
+            except ValueError:
+                continue
+    return None
+
+
+def launch_ranks(world, argv, cmd=None, env=None, timeout=None):
+    """Start `world` ranks of this script as CHILD processes (never an exec: the parent has not touched the GPU and
+    never will), relay rank 0's JSON line on stdout and everything else on stderr; returns the exit status."""
+    cmd = cmd or [sys.executable, os.path.abspath(__file__)]
+    base = dict(os.environ if env is None else env)
+    port = free_port()
+    procs = []
+    for r in range(world):
+        procs.append(subprocess.Popen(cmd + list(argv), env=child_env(base, r, world, port), stdout=subprocess.PIPE,
+                                      stderr=None if r == 0 else subprocess.STDOUT, text=True))
+    outs, status = [""] * world, 0
+    import threading
+
+    def drain(r):  # read each child's pipe to EOF as it runs: a full pipe must never stall a rank
+        outs[r] = procs[r].stdout.read()
+
+    readers = [threading.Thread(target=drain, args=(r,), daemon=True) for r in range(world)]
+    for th in readers:
+        th.start()
+    deadline = None if timeout is None else time.time() + timeout
+    try:
+        pending = set(range(world))
+        while pending:
+            for r in sorted(pending):
+                rc = procs[r].poll()
+                if rc is None:
+                    continue
+                pending.discard(r)
+                if rc != 0 and status == 0:
+                    status = rc
+            if status != 0 or (deadline is not None and time.time() > deadline):
+                break
+            if pending:
+                time.sleep(0.05)
+    finally:
+        for p in procs:  # a failed / timed-out rank takes the others down: exactly the PIDs started here
+            if p.poll() is None:
+                p.kill()
+                status = status or 1
+        for p, th in zip(procs, readers):
+            p.wait()
+            th.join(timeout=10)
+    for r in range(1, world):
+        if outs[r]:
+            sys.stderr.write("".join(f"[rank {r}] {ln}\n" for ln in outs[r].splitlines()))
+    line = pick_json_line(outs[0] or "")
+    rest = [ln for ln in (outs[0] or "").splitlines() if ln.strip() and ln.strip() != line]
+    if rest:
+        sys.stderr.write("".join(f"[rank 0] {ln}\n" for ln in rest))
+    if line is None:
+        sys.stderr.write("[bench] rank 0 produced no JSON line\n")
+        return status or 1
+    sys.stdout.write(line + "\n")
+    sys.stdout.flush()
+    return status
+
+
+# ------------------------------------------------------------------------------------------------ timing
+def timed(fn, steps, warmup, dist, torch, min_s=MIN_TIMED_S, max_repeats=2000):
+    """warm-up, then blocks of exactly `steps` calls, each between barrier + synchronize on both sides (wall clock,
+    MAX over ranks); HIP events on the launch stream give the device-side average per launch.  Blocks repeat until
+    `min_s` seconds have been timed; returns the median block and the spread."""
     t_ramp = time.perf_counter()  # untimed clock ramp: a cold GPU needs tens of ms of load to reach its
     while time.perf_counter() - t_ramp < 0.25:  # steady clock; W short warmup launches alone are ~1 ms
         for i in range(50):
@@ -59,26 +162,36 @@ def timed(fn, steps, warmup, dist, torch):
     for i in range(warmup):
         fn(i)
     torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record()
-    for i in range(steps):
-        fn(i)
-    e1.record()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
-    dev_ms = e0.elapsed_time(e1) / steps
-    if dist is not None:
-        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
-    return wall, dev_ms
+    walls, devs = [], []
+    it = 0
+    while True:
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        for i in range(steps):
+            fn(it + i)
+        e1.record()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        it += steps
+        if dist is not None:  # max over ranks; every rank then takes the same stop decision
+            t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            wall = float(t.item())
+        walls.append(wall)
+        devs.append(e0.elapsed_time(e1) / steps)
+        if sum(walls) >= min_s or len(walls) >= max_repeats:
+            break
+    order = sorted(range(len(walls)), key=lambda k: walls[k])
+    med = order[len(order) // 2]
+    return {"wall": walls[med], "dev_ms": sorted(devs)[len(devs) // 2], "repeats": len(walls), "timed_s": sum(walls),
+            "wall_min": walls[order[0]], "wall_max": walls[order[-1]]}
 
 
 def cpu_baseline(target_s):
@@ -117,8 +230,10 @@ def cpu_baseline(target_s):
 def graph_collectives_ok(dist, dev, torch):
     """Multi-rank pre-flight for the hipGraph leg: can this build capture an RCCL all-reduce and replay it?  Every
     rank captures (recording only -- nothing can block), the ranks agree on the outcome EAGERLY, and only then is the
-    graph replayed, so a rank whose capture failed never leaves the others waiting inside a collective."""
+    graph replayed, so a rank whose capture failed never leaves the others waiting inside a collective.  Only called
+    with world > 1: a one-rank all-reduce captures as an EMPTY graph and proves nothing."""
     world = dist.get_world_size()
+    assert world > 1
     t = torch.ones(4096, device=dev)
     dist.all_reduce(t)  # communicator up, outside any capture
     torch.cuda.synchronize()
@@ -138,8 +253,18 @@ def graph_collectives_ok(dist, dev, torch):
     return abs(float(t[0].item()) - float(world) * float(world)) < 1e-3
 
 
+def load_profile_json(name):
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", name)))
+    except Exception:  # noqa: BLE001
+        return {}
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: become one.  Nothing below this line has run, torch is not even imported here.
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
@@ -147,10 +272,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path is the only path (no CPU fallback)")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1 or os.environ.get("AUGCL_FORCE_DIST") == "1":  # the override rehearses the RCCL path on one GPU
+    rccl_ranks = 1
+    if world > 1:
         import torch.distributed as dist
         # RCCL prints a version banner on STDOUT when its communicator comes up; stdout carries the one JSON line,
         # so point fd 1 at stderr until the first collective has run
@@ -159,17 +287,20 @@ def main():
         os.dup2(2, 1)
         try:
             dist.init_process_group("nccl", device_id=dev)
+            probe = torch.ones(1, device=dev)
+            dist.all_reduce(probe)  # SUM of ones = the number of ranks RCCL actually connected
+            rccl_ranks = int(probe.item())
             dist.barrier()
             torch.cuda.synchronize()
         finally:
             sys.stdout.flush()
             os.dup2(saved, 1)
             os.close(saved)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from augcl_amd import _lib, augmentations as aug
     _lib.load()
     B, R = args.batch, args.ring
+    aug.set_sample_base(rank * B)  # in-kernel Philox parameters are keyed by the GLOBAL sample index: rank r owns [rB, (r+1)B)
     g = torch.Generator(device=dev)
     g.manual_seed(1000 + rank)
     # every input ring must exceed the 256 MiB Infinity Cache on its own: the outputs are written with non-temporal
@@ -191,7 +322,8 @@ def main():
         k = i % R
         call("augcl_random_conv_f32", p(ring_f32[k]), p(outs[k]), B, 3, 84, 84, p(weights), 0, 0, 0, stream)
 
-    wall, dev_ms = timed(conv_step, args.steps, args.warmup, dist, torch)
+    t = timed(conv_step, args.steps, args.warmup, dist, torch)
+    wall, dev_ms = t["wall"], t["dev_ms"]
     value = world * B * args.steps / wall
     ach = BYTES_PER_OBS["random_conv_f32"] * B / (dev_ms * 1e-3) / 1e9
     res = {
@@ -199,31 +331,34 @@ def main():
         "value": value, "unit": "obs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "repeats": t["repeats"], "timed_s": t["timed_s"], "value_min": world * B * args.steps / t["wall_max"],
+        "value_max": world * B * args.steps / t["wall_min"], "rccl_ranks": rccl_ranks,
         "config": {"workload": "walker_walk SVEA strong augmentation: random_conv f32->f32 drop-in on (256,9,84,84) "
                                "per GPU, explicit per-sample 3x3x3x3 weights, ring of %d batches (> L3)" % R,
                    "batch_per_gpu": B, "obs_shape": [9, 84, 84], "parallelism": f"dp{world} (batch-sharded, no collective)"},
         "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                     "traffic": None, "kernel": "k_random_conv<84,84,12>", "bytes_per_launch": BYTES_PER_OBS["random_conv_f32"] * B,
-                     "avg_launch_ms": dev_ms},
+                     "traffic": None, "kernel": "k_conv<84,84,12,256,float,false> (random_conv)",
+                     "bytes_per_launch": BYTES_PER_OBS["random_conv_f32"] * B, "avg_launch_ms": dev_ms},
     }
-    prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(prof):
-        try:
-            t = json.load(open(prof)).get("k_random_conv", {})
-            if t.get("batch") == B:  # measured offline with rocprofv3 --pmc (profiles/, tools/summarize_profiles.py)
-                res["roofline"]["traffic"] = t.get("hbm_bytes_per_launch")
-                res["roofline"]["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
-        except Exception:
-            pass
+    if dist is not None:  # every rank's own rate (its shard / the common block time is `value / world`; this is its device time)
+        mine = torch.tensor([B / (dev_ms * 1e-3)], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        res["per_rank_obs_per_s_device"] = [float(v.item()) for v in allr]
+    tr = load_profile_json("pmc_traffic.json").get("k_random_conv", {})
+    if tr.get("batch") == B:  # measured offline with rocprofv3 --pmc (profiles/, tools/summarize_profiles.py)
+        res["roofline"]["traffic"] = tr.get("hbm_bytes_per_launch")
+        res["roofline"]["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
 
     if not args.no_extras:
         extras = {}
         n2 = max(20, args.steps // 4)
 
         def rate(name, fn):
-            w_, d_ = timed(fn, n2, 10, dist, torch)
-            a_ = BYTES_PER_OBS[name] * B / (d_ * 1e-3) / 1e9
-            extras[name] = {"obs_per_s": world * B * n2 / w_, "GB/s": a_, "frac": a_ / HBM_PEAK_GBS, "avg_launch_ms": d_}
+            t_ = timed(fn, n2, 10, dist, torch, min_s=0.25)
+            a_ = BYTES_PER_OBS[name] * B / (t_["dev_ms"] * 1e-3) / 1e9
+            extras[name] = {"obs_per_s": world * B * n2 / t_["wall"], "GB/s": a_, "frac": a_ / HBM_PEAK_GBS,
+                            "avg_launch_ms": t_["dev_ms"], "repeats": t_["repeats"]}
 
         rate("random_shift_f32", lambda i: call("augcl_random_shift_f32", p(ring_f32[i % R]), p(outs[i % R]), B, 9, 84, 84, 4,
                                                 p(oy), p(ox), 0, 0, 0, stream))
@@ -248,30 +383,37 @@ def main():
         rb.next_seq[:] = (rb.obs_seq + 1) % rb.n_slots
         rb._sync_tables()
         rb.idx, rb.full = 0, True
-        BYTES_PER_OBS["replay_sample_f32"] = 2 * OBS_ELEMS * 5
         rate("replay_sample_f32", lambda i: rb.sample())
+        if hasattr(rb, "sample_shift_conv"):  # gather -> random_shift -> random_conv in one pass over the uint8 ring
+            rate("replay_shift_conv_u8_f32", lambda i: rb.sample_shift_conv())
         res["extras"] = extras
-        try:
-            from augcl_amd import bench_update
-            n_upd = max(10, args.steps // 20)
-            # update() replayed from captured hipGraphs (SAC.enable_hip_graphs); the eager figure beside it.
-            # With several ranks the graphs contain the gradient all-reduce: checked by a pre-flight first.
-            use_graph = dist is None or graph_collectives_ok(dist, dev, torch)
-            def leg(precision):
-                """Both execution modes of update(); the faster one is the reported figure, the other sits beside it
-                (the f32 path is GPU-bound, so replaying graphs buys it nothing; the bf16 mode is launch-bound)."""
-                runs = [bench_update.run(dev, dist, world, rank, steps=n_upd, precision=precision, graph=g)
-                        for g in ((True, False) if use_graph else (False,))]
-                best = min(runs, key=lambda r: r["ms_per_update"])
-                for r in runs:
-                    if r is not best:
-                        best["hip_graph_ms_per_update" if r["hip_graph"] else "eager_ms_per_update"] = r["ms_per_update"]
-                return best
 
-            res["sac"] = leg("f32")  # the parity path
-            res["sac"]["bf16_mode"] = leg("bf16")
-        except ImportError:
-            res["sac"] = None
+        from augcl_amd import bench_update
+        n_upd = max(10, args.steps // 20)
+        # update() replayed from captured hipGraphs (SAC.enable_hip_graphs); the eager figure beside it.
+        # With several ranks the graphs contain the gradient all-reduce: checked by a pre-flight first.
+        use_graph = dist is None or graph_collectives_ok(dist, dev, torch)
+        busy = load_profile_json("r02_mfma_busy.json")
+
+        def leg(precision):
+            """Both execution modes of update(); the faster one is the reported figure, the other sits beside it
+            (the f32 path is GPU-bound, so replaying graphs buys it nothing; the bf16 mode is launch-bound)."""
+            runs = [bench_update.run(dev, dist, world, rank, steps=n_upd, precision=precision, graph=gr)
+                    for gr in ((True, False) if use_graph else (False,))]
+            best = min(runs, key=lambda r: r["ms_per_update"])
+            for r in runs:
+                if r is not best:
+                    best["hip_graph_ms_per_update" if r["hip_graph"] else "eager_ms_per_update"] = r["ms_per_update"]
+            peak = MFMA_F32_PEAK_TFLOPS if precision == "f32" else MFMA_BF16_PEAK_TFLOPS
+            tf = best["approx_TFLOP/s_per_gpu"]
+            best["roofline"] = {"bound": "mfma_f32" if precision == "f32" else "mfma_bf16 (conv stack; heads and optimiser stay f32)",
+                                "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
+                                "mfma_busy": busy.get(precision), "mfma_busy_source": "profiles/r02_mfma_busy.json (rocprofv3 --pmc "
+                                "SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES per conv kernel, time-weighted)" if busy.get(precision) else None}
+            return best
+
+        res["sac"] = leg("f32")  # the parity path
+        res["sac"]["bf16_mode"] = leg("bf16")
 
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         res["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
@@ -279,6 +421,7 @@ def main():
         res["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(res))
+        sys.stdout.flush()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -45,7 +45,6 @@ def test_conv_stack_forward_backward(cuda, B, C, H, n_layers, stride):
 
     wg = [w.clone().to(cuda).requires_grad_(True) for w in ws]
     bg = [b.clone().to(cuda).requires_grad_(True) for b in bs]
-    encoder_ops.set_backend("hip")
     out = encoder_ops.conv_stack(x.to(cuda), wg, bg, first_stride=stride, input_scale=255.0)
     (out * gout.to(cuda)).sum().backward()
     torch.cuda.synchronize()

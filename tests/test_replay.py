@@ -96,10 +96,21 @@ def test_ring_overwrite_is_detected_and_agent_consumes_samples(cuda):
     from augcl_amd.replay import LazyFrames, ReplayBuffer
     from oracle import sac_oracle as so
     small = ReplayBuffer((9, 84, 84), (A,), capacity=16, batch_size=4, frame_slack=-8)  # deliberately too small
-    for of, a, r, nf, d in gi.replay_stream(seed=4, n=16, A=A):
-        small.add(LazyFrames(of), a, r, LazyFrames(nf), d)
-    with pytest.raises(_lib.AugclError):
-        small.sample(idxs=np.array([0, 1, 2, 3]))
+    with pytest.raises(_lib.AugclError, match="frame_slack"):  # at the add() that evicts a live transition's frame
+        for of, a, r, nf, d in gi.replay_stream(seed=4, n=16, A=A):
+            small.add(LazyFrames(of), a, r, LazyFrames(nf), d)
+    # short episodes (2 steps: a fresh frame stack every other transition) overrun the default slack of a wrapped
+    # buffer: reported at once, with the slack this stream needs -- and a ring built with it holds
+    cap = 64
+    short = ReplayBuffer((9, 84, 84), (A,), capacity=cap, batch_size=4)
+    with pytest.raises(_lib.AugclError, match="frame_slack") as ei:
+        for of, a, r, nf, d in gi.replay_stream(seed=4, n=4 * cap, A=A, ep_len=2):
+            short.add(LazyFrames(of), a, r, LazyFrames(nf), d)
+    need = int(str(ei.value).split("frame_slack=")[1].split(")")[0])
+    roomy = ReplayBuffer((9, 84, 84), (A,), capacity=cap, batch_size=4, frame_slack=need)
+    for of, a, r, nf, d in gi.replay_stream(seed=4, n=4 * cap, A=A, ep_len=2):
+        roomy.add(LazyFrames(of), a, r, LazyFrames(nf), d)
+    roomy.sample()
     buf = ReplayBuffer((9, 84, 84), (A,), capacity=64, batch_size=8)
     for of, a, r, nf, d in gi.replay_stream(seed=5, n=40, A=A):
         buf.add(LazyFrames(of), a, r, LazyFrames(nf), d)
@@ -144,6 +155,15 @@ def test_chunked_save_and_load_like_the_reference(cuda, tmp_path):
             assert torch.equal(x, y)
     # frames shared between chunks are stored once
     assert rb2.frame_seq == rb.frame_seq
+    # after the ring wraps (idx < last_save) the reference's slices are empty and it still writes "<a>_<b>.tar": same
+    d2 = str(tmp_path / "wrapped")
+    os.makedirs(d2)
+    for fo, a, r, fn, done in gi.replay_stream(seed=32, n=cap - 40 + 5, A=A):
+        rb.add(LazyFrames(fo), a, r, LazyFrames(fn), done)
+    assert rb.full and rb.idx == 5
+    rb.save(d2)
+    assert os.listdir(d2) == ["40_5.tar"] and rb.last_save == 5
+    assert torch.load(os.path.join(d2, "40_5.tar"), weights_only=True)["seqs"].numel() == 0
     # end_step stops after the chunk that ends there; a gap in the chunk sequence is refused like the reference
     rb3 = ReplayBuffer((9, 84, 84), (A,), cap, B, device=cuda)
     rb3.load(d, end_step=30)

@@ -186,6 +186,42 @@ def test_adam_and_ema_kernels_match_torch(cuda):
     assert torch.equal(tg.cpu()[1:], (0.01 * p0 + (1 - 0.01) * t0)[1:]) and tg.cpu()[0] == t0[0]
 
 
+def test_flat_adam_skips_missing_gradients_like_torch(cuda):
+    """torch.optim.Adam leaves a parameter without gradient untouched (no moment decay, no step, its own step count);
+    FlatAdam steps the runs of tensors that do have one and keeps per-tensor counts from then on."""
+    from augcl_amd import flat
+    rs = np.random.RandomState(1)
+    shapes = [(7, 5), (33,), (4, 4, 3), (10,)]
+    p0 = [torch.from_numpy(rs.standard_normal(s).astype(np.float32)) for s in shapes]
+    ref = [t.clone().requires_grad_(True) for t in p0]
+    opt = torch.optim.Adam(ref, lr=1e-2, betas=(0.9, 0.999), foreach=False)
+    par = [torch.nn.Parameter(t.clone().to(cuda)) for t in p0]
+    grp = flat.FlatGroup([(f"p{i}", p) for i, p in enumerate(par)])
+    fopt = flat.FlatAdam(grp, 1e-2, (0.9, 0.999))
+    present = [(1, 1, 1, 1), (1, 0, 1, 1), (0, 1, 1, 0), (1, 1, 1, 1), (1, 0, 0, 1)]
+    for mask in present:
+        opt.zero_grad(set_to_none=True)
+        fopt.zero_grad()
+        for t, p, m, s in zip(ref, par, mask, shapes):
+            if m:
+                g = torch.from_numpy(rs.standard_normal(s).astype(np.float32))
+                t.grad, p.grad = g.clone(), g.to(cuda)
+        opt.step()
+        fopt.step()
+    torch.cuda.synchronize()
+    for i, (t, p) in enumerate(zip(ref, par)):
+        np.testing.assert_allclose(p.detach().cpu().numpy(), t.detach().numpy(), rtol=2e-6, atol=2e-8, err_msg=f"p{i}")
+        assert fopt.tensor_step(f"p{i}") == int(opt.state[t]["step"])
+    # the same through backward_step(loss): gradients only for the tensors the loss depends on
+    loss_r = (ref[0].sum() * 2.0 + (ref[2] ** 2).sum())
+    opt.zero_grad(set_to_none=True)
+    loss_r.backward()
+    opt.step()
+    fopt.backward_step(par[0].sum() * 2.0 + (par[2] ** 2).sum())
+    for i, (t, p) in enumerate(zip(ref, par)):
+        np.testing.assert_allclose(p.detach().cpu().numpy(), t.detach().numpy(), rtol=2e-6, atol=2e-8, err_msg=f"p{i} (backward_step)")
+
+
 def test_agent_surface_and_actions(cuda):
     args = au.dotdict(algorithm="svea", data_aug="conv", aug_params=None, **so.DEFAULTS)
     agent = make_agent(T.OBS, (6,), args)
@@ -216,6 +252,42 @@ def test_agent_surface_and_actions(cuda):
     assert all(np.isfinite(v) for v in L.rows.values())
     assert {k for _, k in L.rows} >= {"train_critic/loss", "train_critic/shift_loss", "train_critic/aug_loss",
                                       "train_actor/loss", "train_alpha/value"}
+
+
+def test_data_parallel_rank_draws_its_shard_of_the_global_augmentation(cuda):
+    """Data parallel: in-kernel augmentation parameters are keyed by the GLOBAL sample index, and update() tells the
+    kernels where this rank's shard starts (rank * local batch) -- rank 1 of 2 reproduces the second half of what a
+    single process draws for the whole batch, so the global batch keeps its full augmentation diversity."""
+    class Rank1Of2:
+        rank, world = 1, 2
+
+        def allreduce_sum_(self, flat_grad):
+            return 1.0
+
+        def mean_scalar(self, v):
+            return v
+
+    args = au.dotdict(algorithm="svea", data_aug="conv", aug_params=None, **so.DEFAULTS)
+    agent = make_agent(T.OBS, (6,), args)
+    B = 8
+    g = torch.Generator(device=cuda).manual_seed(9)
+    full = (torch.randint(0, 256, (B, 9, 84, 84), device=cuda, generator=g).float(), torch.rand(B, 6, device=cuda) * 2 - 1,
+            torch.rand(B, 1, device=cuda), torch.randint(0, 256, (B, 9, 84, 84), device=cuda, generator=g).float(),
+            torch.ones(B, 1, device=cuda))
+    seen = []
+    agent._learn = lambda t, *a, **k: seen.append(t[0].clone())
+    try:
+        aug.manual_seed(5)
+        agent.update(FakeBuffer(full), None, 0)                       # one process, whole batch
+        agent._reducer = Rank1Of2()
+        aug.manual_seed(5)
+        agent.update(FakeBuffer(tuple(t[B // 2:] for t in full)), None, 0)  # rank 1 of 2, its shard
+    finally:
+        aug.set_sample_base(0)
+    whole, shard = seen
+    assert whole.shape[0] == 2 * B and shard.shape[0] == B  # [shifted; shifted + conv] stacks
+    assert torch.equal(shard[:B // 2], whole[B // 2:B]) and torch.equal(shard[B // 2:], whole[B + B // 2:])
+    assert not torch.equal(whole[:B // 2], whole[B // 2:B])
 
 
 def test_agent_pickle_roundtrip_and_state_dict_names(cuda, tmp_path):

@@ -1,6 +1,8 @@
 import ctypes, sys, os, torch
 sys.path.insert(0, '.')
 from augcl_amd import _lib
+# tuning build (reads the AUGCL_* overrides): make -B -C augcl_amd/csrc EXTRA_FLAGS=-DAUGCL_TUNING OUT=../../tools/libaugcl_tuning.so; then make -B -C augcl_amd/csrc
+_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libaugcl_tuning.so')
 L = _lib.load(); dev = torch.device('cuda:0')
 st = torch.cuda.current_stream().cuda_stream
 p = lambda t: ctypes.c_void_p(t.data_ptr())

@@ -3,6 +3,8 @@ layer sizes: python tools/tune_strips.py [B]"""
 import ctypes, sys, os, torch
 sys.path.insert(0, '.')
 from augcl_amd import _lib
+# tuning build (reads the AUGCL_* overrides): make -B -C augcl_amd/csrc EXTRA_FLAGS=-DAUGCL_TUNING OUT=../../tools/libaugcl_tuning.so; then make -B -C augcl_amd/csrc
+_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libaugcl_tuning.so')
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 dev = torch.device('cuda:0')
 L = _lib.load()
