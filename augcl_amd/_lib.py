@@ -64,6 +64,7 @@ _SIGS = {
     "augcl_color_jitter_f32": [_P, _I, _I, _I, _I, _P, _I, _P, _D, _D, _D, _F, _F, _P],
     "augcl_shift_conv_u8_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _U64, _U64, _I, _P],
     "augcl_shift_conv_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _U64, _U64, _I, _P],
+    "augcl_replay_shift_conv_u8_f32": [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _U64, _U64, _I, _P],
     "augcl_affine_gather_f32": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
     "augcl_cutout_color_f32": [_P, _P, _I, _I, _I, _I, _P, _P, _P],
     "augcl_random_grayscale_f32": [_P, _P, _I, _I, _I, _I, _P, _P],

@@ -195,11 +195,16 @@ class SAC(object):
         if do_target:
             self.soft_update_critic_target()
 
+    def _sample(self, replay_buffer):
+        return replay_buffer.sample()
+
     def update(self, replay_buffer, L, step):
         """sac.py:155-164"""
-        batch = replay_buffer.sample()
         if self._reducer is not None:  # data parallel: augmentation parameters are keyed by the GLOBAL sample index
-            augmentations.set_sample_base(apdist.sample_base(self._reducer, batch[0].shape[0]))
+            augmentations.set_sample_base(apdist.sample_base(self._reducer, getattr(replay_buffer, "batch_size", 0)))
+        batch = self._sample(replay_buffer)
+        if self._reducer is not None:
+            augmentations.set_sample_base(apdist.sample_base(self._reducer, batch[1].shape[0]))
         do_actor = step % self.actor_update_freq == 0
         do_target = step % self.critic_target_update_freq == 0
         if self._graph is not None:

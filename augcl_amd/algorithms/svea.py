@@ -42,9 +42,23 @@ class SVEA(RAD):
             self._log(L, "train_critic/loss", critic_loss, step)
         self.critic_optimizer.backward_step(critic_loss)  # zero_grad / backward / step
 
+    def _sample(self, replay_buffer):
+        """With the device-resident replay buffer and the fused front end, sampling and augmentation are ONE pass over
+        the uint8 frame ring (ReplayBuffer.sample_shift_conv): the first tensor of the batch is then already the
+        (2B,C,H,W) stack `_front_end` would build."""
+        fused = getattr(replay_buffer, "sample_shift_conv", None)
+        if fused is None or not self._fused_front_end(None):
+            return replay_buffer.sample()
+        static = self._graph["static"] if self._graph is not None and self._graph["seen"] >= self._graph["warmup"] else None
+        if static is not None and static[0].shape[0] != 2 * replay_buffer.batch_size:
+            static = None  # another batch size: the graphs are about to be re-captured
+        return fused(out=None if static is None else static[0])
+
     def _front_end(self, obs, action, reward, next_obs, not_done, out=None):
         """svea.py:66-68.  Returns (obs_both | obs, action, reward, next_obs, not_done): with the fused front end
         the first tensor is the (2B,C,H,W) stack [random_shift(obs); random_conv(random_shift(obs))]."""
+        if obs.shape[0] == 2 * action.shape[0]:  # already [shifted; shifted + conv] straight from the replay ring
+            return obs, action, reward, next_obs, not_done
         if self._fused_front_end(obs):
             # one pass over the (uint8 or f32) batch: random_shift AND random_conv(random_shift) together, written
             # as the two halves of one (2B,C,H,W) buffer so the critic consumes them without a concatenation copy
@@ -67,5 +81,5 @@ class SVEA(RAD):
     def _fused_front_end(self, obs):
         a = self.aug_funcs
         return (list(a) == ["conv"] and a["conv"]["func"] is augmentations.random_conv and not a["conv"]["params"]
-                and obs.shape[-1] in (84, 100) and obs.shape[-2] == obs.shape[-1]
+                and (obs is None or (obs.shape[-1] in (84, 100) and obs.shape[-2] == obs.shape[-1]))
                 and getattr(self, "fuse_front_end", True))

@@ -153,18 +153,21 @@ __global__ __launch_bounds__(256) void k_random_shift_generic(const TIn *__restr
 }
 
 // =========================================================================================
-// random_conv (+ optional fused random_shift front end)
-//   workgroup = one R-row strip of one RGB frame; the (R+2) x 3 x W input rows are staged
-//   ONCE into LDS already divided by 255 (the reference's x/255.0, one IEEE division per
-//   input element instead of 27), 3x3 windows are then read from LDS: one ds_read_b128 +
-//   two edge ds_read_b32 per (channel,row), 81 FMAs per output pixel triple against
-//   LDS-broadcast weights, sigmoid, *255, one float4 store per output channel.
+// random_conv (+ optional fused random_shift front end, + optional gather from the replay ring)
+//   work item = one R-row strip of one RGB frame; the (R+2) x 3 x W input rows are staged ONCE
+//   into LDS already divided by 255 (the reference's x/255.0, one IEEE division per input element
+//   instead of 27), 3x3 windows are then read from LDS: one ds_read_b128 + two edge ds_read_b32
+//   per (channel,row), 81 v_pk_fma_f32 pairs per output pixel quad, sigmoid, *255, one float4 store
+//   per output channel.
+//   The 81 weights of the item's sample sit ONCE in LDS and are read with broadcast ds_reads one input
+//   channel (27 weights) at a time; v_pk_fma_f32 takes a weight as an op_sel-splatted register half,
+//   so no (w,w) pair has to exist anywhere (the duplicated-pair layout cost twice the LDS traffic:
+//   more LDS time than the pixel windows).
 // =========================================================================================
 template <int H, int W, int R>
 struct ConvSmem {
     float tile[3][R + 2][W]; // x/255, rows y0-1 .. y0+R (row-clamped = replicate pad)
-    f32x2 w[84];             // 81 weights [o][i][ky][kx] (+3 pad), each stored twice: one aligned
-                             // ds_read_b64 yields the (w,w) operand of v_pk_fma_f32 with no v_mov
+    float w[84];             // the sample's 81 weights [o][i][ky][kx] (+3: the Philox draw comes in fours)
 };
 
 // x / 255.0f, correctly rounded, in 3 VALU ops instead of the ~10 of the IEEE division
@@ -180,6 +183,14 @@ __device__ __forceinline__ float div255(float x)
     return __builtin_isinf(x) ? x : y;
 }
 
+// the same for FINITE x (pixel data): without the +-inf pass-through
+__device__ __forceinline__ float div255_finite(float x)
+{
+    const float r = 1.0f / 255.0f;
+    const float q = x * r;
+    return __builtin_fmaf(__builtin_fmaf(-q, 255.0f, x), r, q);
+}
+
 __device__ __forceinline__ float sigmoid255(float a)
 {
     // torch.sigmoid = 1/(1+exp(-a)).  exp(-a) = 2^(-a*log2 e) on the v_exp_f32 unit: the rounding of
@@ -190,35 +201,17 @@ __device__ __forceinline__ float sigmoid255(float a)
     return __builtin_amdgcn_rcpf(1.0f + e) * 255.0f;
 }
 
-template <int H, int W, int R>
-__device__ __forceinline__ void conv_stage_weights(ConvSmem<H, W, R> &sm, const float *__restrict__ weights,
-                                                   uint64_t seed, uint64_t offset, int gsample, int b)
-{
-    const int tid = threadIdx.x;
-    if (weights != nullptr) {
-        if (tid < 81) {
-            const float wv = weights[(size_t)b * 81 + tid];
-            sm.w[tid] = f32x2{wv, wv};
-        }
-    } else if (tid < 21) {
-        float w4[4];
-        philox_conv_weights4(seed, offset, (uint32_t)gsample, tid, w4);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) sm.w[4 * tid + k] = f32x2{w4[k], w4[k]};
-    }
-}
 
 // one thread = 4 consecutive pixels of one row, all 3 output channels.  FMAs are issued as
 // v_pk_fma_f32 on the pixel pairs (0,1) and (2,3): for tap kx the operand pairs are
 // (v[kx],v[kx+1]) and (v[kx+2],v[kx+3]) of the 6-wide window v = [left, m0..m3, right]; the even
 // pairs come from ds_read2_b32, the odd pairs are the two halves of one aligned ds_read_b128.
 // Accumulation order per output: i, ky, kx ascending (same as oracle/aug_oracle.c).
-template <int H, int W, int R, int ABL = 0> // ABL: developer ablation switch (tools/kbench), 0 = product
-__device__ __forceinline__ void conv_compute_store(const ConvSmem<H, W, R> &sm, float *__restrict__ out_frame,
-                                                   int y0)
+template <int H, int W, int R>
+__device__ __forceinline__ void conv_compute_store(const ConvSmem<H, W, R> &sm, float *__restrict__ out_frame, int y0,
+                                                   int tid)
 {
     constexpr int W4 = W / 4;
-    const int tid = threadIdx.x;
     if (tid >= R * W4) return;
     const int ry = tid / W4;
     const int x4 = (tid - ry * W4) * 4;
@@ -229,7 +222,7 @@ __device__ __forceinline__ void conv_compute_store(const ConvSmem<H, W, R> &sm, 
 #pragma unroll
     for (int o = 0; o < 3; ++o) acc[o][0] = acc[o][1] = f32x2{0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < (ABL == 2 ? 1 : 3); ++i) {
+    for (int i = 0; i < 3; ++i) {
         f32x2 pe[3][3], po[3][2]; // even pairs (v0v1,v2v3,v4v5), odd pairs (v1v2,v3v4)
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
@@ -247,7 +240,8 @@ __device__ __forceinline__ void conv_compute_store(const ConvSmem<H, W, R> &sm, 
             for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
                 for (int o = 0; o < 3; ++o) {
-                    const f32x2 w2 = sm.w[((o * 3 + i) * 3 + ky) * 3 + kx];
+                    const float ws = sm.w[((o * 3 + i) * 3 + ky) * 3 + kx]; // same address in every lane: broadcast read
+                    const f32x2 w2 = f32x2{ws, ws}; // op_sel splat of one register half: no move, no second copy
                     const f32x2 in01 = (kx == 1) ? po[ky][0] : pe[ky][kx / 2];
                     const f32x2 in23 = (kx == 1) ? po[ky][1] : pe[ky][kx / 2 + 1];
                     acc[o][0] = __builtin_elementwise_fma(w2, in01, acc[o][0]);
@@ -256,31 +250,34 @@ __device__ __forceinline__ void conv_compute_store(const ConvSmem<H, W, R> &sm, 
     }
 #pragma unroll
     for (int o = 0; o < 3; ++o) {
-        float4 res = make_float4(sigmoid255(acc[o][0].x), sigmoid255(acc[o][0].y), sigmoid255(acc[o][1].x),
-                                 sigmoid255(acc[o][1].y));
-        if (ABL == 1) res = make_float4(acc[o][0].x, acc[o][0].y, acc[o][1].x, acc[o][1].y);
+        const float4 res = make_float4(sigmoid255(acc[o][0].x), sigmoid255(acc[o][0].y), sigmoid255(acc[o][1].x),
+                                       sigmoid255(acc[o][1].y));
         store_nt(out_frame + ((size_t)o * H + (y0 + ry)) * W + x4, res);
     }
 }
 
-// =========================================================================================
-// random_conv / fused random_shift -> (out_shift) -> random_conv -> (out_aug)
-//   SHIFT = false: plain random_conv (in -> out_aug);  TIn = float | uint8_t
-//   Every thread first issues ALL of its strip loads (NI quads in flight), then converts,
-//   optionally stores the shifted rows, divides by 255 and writes the LDS tile.
-// =========================================================================================
-template <int H, int W, int R, int NT, typename TIn, bool SHIFT, int ABL = 0>
+//   SHIFT  = false: plain random_conv (in -> out_aug);  true: out_shift = random_shift(in), out_aug = conv(out_shift)
+//   GATHER = true : `in` is the replay buffer's uint8 frame ring; the frames of sample b are named by
+//                   slot_tab[idx[b]][0..frames) (ReplayBuffer.sample + SVEA's front end in ONE pass over the ring)
+//   One workgroup per strip, 8 workgroups per CU: every thread first issues ALL of its strip loads (NI quads in
+//   flight), then converts, optionally stores the shifted rows, divides by 255 and writes the LDS tile.  (A
+//   persistent, software-pipelined form -- next strip's loads issued before the current strip's FMAs -- measured
+//   SLOWER, 31.4 vs 26.7 us at B=256: the prefetch registers cut occupancy to 4-5 waves per SIMD and the two barriers
+//   per strip serialise each workgroup, while eight independent short workgroups per CU desynchronise by themselves
+//   and keep loads, FMAs and stores of different strips overlapped; tools/kbench2.hip has both.)
+template <int H, int W, int R, int NT, typename TIn, bool SHIFT, bool GATHER, int EXP = (sizeof(TIn) == 1 ? 3 : 2)>
 __global__ __launch_bounds__(NT) void k_conv(const TIn *__restrict__ in, float *__restrict__ out_shift,
                                              float *__restrict__ out_aug, int n_frames, int frames, int pad,
                                              const int32_t *__restrict__ oy, const int32_t *__restrict__ ox,
                                              const float *__restrict__ weights, uint64_t seed, uint64_t offset,
-                                             int sample0)
+                                             int sample0, const int32_t *__restrict__ slot_tab,
+                                             const int64_t *__restrict__ idx, int tab_cols)
 {
     constexpr int NS = H / R;
     constexpr int W4 = W / 4;
     constexpr int NQ = 3 * (R + 2) * W4;
     constexpr int NI = (NQ + NT - 1) / NT;
-    static_assert(R * W4 <= NT, "one compute task per thread");
+    static_assert(R * W4 <= NT && H % R == 0, "one compute task per thread");
     __shared__ __attribute__((aligned(16))) ConvSmem<H, W, R> sm;
     // XCD-aware item map: workgroups g, g+8, g+16, ... share an XCD (and its L2), so the NS strips of
     // one frame are given to consecutive workgroups of ONE residue class: their halo rows are then
@@ -303,9 +300,17 @@ __global__ __launch_bounds__(NT) void k_conv(const TIn *__restrict__ in, float *
     const int y0 = strip * R;
     int dy = 0, dx = 0;
     if constexpr (SHIFT) sample_shift(oy, ox, seed, offset, sample0 + b, b, pad, dy, dx);
-    if (out_aug != nullptr) conv_stage_weights<H, W, R>(sm, weights, seed, offset, sample0 + b, b);
-    const TIn *__restrict__ src = in + (size_t)fidx * 3 * H * W;
+    const TIn *__restrict__ src;
+    if constexpr (GATHER) {
+        const int slot = slot_tab[(size_t)idx[b] * tab_cols + (fidx - b * frames)];
+        src = in + (size_t)slot * (3 * H * W);
+    } else {
+        src = in + (size_t)fidx * 3 * H * W;
+    }
 
+    // EXP bit 0: raise the wave priority while the strip's loads are issued (uint8 front end: 31.1 -> 30.0 us at B=256; it
+    // costs the f32 kernel 0.9 us, whose prologue is 4x the bytes); bit 1: x/255 without the +-inf pass-through.
+    if (EXP & 1) __builtin_amdgcn_s_setprio(3);
     Quad<W, TIn> raw[NI];
 #pragma unroll
     for (int k = 0; k < NI; ++k) {
@@ -320,6 +325,17 @@ __global__ __launch_bounds__(NT) void k_conv(const TIn *__restrict__ in, float *
             raw[k].load(src + ((size_t)ch * H + sy) * W, clampi(x4 + dx, 0, W - 4));
         }
     }
+    if (EXP & 1) __builtin_amdgcn_s_setprio(0);
+    if (out_aug != nullptr) { // the sample's 81 weights -> LDS (caller's array, or 21 lanes draw 84 Philox normals)
+        if (weights != nullptr) {
+            if (threadIdx.x < 81) sm.w[threadIdx.x] = weights[(size_t)b * 81 + threadIdx.x];
+        } else if (threadIdx.x < 21) {
+            float w4[4];
+            philox_conv_weights4(seed, offset, (uint32_t)(sample0 + b), threadIdx.x, w4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sm.w[4 * threadIdx.x + k] = w4[k];
+        }
+    }
 #pragma unroll
     for (int k = 0; k < NI; ++k) {
         const int j = threadIdx.x + k * NT;
@@ -332,26 +348,17 @@ __global__ __launch_bounds__(NT) void k_conv(const TIn *__restrict__ in, float *
             float4 q = raw[k].get(SHIFT ? x4 + dx - clampi(x4 + dx, 0, W - 4) : 0);
             if (SHIFT && out_shift != nullptr && ys >= y0 && ys < y0 + R)
                 store_nt(out_shift + ((size_t)(fidx * 3 + ch) * H + ys) * W + x4, q);
-            q.x = div255(q.x);
-            q.y = div255(q.y);
-            q.z = div255(q.z);
-            q.w = div255(q.w);
+            if (EXP & 2) {
+                q.x = div255_finite(q.x); q.y = div255_finite(q.y); q.z = div255_finite(q.z); q.w = div255_finite(q.w);
+            } else {
+                q.x = div255(q.x); q.y = div255(q.y); q.z = div255(q.z); q.w = div255(q.w);
+            }
             *reinterpret_cast<float4 *>(&sm.tile[ch][rr][x4]) = q;
         }
     }
     if (out_aug == nullptr) return;
     __syncthreads();
-    if (ABL == 3) { // staging only: copy the strip's rows back out of LDS
-        const int tid = threadIdx.x;
-        if (tid < R * W4) {
-            const int ry = tid / W4, x4 = (tid - ry * W4) * 4;
-            for (int o = 0; o < 3; ++o)
-                *reinterpret_cast<float4 *>(out_aug + ((size_t)(fidx * 3 + o) * H + y0 + ry) * W + x4) =
-                    *reinterpret_cast<const float4 *>(&sm.tile[o][ry + 1][x4]);
-        }
-        return;
-    }
-    conv_compute_store<H, W, R, ABL>(sm, out_aug + (size_t)fidx * 3 * H * W, y0);
+    conv_compute_store<H, W, R>(sm, out_aug + (size_t)fidx * 3 * H * W, y0, threadIdx.x);
 }
 
 // any shape: one output pixel (3 channels) per thread straight from global memory
@@ -432,7 +439,8 @@ __global__ __launch_bounds__(256) void k_random_overlay_generic(const float *__r
 }
 
 // =========================================================================================
-// color_jitter (torchvision 0.8.2 float path, restated): one workgroup per RGB frame; the
+// color_jitter (torchvision 0.8.2 float path, restated -- blends literally, the hue op in VALU-friendly form, see
+// hue_shift): one workgroup per RGB frame; the
 // whole frame (3*H*W f32 = 84.7 KB at 84x84) lives in LDS, so HBM sees one read + one write
 // even though adjust_contrast needs the frame's mean before it can touch a pixel.
 // A frame is processed iff it appears in idx (duplicates collapse, matching the reference's
@@ -454,39 +462,46 @@ __device__ __forceinline__ float blend(float a, float b, float ratio, float inv,
     return clampf(ratio * a + inv * b, 0.0f, bound);
 }
 
+// 1/x to <= 1 ulp: v_rcp_f32 (1 ulp) + one Newton step, 3 VALU ops instead of the ~10 of the IEEE division sequence
+__device__ __forceinline__ float rcp_nr(float x)
+{
+    const float r = __builtin_amdgcn_rcpf(x);
+    return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
+}
+
 __device__ __forceinline__ void hue_shift(float &r, float &g, float &b, float hue)
 {
-    // torchvision _rgb2hsv -> h = (h + hue) % 1 -> _hsv2rgb.  The three (maxc - c) / cr quotients share one
-    // IEEE reciprocal (<= 1 ulp from the separate divisions; HSV->RGB is continuous across sector boundaries, so
-    // a last-bit difference cannot jump), and fmod(x, 1) is written as x - trunc(x), which is exact.
+    // torchvision _rgb2hsv -> h = (h + hue) % 1 -> _hsv2rgb, restated for the VALU (the IEEE-faithful form cost ~200
+    // instructions per pixel and made the whole operator compute-bound at 0.37 of the HBM roofline):
+    //  * the quotients cr/maxc and (maxc-c)/cr use rcp + one Newton step (<= 2 ulp from the IEEE quotient), h/6 is a
+    //    multiplication by RN(1/6);
+    //  * fmod(x, 1) and python's x % 1.0 are v_fract_f32 (x - floor(x)); where the reference's remainder rounds up
+    //    to exactly 1.0 (x = -tiny) fract gives 1 - 2^-24, and sector 5 at f -> 1 equals sector 0 at f = 0 (HSV -> RGB
+    //    is continuous), so the output moves by <= 1 ulp;
+    //  * HSV -> RGB: channel c = v * (1 - s * (1 - k_c)), k_c = clamp(|fract(h + K_c) * 6 - 3| - 1, 0, 1) with
+    //    K = (1, 2/3, 1/3): algebraically torchvision's sector table (k = 1 -> v, k = 0 -> p, in between -> q / t)
+    //    without the five-way selects.  p, q, t are clamped to [0, 1] like the reference's, v is not.
+    // All deviations are a few ulp: the parity tolerance of this operator is 1e-5 (its torchvision arithmetic is
+    // unpinned in the first place: the library is absent from the container).
     const float maxc = fmaxf(r, fmaxf(g, b)), minc = fminf(r, fminf(g, b));
-    const bool eqc = (maxc == minc);
     const float cr = maxc - minc;
-    const float sat = cr / (eqc ? 1.0f : maxc);
-    const float inv = 1.0f / (eqc ? 1.0f : cr);
+    const bool eqc = (maxc == minc);
+    const float sat = cr * rcp_nr(eqc ? 1.0f : maxc);
+    const float inv = rcp_nr(eqc ? 1.0f : cr);
     const float rc = (maxc - r) * inv, gc = (maxc - g) * inv, bc = (maxc - b) * inv;
-    const float hr = (maxc == r) ? (bc - gc) : 0.0f;
-    const float hg = ((maxc == g) && (maxc != r)) ? (2.0f + rc - bc) : 0.0f;
-    const float hb = ((maxc != g) && (maxc != r)) ? (4.0f + gc - rc) : 0.0f;
-    float h = (hr + hg) + hb;
-    h = h / 6.0f + 1.0f;
-    h = h - truncf(h); // fmod(h, 1), h > 0
-    float hh = h + hue;
-    hh = hh - truncf(hh); // fmod(hh, 1): keeps the sign of hh
-    if (hh != 0.0f && hh < 0.0f) hh += 1.0f; // python-style remainder
+    const float h6 = (maxc == r) ? (bc - gc) : (maxc == g) ? ((2.0f + rc) - bc) : ((4.0f + gc) - rc);
+    const float h = __builtin_amdgcn_fractf(__builtin_fmaf(h6, 0.16666667163372040f, 1.0f));
+    const float hh = __builtin_amdgcn_fractf(h + hue);
     const float v = maxc;
-    const float h6 = hh * 6.0f;
-    const float fl = floorf(h6);
-    const float f = h6 - fl;
-    int i = (int)fl;
-    i = i >= 6 ? i - 6 : i; // hh in [0, 1] => fl in {0..6}
-    const float p = clampf(v * (1.0f - sat), 0.0f, 1.0f);
-    const float q = clampf(v * (1.0f - sat * f), 0.0f, 1.0f);
-    const float t = clampf(v * (1.0f - sat * (1.0f - f)), 0.0f, 1.0f);
-    const float r0 = (i == 0 || i == 5) ? v : (i == 1) ? q : (i == 4) ? t : p;
-    const float g0 = (i == 1 || i == 2) ? v : (i == 0) ? t : (i == 3) ? q : p;
-    const float b0 = (i == 3 || i == 4) ? v : (i == 2) ? t : (i == 5) ? q : p;
-    r = r0; g = g0; b = b0;
+    auto chan = [&](float K) -> float {
+        const float x = __builtin_amdgcn_fractf(hh + K);
+        const float k = clampf(fabsf(__builtin_fmaf(x, 6.0f, -3.0f)) - 1.0f, 0.0f, 1.0f);
+        const float m = v * (1.0f - sat * (1.0f - k));
+        return k >= 1.0f ? v : clampf(m, 0.0f, 1.0f);
+    };
+    r = chan(1.0f);
+    g = chan(0.66666668653488159f);
+    b = chan(0.33333334326744080f);
 }
 
 // Register-resident variant (the product path for 84x84 / 100x100 frames): NT threads own the whole RGB
@@ -607,68 +622,9 @@ __global__ __launch_bounds__(NT, WPS) void k_color_jitter_reg(float *__restrict_
     }
 }
 
-// Persistent, software-pipelined form of the same kernel (one 16-wave workgroup per CU walks frames f, f+G, f+2G..):
-// the NEXT frame's 3*NQ loads are issued before the current frame's arithmetic and the current frame's stores drain
-// under the next frame's, so a CU's load / compute / store phases overlap instead of running back to back (with one
-// workgroup per CU and one frame per workgroup they cannot: 87 registers allow only 5 waves per SIMD).
-template <int NT, int NQ>
-__global__ __launch_bounds__(NT, 4) void k_color_jitter_pipe(float *__restrict__ inout, int n, int nframes,
-                                                             const int32_t *__restrict__ idx, int n_idx, JitterParams p)
-{
-    __shared__ double red[NT / 64];
-    const int tid = threadIdx.x;
-    const int n4 = n / 4;
-    auto is_hit = [&](int frame) -> bool { // block-uniform
-        if (frame >= nframes) return false;
-        if (idx == nullptr) return true;
-        int hit = 0;
-        for (int k = tid; k < n_idx; k += NT) hit |= (idx[k] == frame);
-        return __syncthreads_or(hit) != 0;
-    };
-    auto next_hit = [&](int frame) -> int { // first touched frame of this workgroup at or after `frame`, or -1
-        for (; frame < nframes; frame += gridDim.x)
-            if (is_hit(frame)) return frame;
-        return -1;
-    };
-    auto load = [&](int frame, float4 (&px)[3][NQ]) {
-        const float4 *__restrict__ g = reinterpret_cast<const float4 *>(inout + (size_t)frame * 3 * n);
-#pragma unroll
-        for (int j = 0; j < NQ; ++j) {
-            const int q = min(tid + j * NT, n4 - 1); // clamped: every lane loads something real (masked at the store)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) px[c][j] = g[c * n4 + q];
-        }
-    };
-    int cur = next_hit(blockIdx.x);
-    if (cur < 0) return;
-    float4 px[3][NQ], pn[3][NQ];
-    load(cur, px);
-    while (cur >= 0) {
-        const int nxt = next_hit(cur + gridDim.x);
-        if (nxt >= 0) load(nxt, pn);
-#pragma unroll
-        for (int j = 0; j < NQ; ++j) // lanes past the frame must not disturb the contrast mean
-            if (tid + j * NT >= n4) {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) px[c][j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        jitter_frame_ops<NT, NQ>(px, p, red, n, n4, tid);
-        float4 *__restrict__ g = reinterpret_cast<float4 *>(inout + (size_t)cur * 3 * n);
-#pragma unroll
-        for (int j = 0; j < NQ; ++j) {
-            const int q = tid + j * NT;
-            if (q < n4) {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) g[c * n4 + q] = px[c][j];
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < NQ; ++j)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) px[c][j] = pn[c][j];
-        cur = nxt;
-    }
-}
+// (Splitting the work into two streaming phases around the contrast mean -- per-quad operators as the loads land, per-quad
+// stores behind the arithmetic -- measured SLOWER, 36.1 vs 32.4 us at B=256: the operator chain is then instantiated
+// per quad and phase with run-time trip counts and the scheduler loses the cross-quad interleaving it has here.)
 
 // LDS-resident variant for other frame sizes (whole frame in LDS, up to 160 KiB)
 template <int NT>
@@ -815,10 +771,21 @@ static int shift_dispatch(const TIn *in, TOut *out, int B, int C, int H, int W, 
     LAUNCH_CHECK(name);
 }
 
-template <typename TIn>
+template <int H, int W, int R, typename TIn, bool SHIFT, bool GATHER>
+static void launch_conv(const TIn *in, float *out_shift, float *out_aug, int B, int frames, int pad, const int32_t *oy,
+                        const int32_t *ox, const float *weights, uint64_t seed, uint64_t offset, int sample0,
+                        const int32_t *slot_tab, const int64_t *idx, int tab_cols, hipStream_t s)
+{
+    const int n_frames = B * frames;
+    hipLaunchKernelGGL((k_conv<H, W, R, 256, TIn, SHIFT, GATHER>), dim3(n_frames * (H / R)), dim3(256), 0, s, in, out_shift,
+                       out_aug, n_frames, frames, pad, oy, ox, weights, seed, offset, sample0, slot_tab, idx, tab_cols);
+}
+
+template <typename TIn, bool GATHER = false>
 static int shift_conv_dispatch(const TIn *in, float *out_shift, float *out_aug, int B, int frames, int H, int W,
                                int pad, const int32_t *oy, const int32_t *ox, const float *weights, uint64_t seed,
-                               uint64_t offset, int sample0, augcl_stream_t stream, const char *name)
+                               uint64_t offset, int sample0, augcl_stream_t stream, const char *name,
+                               const int32_t *slot_tab = nullptr, const int64_t *idx = nullptr, int tab_cols = 0)
 {
     AUGCL_REQUIRE(B >= 0 && frames > 0 && pad >= 0, "%s: bad shape", name);
     if (B == 0) return AUGCL_OK;
@@ -827,14 +794,14 @@ static int shift_conv_dispatch(const TIn *in, float *out_shift, float *out_aug, 
     AUGCL_REQUIRE(fast_shape(H, W), "%s: only 84x84 / 100x100 frames are supported (got %dx%d)", name, H, W);
     AUGCL_REQUIRE(aligned16(in) && aligned16(out_shift) && aligned16(out_aug), "%s: tensors must be 16-byte aligned",
                   name);
-    if (B == 0) return AUGCL_OK;
+    AUGCL_REQUIRE(!GATHER || (slot_tab && idx && tab_cols >= frames), "%s: slot table / index list missing", name);
     hipStream_t s = as_stream(stream);
     if (H == 84)
-        hipLaunchKernelGGL((k_conv<84, 84, 12, 256, TIn, true>), dim3(B * frames * 7), dim3(256), 0, s, in, out_shift,
-                           out_aug, B * frames, frames, pad, oy, ox, weights, seed, offset, sample0);
+        launch_conv<84, 84, 12, TIn, true, GATHER>(in, out_shift, out_aug, B, frames, pad, oy, ox, weights, seed, offset,
+                                                   sample0, slot_tab, idx, tab_cols, s);
     else
-        hipLaunchKernelGGL((k_conv<100, 100, 10, 256, TIn, true>), dim3(B * frames * 10), dim3(256), 0, s, in, out_shift,
-                           out_aug, B * frames, frames, pad, oy, ox, weights, seed, offset, sample0);
+        launch_conv<100, 100, 10, TIn, true, GATHER>(in, out_shift, out_aug, B, frames, pad, oy, ox, weights, seed, offset,
+                                                     sample0, slot_tab, idx, tab_cols, s);
     LAUNCH_CHECK(name);
 }
 
@@ -872,13 +839,11 @@ int augcl_random_conv_f32(const float *in, float *out, int B, int frames, int H,
     hipStream_t s = as_stream(stream);
     const bool vec_ok = fast_shape(H, W) && aligned16(in) && aligned16(out);
     if (vec_ok && H == 84)
-        hipLaunchKernelGGL((k_conv<84, 84, 12, 256, float, false>), dim3(B * frames * 7), dim3(256), 0, s, in,
-                           (float *)nullptr, out, B * frames, frames, 0, (const int32_t *)nullptr, (const int32_t *)nullptr,
-                           weights, seed, offset, sample0);
+        launch_conv<84, 84, 12, float, false, false>(in, nullptr, out, B, frames, 0, nullptr, nullptr, weights, seed, offset,
+                                                     sample0, nullptr, nullptr, 0, s);
     else if (vec_ok && H == 100)
-        hipLaunchKernelGGL((k_conv<100, 100, 10, 256, float, false>), dim3(B * frames * 10), dim3(256), 0, s, in,
-                           (float *)nullptr, out, B * frames, frames, 0, (const int32_t *)nullptr, (const int32_t *)nullptr,
-                           weights, seed, offset, sample0);
+        launch_conv<100, 100, 10, float, false, false>(in, nullptr, out, B, frames, 0, nullptr, nullptr, weights, seed,
+                                                       offset, sample0, nullptr, nullptr, 0, s);
     else {
         const int gx = (H * W + 255) / 256 < 64 ? (H * W + 255) / 256 : 64;
         hipLaunchKernelGGL(k_random_conv_generic, dim3(gx, B * frames), dim3(256), 0, s, in, out, frames, H, W,
@@ -901,6 +866,16 @@ int augcl_shift_conv_f32(const float *in, float *out_shift, float *out_aug, int 
 {
     return shift_conv_dispatch<float>(in, out_shift, out_aug, B, frames, H, W, pad, oy, ox, weights, seed, offset,
                                       sample0, stream, "augcl_shift_conv_f32");
+}
+
+int augcl_replay_shift_conv_u8_f32(const uint8_t *ring, const int32_t *slot_tab, const int64_t *idx, int tab_cols,
+                                   float *out_shift, float *out_aug, int B, int frames, int H, int W, int pad,
+                                   const int32_t *oy, const int32_t *ox, const float *weights, uint64_t seed,
+                                   uint64_t offset, int sample0, augcl_stream_t stream)
+{
+    return shift_conv_dispatch<uint8_t, true>(ring, out_shift, out_aug, B, frames, H, W, pad, oy, ox, weights, seed,
+                                              offset, sample0, stream, "augcl_replay_shift_conv_u8_f32", slot_tab, idx,
+                                              tab_cols);
 }
 
 int augcl_random_overlay_f32(const float *in, const float *overlay, float *out, int B, int frames, int H, int W,
@@ -958,19 +933,12 @@ int augcl_color_jitter_f32(float *inout, int B, int frames, int H, int W, const 
         return augcl::fail(AUGCL_E_UNSUPPORTED, "%s: a %dx%d RGB frame (%zu B) exceeds the 160 KiB LDS of a CU", name, H,
                            W, smem);
     if (B == 0 || (idx != nullptr && n_idx == 0)) return AUGCL_OK;
-    if (n / 4 <= 1024 * 2) { // 84x84 (1764 quads): register-resident; persistent + pipelined once every CU has >1 frame
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) {
-            int v = 0;
-            if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-        }
-        const int nframes = B * frames;
-        if (nframes > cus)
-            hipLaunchKernelGGL((k_color_jitter_pipe<1024, 2>), dim3(cus), dim3(1024), 0, as_stream(stream), inout, n, nframes,
-                               idx, n_idx, p);
-        else
-            hipLaunchKernelGGL((k_color_jitter_reg<1024, 2, 4>), dim3(nframes), dim3(1024), 0, as_stream(stream), inout, n,
-                               idx, n_idx, p);
+    if (n / 4 <= 1024 * 2) { // 84x84 (1764 quads): register-resident, two 16-wave workgroups per CU (61 VGPRs)
+        // (a persistent one-workgroup-per-CU form with the next frame's loads issued early was the faster one while the
+        // hue arithmetic needed 128 registers; with the lean arithmetic two independent workgroups per CU overlap
+        // better: 32.4 vs 39.0 us at B=256, tools/kbench2.hip)
+        hipLaunchKernelGGL((k_color_jitter_reg<1024, 2, 4>), dim3(B * frames), dim3(1024), 0, as_stream(stream), inout, n,
+                           idx, n_idx, p);
         LAUNCH_CHECK(name);
     }
     if (n / 4 <= 1024 * 3) { // 100x100 (2500 quads)

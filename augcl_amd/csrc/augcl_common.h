@@ -122,16 +122,18 @@ __host__ __device__ inline void philox_shift_offsets(uint64_t seed, uint64_t off
     ox = (int)(((uint64_t)r.y * n) >> 32);
 }
 
-// Box-Muller on two 24-bit uniforms in (0,1)
+// Box-Muller on two 24-bit uniforms in (0,1), on the transcendental unit: v_log_f32 (log2), v_sqrt_f32 and
+// v_sin_f32 / v_cos_f32, whose argument is in REVOLUTIONS -- exactly the 2*pi*u2 Box-Muller wants, no range reduction.
+// ~8 instructions instead of ~200 for logf + sincosf: inside random_conv the 21 lanes that draw a sample's weights sit
+// on the workgroup's critical path (the strip cannot be convolved before they are done).  ~1e-6 absolute accuracy --
+// these are random draws, defined by this function (the exported streams use it too), not a parity-bound quantity.
 __device__ inline void box_muller(uint32_t a, uint32_t b, float &n0, float &n1)
 {
     const float u1 = ((float)(a >> 8) + 0.5f) * 5.9604644775390625e-8f; // 2^-24
     const float u2 = ((float)(b >> 8) + 0.5f) * 5.9604644775390625e-8f;
-    const float rad = sqrtf(-2.0f * logf(u1));
-    float s, c;
-    sincosf(6.283185307179586f * u2, &s, &c);
-    n0 = rad * c;
-    n1 = rad * s;
+    const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1)); // sqrt(-2 ln u1)
+    n0 = rad * __builtin_amdgcn_cosf(u2);
+    n1 = rad * __builtin_amdgcn_sinf(u2);
 }
 
 // slots 1..21: the 81 N(0,1) conv weights of a sample, 4 per Philox call (j = 0..20 -> weights 4j..4j+3)

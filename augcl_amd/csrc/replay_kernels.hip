@@ -40,7 +40,9 @@ __global__ __launch_bounds__(256) void k_replay_sample(const uint8_t *__restrict
 {
     // blockIdx.y = one frame of one stack: (which tensor, sample b, frame k) -- the table lookups are per workgroup and
     // on the scalar unit; blockIdx.x walks the frame's dwords (no per-element division).
-    const int f = blockIdx.y, per = B * stack;
+    const int per = B * stack;
+    const int first = obs == nullptr ? 1 : 0;      // obs == NULL: only the next_obs half (+ scalars) is wanted
+    const int f = blockIdx.y + first * per;
     const int which = f >= per;
     const int fi = f - which * per; // = b*stack + k
     const int b = fi / stack, k = fi - b * stack;
@@ -56,7 +58,7 @@ __global__ __launch_bounds__(256) void k_replay_sample(const uint8_t *__restrict
             store_nt(reinterpret_cast<float *>(out) + 4 * r,
                      make_float4((float)(v & 0xffu), (float)((v >> 8) & 0xffu), (float)((v >> 16) & 0xffu), (float)(v >> 24)));
     }
-    if (blockIdx.x == 0 && which == 0 && k == 0) { // one workgroup per sample copies its scalars
+    if (blockIdx.x == 0 && which == first && k == 0) { // one workgroup per sample copies its scalars
         const int A = S - 2; // outputs as three contiguous blocks: actions [B][S-2], rewards [B], not_dones [B]
         for (int j = threadIdx.x; j < S; j += 256)
             scal_out[j < A ? (size_t)b * A + j : (size_t)B * A + (size_t)(j - A) * B + b] = scal[idx[b] * S + j];
@@ -74,11 +76,11 @@ extern "C" int augcl_replay_sample(const uint8_t *frames, const int32_t *slot_ta
     const char *name = "augcl_replay_sample";
     AUGCL_REQUIRE(B >= 0 && stack > 0 && frame_bytes > 0 && (frame_bytes & 3) == 0 && S >= 0, "%s: bad shape", name);
     if (B == 0) return AUGCL_OK;
-    AUGCL_REQUIRE(frames && slot_tab && idx && obs && next_obs && (S == 0 || (scal && scal_out)), "%s: null buffer", name);
+    AUGCL_REQUIRE(frames && slot_tab && idx && next_obs && (S == 0 || (scal && scal_out)), "%s: null buffer", name);
     AUGCL_REQUIRE(aligned16(frames) && aligned16(obs) && aligned16(next_obs), "%s: buffers must be 16-byte aligned", name);
     const int fq = frame_bytes / 4;
     AUGCL_REQUIRE((size_t)2 * B * stack <= 65535, "%s: batch too large for one launch", name);
-    const dim3 grid((fq + 255) / 256 < 8 ? (fq + 255) / 256 : 8, 2 * B * stack);
+    const dim3 grid((fq + 255) / 256 < 8 ? (fq + 255) / 256 : 8, (obs ? 2 : 1) * B * stack);
     hipStream_t s = as_stream(stream);
     if (out_f32)
         hipLaunchKernelGGL(k_replay_sample<float>, dim3(grid), dim3(256), 0, s, frames, slot_tab, scal, idx, (float *)obs,

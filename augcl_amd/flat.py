@@ -137,6 +137,8 @@ class FlatAdam:
         """Some parameters got no gradient: like torch.optim.Adam, leave those alone (moments, step count, value) and
         step the others -- one launch per run of neighbouring tensors that share a step count."""
         g = self.group
+        if len(missing) == len(g.names):
+            return  # nothing received a gradient (AugCL's orphan weak optimiser before the hand-off, augcl.py:13-14): no-op
         if self.step_state is not None:
             raise _lib.AugclError("FlatAdam: parameters without a gradient cannot be skipped inside a captured hipGraph "
                                   f"(no gradient for {missing[:3]}...)")

@@ -171,18 +171,22 @@ class ReplayBuffer(object):
         tab = np.concatenate([self.obs_seq[a:b], self.next_seq[a:b]], axis=1) % self.n_slots
         self.slot_tab[a:b] = torch.from_numpy(tab.astype(np.int32)).to(self.device)
 
+    def _checked_idxs(self, idxs):
+        idxs = np.ascontiguousarray(idxs, dtype=np.int64)
+        if idxs.size and (idxs.min() < 0 or idxs.max() >= (self.capacity if self.full else max(self.idx, 1))):
+            raise IndexError("replay sample: transition index outside the filled part of the buffer")
+        if idxs.size and min(self.obs_seq[idxs].min(), self.next_seq[idxs].min()) < self.frame_seq - self.n_slots:
+            raise _lib.AugclError("replay frame ring too small: a sampled transition's frame was overwritten "
+                                  f"(slots={self.n_slots}); raise frame_slack")
+        return idxs
+
     def sample(self, n=None, idxs=None, dtype=None):
         """src/utils.py:272-280: returns (obs, actions, rewards, next_obs, not_dones) on the device -- one H2D copy
         of the drawn indices and one launch (augcl_replay_sample) for all five tensors."""
         if idxs is None:
             idxs = self._get_idxs(n)
-        idxs = np.ascontiguousarray(idxs, dtype=np.int64)
-        if idxs.size and (idxs.min() < 0 or idxs.max() >= (self.capacity if self.full else max(self.idx, 1))):
-            raise IndexError("replay sample: transition index outside the filled part of the buffer")
+        idxs = self._checked_idxs(idxs)
         dtype = dtype or self.sample_dtype
-        if min(self.obs_seq[idxs].min(), self.next_seq[idxs].min()) < self.frame_seq - self.n_slots:
-            raise _lib.AugclError("replay frame ring too small: a sampled transition's frame was overwritten "
-                                  f"(slots={self.n_slots}); raise frame_slack")
         B, A = idxs.shape[0], self.A
         it = torch.from_numpy(idxs).to(self.device, non_blocking=True)
         obs = torch.empty((B, 3 * self.stack, self.h, self.w), dtype=dtype, device=self.device)
@@ -192,6 +196,35 @@ class ReplayBuffer(object):
                   obs.data_ptr(), next_obs.data_ptr(), sc.data_ptr(), B, self.stack, self.frame_bytes, A + 2,
                   1 if dtype == torch.float32 else 0, _lib.current_stream(self.device))
         return (obs, sc[:B * A].view(B, A), sc[B * A:B * A + B].view(B, 1), next_obs, sc[B * A + B:].view(B, 1))
+
+    def sample_shift_conv(self, n=None, idxs=None, pad=4, *, oy=None, ox=None, weights=None, out=None):
+        """sample() + SVEA's front end (src/algorithms/svea.py:66-68 and :49) in one pass over the uint8 ring: returns
+        (obs_both, actions, rewards, next_obs, not_dones) where obs_both is the (2B, C, H, W) stack
+        [random_shift(obs); random_conv(random_shift(obs))] -- the sampled obs batch itself is never materialised
+        (63.5 KB read per observation instead of 63.5 KB read + 254 KB written + 254 KB read again).  Bit-identical to
+        `sample()` followed by `augmentations.shift_conv(obs, stacked=True)` with the same parameters / Philox call."""
+        from . import augmentations
+        if idxs is None:
+            idxs = self._get_idxs(n)
+        idxs = self._checked_idxs(idxs)
+        B, A, C = idxs.shape[0], self.A, 3 * self.stack
+        it = torch.from_numpy(idxs).to(self.device, non_blocking=True)
+        both = out if out is not None else torch.empty((2 * B, C, self.h, self.w), dtype=torch.float32, device=self.device)
+        assert both.shape == (2 * B, C, self.h, self.w) and both.dtype == torch.float32 and both.is_contiguous()
+        oy = augmentations._i32(oy, B, self.device, "oy")
+        ox = augmentations._i32(ox, B, self.device, "ox")
+        if weights is not None:
+            weights = torch.as_tensor(weights, device=self.device, dtype=torch.float32).contiguous()
+        seed, off, s0 = augmentations._next_call()
+        st = _lib.current_stream(self.device)
+        _lib.call("augcl_replay_shift_conv_u8_f32", self.frames.data_ptr(), self.slot_tab.data_ptr(), it.data_ptr(),
+                  2 * self.stack, both[:B].data_ptr(), both[B:].data_ptr(), B, self.stack, self.h, self.w, int(pad),
+                  _lib.ptr(oy), _lib.ptr(ox), _lib.ptr(weights), seed, off, s0, st)
+        next_obs = torch.empty((B, C, self.h, self.w), dtype=torch.float32, device=self.device)
+        sc = torch.empty(B * (A + 2), dtype=torch.float32, device=self.device)
+        _lib.call("augcl_replay_sample", self.frames.data_ptr(), self.slot_tab.data_ptr(), self.scal.data_ptr(), it.data_ptr(),
+                  None, next_obs.data_ptr(), sc.data_ptr(), B, self.stack, self.frame_bytes, A + 2, 1, st)
+        return (both, sc[:B * A].view(B, A), sc[B * A:B * A + B].view(B, 1), next_obs, sc[B * A + B:].view(B, 1))
 
     def sample_obs(self, n=None):
         return self._gather(self.obs_seq[self._get_idxs(n)], torch.float32)

@@ -137,6 +137,17 @@ int augcl_shift_conv_f32(const float *in, float *out_shift, float *out_aug,
                          const int32_t *oy, const int32_t *ox, const float *weights,
                          uint64_t seed, uint64_t offset, int sample0, augcl_stream_t stream);
 
+/* ---- ReplayBuffer.sample -> random_shift -> random_conv in ONE pass over the replay buffer's uint8 frame ring
+ * (src/utils.py:206-214, 234-240 + src/algorithms/svea.py:68 + :49): sample b's `frames` RGB frames are
+ * ring[slot_tab[idx[b]][f]] (slot_tab: device int32 [capacity][tab_cols], first `frames` columns = the obs stack;
+ * idx: device int64[B], the np.random.randint draw), each 3*H*W bytes.  63.5 KB read per observation instead of
+ * 63.5 KB read + 254 KB written + 254 KB read again.  Same outputs / parameters as augcl_shift_conv_u8_f32 on the
+ * gathered batch (bit-identical). */
+int augcl_replay_shift_conv_u8_f32(const uint8_t *ring, const int32_t *slot_tab, const int64_t *idx, int tab_cols,
+                                   float *out_shift, float *out_aug, int B, int frames, int H, int W, int pad,
+                                   const int32_t *oy, const int32_t *ox, const float *weights,
+                                   uint64_t seed, uint64_t offset, int sample0, augcl_stream_t stream);
+
 /* ---- fused optimiser step over a FLAT parameter group: torch.optim.Adam(betas=(b1,.999), eps=1e-8)
  * as used at src/algorithms/sac.py:48-56 (math of torch/optim/adam.py, single-tensor form):
  *   g *= grad_scale; m = b1*m+(1-b1)*g; v = b2*v+(1-b2)*g*g; p -= (lr/bc1) * m/(sqrt(v)/sqrt(bc2)+eps)

@@ -372,11 +372,16 @@ class OracleAgent:
         soft_update(src, self.critic_target, e, self.hp["encoder_tau"])
 
     # -- update() ---------------------------------------------------------------------------
-    def update(self, batch, step, noise_target, noise_actor=None, aug=None, shift=None, shift2=None, forced=None):
+    def update(self, batch, step, noise_target, noise_actor=None, aug=None, shift=None, shift2=None, forced=None,
+               after_critic=None):
         """batch = (obs, action, reward, next_obs, not_done) tensors of self.dtype.
         forced: ReLU gates of the gradient-carrying passes taken from outside (see `_relu`): {"critic": [one dict
         {"cnn": [...], "Q1": [...], "Q2": [...]} per critic pass, in order], "weak": [...] (AugCL's weak critic),
         "actor": {"mlp": [...]}, "actor_q": {"Q1": [...], "Q2": [...]}}.
+        after_critic(agent): called between the critic step(s) and the actor step -- the parity tests use it to hand the
+        referee the critic parameters of the implementation under test, so that the actor phase is compared from an
+        identical state (Adam's FIRST step is lr*sign(g): an element whose gradient is ~0 lands 2*lr apart in two correct
+        evaluations, which would otherwise leak into every quantity computed afterwards).
         aug(x): the RAD chain; shift(x)/shift2(x): random_shift with the caller's offsets (shift2 is DrQ's draw
         for next_obs).  DrQ with K or M > 1 (drq.py:15-65): shift / shift2 are LISTS of K / M callables and
         noise_target a list of M noise tensors (one actor call per next_obs copy)."""
@@ -454,6 +459,8 @@ class OracleAgent:
         else:
             raise KeyError(algo)
         self.rec["target_Q"] = y.detach().clone()
+        if after_critic is not None:
+            after_critic(self)
         if step % self.hp["actor_update_freq"] == 0:
             self.update_actor_and_alpha(actor_obs, noise_actor, log, forced)
         if step % self.hp["critic_target_update_freq"] == 0:

@@ -156,7 +156,7 @@ def test_chunked_save_and_load_like_the_reference(cuda, tmp_path):
     # frames shared between chunks are stored once
     assert rb2.frame_seq == rb.frame_seq
     # after the ring wraps (idx < last_save) the reference's slices are empty and it still writes "<a>_<b>.tar": same
-    d2 = str(tmp_path / "wrapped")
+    d2 = str(tmp_path) + "_wrapped"  # a sibling: load(d) lists d and expects nothing but chunks there
     os.makedirs(d2)
     for fo, a, r, fn, done in gi.replay_stream(seed=32, n=cap - 40 + 5, A=A):
         rb.add(LazyFrames(fo), a, r, LazyFrames(fn), done)
@@ -171,3 +171,49 @@ def test_chunked_save_and_load_like_the_reference(cuda, tmp_path):
     os.remove(os.path.join(d, "0_15.tar"))
     with pytest.raises(AssertionError):
         ReplayBuffer((9, 84, 84), (A,), cap, B, device=cuda).load(d)
+
+
+@pytest.mark.gpu
+def test_fused_sample_shift_conv_equals_sample_then_front_end(cuda):
+    """ReplayBuffer.sample_shift_conv (gather -> random_shift -> random_conv in ONE pass over the uint8 ring,
+    src/utils.py:206-240 + src/algorithms/svea.py:66-68,49) == sample() followed by augmentations.shift_conv, bit for
+    bit: explicit parameters and the in-kernel Philox streams, the same index draw, and SVEA consumes it."""
+    import torch
+
+    from augcl_amd import augmentations as aug
+    from augcl_amd import utils as au
+    from augcl_amd.algorithms import make_agent
+    from augcl_amd.replay import LazyFrames, ReplayBuffer
+    from oracle import sac_oracle as so
+    rb = ReplayBuffer((9, 84, 84), (A,), capacity=96, batch_size=B, device=cuda)
+    for of, a, r, nf, d in gi.replay_stream(seed=41, n=80, A=A):
+        rb.add(LazyFrames(of), a, r, LazyFrames(nf), d)
+    rs = np.random.RandomState(3)
+    oy, ox = rs.randint(0, 9, B).astype(np.int32), rs.randint(0, 9, B).astype(np.int32)
+    w = rs.standard_normal((B, 3, 3, 3, 3)).astype(np.float32)
+    for explicit in (True, False):
+        kw = dict(oy=oy, ox=ox, weights=w) if explicit else {}
+        np.random.seed(5)
+        aug.manual_seed(77)
+        obs, act, rew, nobs, nd = rb.sample()
+        want = aug.shift_conv(obs, stacked=True, **kw)
+        np.random.seed(5)
+        aug.manual_seed(77)
+        both, act2, rew2, nobs2, nd2 = rb.sample_shift_conv(**kw)
+        assert both.shape == (2 * B, 9, 84, 84)
+        assert torch.equal(both, want), "fused front end differs from sample() + shift_conv"
+        for x, y in ((act, act2), (rew, rew2), (nobs, nobs2), (nd, nd2)):
+            assert torch.equal(x, y)
+    # SVEA through the fused path walks the same trajectory as through sample() + its own front end
+    snaps = []
+    for fused in (True, False):
+        torch.manual_seed(3)
+        aug.manual_seed(9)
+        np.random.seed(9)
+        agent = make_agent((9, 84, 84), (A,), au.dotdict(algorithm="svea", data_aug="conv", aug_params=None, **so.DEFAULTS))
+        buf = rb if fused else type("Plain", (), {"sample": lambda self, n=None: rb.sample(), "batch_size": B})()
+        for step in range(3):
+            agent.update(buf, None, step)
+        torch.cuda.synchronize()
+        snaps.append((agent.critic_group.param.clone(), agent.actor_group.param.clone()))
+    assert torch.equal(snaps[0][0], snaps[1][0]) and torch.equal(snaps[0][1], snaps[1][1])
