@@ -75,7 +75,10 @@ _SIGS = {
     "augcl_gauss_head_backward": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _D, _D, _P],
     "augcl_ln_tanh_forward": [_P, _P, _P, _P, _I, _I, _D, _P],
     "augcl_ln_tanh_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _D, _P],
-    "augcl_td_target_f32": [_P, _P, _P, _P, _P, _P, _D, _P, _I, _P],
+    "augcl_td_target_f32": [_P, _P, _P, _P, _P, _P, _I, _D, _P, _I, _P],
+    "augcl_actor_loss_forward": [_P, _P, _P, _P, _P, _I, _P],
+    "augcl_actor_loss_backward": [_P, _P, _P, _P, _P, _P, _P, _I, _P],
+    "augcl_alpha_step_f64": [_P, _P, _I, _D, _D, _D, _D, _D, _P, _P, _I, _P],
     "augcl_q_loss_forward": [_P, _P, _P, _I, _I, _P, _P, _P],
     "augcl_q_loss_backward": [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
     "augcl_adam_f32": [_P, _P, _P, _P, _SZ, _D, _D, _D, _D, _c.c_int64, _D, _P],

@@ -15,8 +15,8 @@ class AugCL(RAD):
         # as in the reference (augcl.py:13-14) the pre-hand-off weak critic is a detached copy whose
         # optimiser owns orphan tensors; it only becomes meaningful after load_pretrained_agent()
         self.critic_weak = deepcopy(self.critic)
-        self._weak_group = flat.FlatGroup(self.critic_weak.named_parameters())
-        self.critic_weak_optimizer = flat.FlatAdam(flat.FlatGroup(deepcopy(self.critic).named_parameters()),
+        self._weak_group = flat.FlatGroup(flat.critic_order(self.critic_weak.named_parameters()))
+        self.critic_weak_optimizer = flat.FlatAdam(flat.FlatGroup(flat.critic_order(deepcopy(self.critic).named_parameters())),
                                                    self._hp["critic_lr"], (self._hp["critic_beta"], 0.999),
                                                    reducer=self._reducer)
 
@@ -37,6 +37,8 @@ class AugCL(RAD):
 
     def update_critic(self, obs_aug, obs_shift, action, reward, next_obs, not_done, L=None, step=None):
         target_Q = self.calculate_target_Q(next_obs=next_obs, reward=reward, not_done=not_done)
+        self._cuts(self.critic_weak)
+        self._cuts(self.critic)
         q1, q2 = self.critic_weak(obs_shift, action)
         critic_loss_shift = self._q_loss(q1, q2, target_Q)
         q1, q2 = self.critic(obs_aug, action)
@@ -44,8 +46,13 @@ class AugCL(RAD):
         if L is not None:
             self._log(L, "train_critic_weak/loss", critic_loss_shift, step)
             self._log(L, "train_critic_strong/loss", critic_loss_aug, step)
-        self.critic_weak_optimizer.backward_step(critic_loss_shift)  # zero_grad / backward / step (augcl.py:50-52)
-        self.critic_optimizer.backward_step(critic_loss_aug)         # (augcl.py:54-56)
+        # zero_grad / backward / step of the weak critic (augcl.py:50-52), then of the strong one (augcl.py:54-56).  The
+        # two networks share nothing, so both backward passes run first -- with several ranks the weak critic's gradient
+        # exchange is then in flight during the strong critic's backward -- and the two Adam steps follow.
+        weak = self.critic_weak_optimizer.backward_begin(critic_loss_shift, self._cuts(self.critic_weak, False))
+        strong = self.critic_optimizer.backward_begin(critic_loss_aug, self._cuts(self.critic, False))
+        self.critic_weak_optimizer.backward_finish(weak)
+        self.critic_optimizer.backward_finish(strong)
 
     def soft_update_critic_target(self):
         self._soft_update_from(self._weak_group)  # the target tracks the weak critic (augcl.py:58-67)

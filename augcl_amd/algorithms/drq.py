@@ -22,6 +22,7 @@ class DrQ(SAC):
         target_Q = target_Q / self.m
         critic_loss = 0
         q1s, q2s = [], []
+        self._cuts(self.critic)
         for obs in obs_list:
             q1, q2 = self.critic(obs, action)
             critic_loss = critic_loss + self._q_loss(q1, q2, target_Q)
@@ -34,7 +35,7 @@ class DrQ(SAC):
             self._log(L, f"train_critic/target_Q_variance_m={self.m}", var(targets), step)
             self._log(L, f"train_critic/Q1_variance_k={self.k}", var(q1s), step)
             self._log(L, f"train_critic/Q2_variance_k={self.k}", var(q2s), step)
-        self.critic_optimizer.backward_step(critic_loss)  # zero_grad / backward / step
+        self.critic_optimizer.backward_step(critic_loss, self._cuts(self.critic, False))  # zero_grad / backward / step
 
     def _front_end(self, obs, action, reward, next_obs, not_done, out=None):
         """drq.py:69-74: K shifted copies of obs, M of next_obs"""

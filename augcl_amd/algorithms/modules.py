@@ -161,6 +161,7 @@ class Encoder(nn.Module):
         super().__init__()
         self.shared_cnn, self.head_cnn, self.projection = shared_cnn, head_cnn, projection
         self.out_dim = projection.out_dim
+        self.cuts = None  # data parallel: a list that collects the CNN features of gradient-carrying passes (SAC._cuts)
 
     def features(self, x):
         return self.head_cnn(self.shared_cnn(x))
@@ -171,6 +172,8 @@ class Encoder(nn.Module):
         x = self.features(x) if features is None else features
         if detach:
             x = x.detach()
+        elif self.cuts is not None and x.requires_grad:
+            self.cuts.append(x)  # the cut between conv stack and heads (flat.FlatAdam.backward_begin)
         return self.projection(x)
 
 
@@ -230,9 +233,14 @@ class Critic(nn.Module):
         self.Q1 = QFunction(self.encoder.out_dim, action_shape[0], hidden_dim)
         self.Q2 = QFunction(self.encoder.out_dim, action_shape[0], hidden_dim)
 
+    def _twin(self, h, action):
+        assert h.size(0) == action.size(0)
+        if head_ops._ok(h, action):  # both trunks as one batched network (head_ops.twin_q); nn.Sequential otherwise
+            return head_ops.twin_q(h, action, self.Q1, self.Q2)
+        return self.Q1(h, action), self.Q2(h, action)
+
     def forward(self, x, action, detach=False, features=None):
-        x = self.encoder(x, detach, features=features)
-        return self.Q1(x, action), self.Q2(x, action)
+        return self._twin(self.encoder(x, detach, features=features), action)
 
     def forward_Q(self, x_encoded, action):
-        return self.Q1(x_encoded, action), self.Q2(x_encoded, action)
+        return self._twin(x_encoded, action)

@@ -58,17 +58,19 @@ class SAC(object):
         hp = self._hp
         reducer = apdist.default_reducer()
         # critic group: CNN + critic projection + Q1 + Q2, in nn.Module.parameters() order
-        self.critic_group = flat.FlatGroup(self.critic.named_parameters())
+        self.critic_group = flat.FlatGroup(flat.critic_order(self.critic.named_parameters()))
         # actor group: what the actor owns exclusively.  The reference's actor optimiser also lists the shared
         # CNN tensors, but they never receive a gradient there (detach=True, sac.py:120) so it never moves them.
         shared = {id(p) for p in self.critic.parameters()}
         self.actor_group = flat.FlatGroup([(n, p) for n, p in self.actor.named_parameters() if id(p) not in shared])
-        self.target_group = flat.FlatGroup(self.critic_target.named_parameters())
+        self.target_group = flat.FlatGroup(flat.critic_order(self.critic_target.named_parameters()))
         assert self.target_group.names == self.critic_group.names
         self.critic_optimizer = flat.FlatAdam(self.critic_group, hp["critic_lr"], (hp["critic_beta"], 0.999), reducer=reducer)
         self.actor_optimizer = flat.FlatAdam(self.actor_group, hp["actor_lr"], (hp["actor_beta"], 0.999), reducer=reducer)
-        self.log_alpha_optimizer = torch.optim.Adam([self.log_alpha], lr=hp["alpha_lr"], betas=(hp["alpha_beta"], 0.999))
+        self.log_alpha_optimizer = flat.ScalarAdam(self.log_alpha, hp["alpha_lr"], (hp["alpha_beta"], 0.999))
         self._reducer = reducer
+        for grp in (self.critic_group, self.target_group):
+            grp.mark_cut(lambda n: n.startswith("encoder.shared_cnn.") or n.startswith("encoder.head_cnn."))
         if reducer is not None:  # replicas must start identical
             for g in (self.critic_group, self.actor_group, self.target_group):
                 reducer.broadcast_(g.param)
@@ -117,7 +119,8 @@ class SAC(object):
             _, policy_action, log_pi, _ = self.actor(next_obs, features=fa)
             target_Q1, target_Q2 = self.critic_target(next_obs, policy_action, features=ft)
             if head_ops._ok(target_Q1, log_pi, reward, not_done):
-                return head_ops.td_target(target_Q1, target_Q2, log_pi, reward, not_done, self.alpha, self.discount)
+                return head_ops.td_target(target_Q1, target_Q2, log_pi, reward, not_done, None, self.discount,
+                                          log_alpha=self.log_alpha)
             target_V = torch.min(target_Q1, target_Q2) - self.alpha.detach() * log_pi
             return reward + (not_done * self.discount * target_V)
 
@@ -133,13 +136,24 @@ class SAC(object):
                 value = self._reducer.mean_scalar(value)
             L.log(key, value, step)
 
+    def _cuts(self, critic, begin=True):
+        """Data parallel only: collect (begin) / hand over the CNN features of a critic's gradient-carrying passes, the
+        cut that lets the heads' gradient exchange overlap the conv stack's backward (flat.FlatAdam.backward_begin)."""
+        enc = critic.encoder
+        if begin:
+            enc.cuts = [] if (self._reducer is not None and self._reducer.world > 1) else None
+            return None
+        cuts, enc.cuts = enc.cuts, None
+        return cuts
+
     def update_critic(self, obs, action, reward, next_obs, not_done, L=None, step=None):
         """sac.py:103-117"""
         target_Q = self.calculate_target_Q(next_obs=next_obs, reward=reward, not_done=not_done)
+        self._cuts(self.critic)
         current_Q1, current_Q2 = self.critic(obs, action)
         critic_loss = self._q_loss(current_Q1, current_Q2, target_Q)
         self._log(L, "train_critic/loss", critic_loss, step)
-        self.critic_optimizer.backward_step(critic_loss)  # zero_grad / backward / step (sac.py:115-117)
+        self.critic_optimizer.backward_step(critic_loss, self._cuts(self.critic, False))  # zero_grad / backward / step
 
     def update_actor_and_alpha(self, obs, L=None, step=None, update_alpha=True, critic=None):
         """sac.py:119-146.  The actor's and the critic's encoders share the CNN and see the same obs
@@ -150,8 +164,11 @@ class SAC(object):
         same_cnn = critic.encoder.shared_cnn is self.actor.encoder.shared_cnn
         _, pi, log_pi, log_std = self.actor(obs, detach=True, features=feat)
         actor_Q1, actor_Q2 = critic(obs, pi, detach=True, features=feat if same_cnn else None)
-        actor_Q = torch.min(actor_Q1, actor_Q2)
-        actor_loss = (self.alpha.detach() * log_pi - actor_Q).mean()
+        fused = head_ops._ok(log_pi, actor_Q1, actor_Q2)
+        if fused:  # alpha * log_pi - min(Q1, Q2), mean: one launch forward, one backward
+            actor_loss = head_ops.actor_loss(log_pi, actor_Q1, actor_Q2, self.log_alpha)
+        else:
+            actor_loss = (self.alpha.detach() * log_pi - torch.min(actor_Q1, actor_Q2)).mean()
         if L is not None:
             entropy = 0.5 * log_std.shape[1] * (1.0 + np.log(2 * np.pi)) + log_std.sum(dim=-1)
             self._log(L, "train_actor/loss", actor_loss, step)
@@ -160,6 +177,12 @@ class SAC(object):
         # computes here and discards at the next critic zero_grad, are never built
         self.actor_optimizer.backward_step(actor_loss)
         if update_alpha:
+            if fused:  # temperature loss, its gradient and Adam's step on the float64 scalar: one launch (sac.py:137-146)
+                alpha_loss, alpha_before = self.log_alpha_optimizer.fused_step(log_pi, self.target_entropy, self._reducer)
+                if L is not None:
+                    self._log(L, "train_alpha/loss", alpha_loss.clone(), step)
+                    self._log(L, "train_alpha/value", alpha_before.clone(), step)
+                return
             self.log_alpha_optimizer.zero_grad()
             alpha_loss = (self.alpha * (-log_pi - self.target_entropy).detach()).mean()
             self._log(L, "train_alpha/loss", alpha_loss, step)
@@ -225,14 +248,6 @@ class SAC(object):
             return
         for opt in self._optimizers():
             opt.make_capturable()
-        old = self.log_alpha_optimizer
-        hp = self._hp
-        new = torch.optim.Adam([self.log_alpha], lr=hp["alpha_lr"], betas=(hp["alpha_beta"], 0.999), capturable=True)
-        if old.state_dict()["state"]:
-            new.load_state_dict(old.state_dict())
-            for grp in new.param_groups:
-                grp["capturable"] = True
-        self.log_alpha_optimizer = new
         self._graph = dict(warmup=int(warmup), seen=0, graphs={}, static=None, pool=None, shapes=None)
 
     def _graph_update(self, batch, L, step, do_actor, do_target):

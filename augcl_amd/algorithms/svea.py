@@ -25,6 +25,7 @@ class SVEA(RAD):
                 # only then is the reference's obs.clone() needed to keep `obs` intact for the actor update
                 obs_aug = self.apply_aug(obs.clone() if self._aug_mutates() else obs)
             obs_both = torch.cat([obs, obs_aug], dim=0)
+        self._cuts(self.critic)
         q1, q2 = self.critic(obs_both, torch.cat([action, action], dim=0))
         if head_ops._ok(q1, q2, target_Q):
             # one launch: per-half mse(Q1,y) + mse(Q2,y) and their weighted sum (and one launch backward)
@@ -40,7 +41,7 @@ class SVEA(RAD):
             self._log(L, "train_critic/shift_loss", critic_loss_shift, step)
             self._log(L, "train_critic/aug_loss", critic_loss_aug, step)
             self._log(L, "train_critic/loss", critic_loss, step)
-        self.critic_optimizer.backward_step(critic_loss)  # zero_grad / backward / step
+        self.critic_optimizer.backward_step(critic_loss, self._cuts(self.critic, False))  # zero_grad / backward / step
 
     def _sample(self, replay_buffer):
         """With the device-resident replay buffer and the fused front end, sampling and augmentation are ONE pass over

@@ -457,10 +457,14 @@ struct JitterParams {
 
 __device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
 __device__ __forceinline__ float gray(float r, float g, float b) { return (0.2989f * r + 0.587f * g) + 0.114f * b; }
+__device__ __forceinline__ float clamp01(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, 1.0f); } // folds into the
+                                                                                  // producer's `clamp` output modifier
 __device__ __forceinline__ float blend(float a, float b, float ratio, float inv, float bound)
 {
     return clampf(ratio * a + inv * b, 0.0f, bound);
 }
+// torchvision's _blend with its own ceiling of 1.0 (the only one the operator is ever called with from Python)
+__device__ __forceinline__ float blend1(float a, float b, float ratio, float inv) { return clamp01(ratio * a + inv * b); }
 
 // 1/x to <= 1 ulp: v_rcp_f32 (1 ulp) + one Newton step, 3 VALU ops instead of the ~10 of the IEEE division sequence
 __device__ __forceinline__ float rcp_nr(float x)
@@ -495,9 +499,9 @@ __device__ __forceinline__ void hue_shift(float &r, float &g, float &b, float hu
     const float v = maxc;
     auto chan = [&](float K) -> float {
         const float x = __builtin_amdgcn_fractf(hh + K);
-        const float k = clampf(fabsf(__builtin_fmaf(x, 6.0f, -3.0f)) - 1.0f, 0.0f, 1.0f);
+        const float k = clamp01(fabsf(__builtin_fmaf(x, 6.0f, -3.0f)) - 1.0f);
         const float m = v * (1.0f - sat * (1.0f - k));
-        return k >= 1.0f ? v : clampf(m, 0.0f, 1.0f);
+        return k >= 1.0f ? v : clamp01(m);
     };
     r = chan(1.0f);
     g = chan(0.66666668653488159f);
@@ -509,10 +513,11 @@ __device__ __forceinline__ void hue_shift(float &r, float &g, float &b, float hu
 // NT/64 partial sums of the contrast mean.  Every load of a thread is issued up front (3*NQ dwordx4 in
 // flight), several workgroups fit per CU, and HBM sees one read and one write per element.
 // The jitter ops on a register-resident frame (NQ quads per thread and channel); `red` = NT/64 doubles of LDS.
-template <int NT, int NQ>
+template <int NT, int NQ, bool UNIT> // UNIT: blend ceiling == 1.0 (clamps become free output modifiers)
 __device__ __forceinline__ void jitter_frame_ops(float4 (&px)[3][NQ], const JitterParams &p, double *red, int n, int n4,
                                                  int tid)
 {
+    auto bl = [&](float a, float b, float ratio, float inv) { return UNIT ? blend1(a, b, ratio, inv) : blend(a, b, ratio, inv, p.bound); };
     if (p.scale == 255.0f) { // uniform branches: a per-element select would execute the IEEE division as well
 #pragma unroll
         for (int c = 0; c < 3; ++c)
@@ -520,7 +525,7 @@ __device__ __forceinline__ void jitter_frame_ops(float4 (&px)[3][NQ], const Jitt
             for (int j = 0; j < NQ; ++j) {
                 float *v = &px[c][j].x;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = div255(v[e]);
+                for (int e = 0; e < 4; ++e) v[e] = div255_finite(v[e]); // pixel data: finite
             }
     } else if (p.scale != 1.0f) {
 #pragma unroll
@@ -556,7 +561,7 @@ __device__ __forceinline__ void jitter_frame_ops(float4 (&px)[3][NQ], const Jitt
                 for (int j = 0; j < NQ; ++j) {
                     float *v = &px[c][j].x;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = blend(v[e], mean, p.c_r, p.c_inv, p.bound);
+                    for (int e = 0; e < 4; ++e) v[e] = bl(v[e], mean, p.c_r, p.c_inv);
                 }
         } else if (op == 2) {
 #pragma unroll
@@ -565,9 +570,9 @@ __device__ __forceinline__ void jitter_frame_ops(float4 (&px)[3][NQ], const Jitt
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float gy = gray(r[e], gg[e], b[e]);
-                    r[e] = blend(r[e], gy, p.s_r, p.s_inv, p.bound);
-                    gg[e] = blend(gg[e], gy, p.s_r, p.s_inv, p.bound);
-                    b[e] = blend(b[e], gy, p.s_r, p.s_inv, p.bound);
+                    r[e] = bl(r[e], gy, p.s_r, p.s_inv);
+                    gg[e] = bl(gg[e], gy, p.s_r, p.s_inv);
+                    b[e] = bl(b[e], gy, p.s_r, p.s_inv);
                 }
             }
         } else if (op == 3) {
@@ -590,7 +595,7 @@ __device__ __forceinline__ void jitter_frame_ops(float4 (&px)[3][NQ], const Jitt
     }
 }
 
-template <int NT, int NQ, int WPS>
+template <int NT, int NQ, int WPS, bool UNIT = true>
 __global__ __launch_bounds__(NT, WPS) void k_color_jitter_reg(float *__restrict__ inout, int n /* H*W, %4==0 */,
                                                          const int32_t *__restrict__ idx, int n_idx, JitterParams p)
 {
@@ -611,7 +616,7 @@ __global__ __launch_bounds__(NT, WPS) void k_color_jitter_reg(float *__restrict_
 #pragma unroll
         for (int c = 0; c < 3; ++c) px[c][j] = q < n4 ? g[c * n4 + q] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    jitter_frame_ops<NT, NQ>(px, p, red, n, n4, tid);
+    jitter_frame_ops<NT, NQ, UNIT>(px, p, red, n, n4, tid);
 #pragma unroll
     for (int j = 0; j < NQ; ++j) {
         const int q = tid + j * NT;
@@ -937,13 +942,21 @@ int augcl_color_jitter_f32(float *inout, int B, int frames, int H, int W, const 
         // (a persistent one-workgroup-per-CU form with the next frame's loads issued early was the faster one while the
         // hue arithmetic needed 128 registers; with the lean arithmetic two independent workgroups per CU overlap
         // better: 32.4 vs 39.0 us at B=256, tools/kbench2.hip)
-        hipLaunchKernelGGL((k_color_jitter_reg<1024, 2, 4>), dim3(B * frames), dim3(1024), 0, as_stream(stream), inout, n,
-                           idx, n_idx, p);
+        if (bound == 1.0f)
+            hipLaunchKernelGGL((k_color_jitter_reg<1024, 2, 4, true>), dim3(B * frames), dim3(1024), 0, as_stream(stream),
+                               inout, n, idx, n_idx, p);
+        else
+            hipLaunchKernelGGL((k_color_jitter_reg<1024, 2, 4, false>), dim3(B * frames), dim3(1024), 0, as_stream(stream),
+                               inout, n, idx, n_idx, p);
         LAUNCH_CHECK(name);
     }
     if (n / 4 <= 1024 * 3) { // 100x100 (2500 quads)
-        hipLaunchKernelGGL((k_color_jitter_reg<1024, 3, 4>), dim3(B * frames), dim3(1024), 0, as_stream(stream), inout, n,
-                           idx, n_idx, p);
+        if (bound == 1.0f)
+            hipLaunchKernelGGL((k_color_jitter_reg<1024, 3, 4, true>), dim3(B * frames), dim3(1024), 0, as_stream(stream),
+                               inout, n, idx, n_idx, p);
+        else
+            hipLaunchKernelGGL((k_color_jitter_reg<1024, 3, 4, false>), dim3(B * frames), dim3(1024), 0, as_stream(stream),
+                               inout, n, idx, n_idx, p);
         LAUNCH_CHECK(name);
     }
     static size_t attr_max = 48 * 1024; // idempotent; a benign race at worst repeats the call

@@ -78,11 +78,11 @@ __global__ __launch_bounds__(256) void k_gauss_head_bwd(GaussArgs a)
 __global__ __launch_bounds__(256) void k_td_target(const float *__restrict__ tq1, const float *__restrict__ tq2,
                                                    const float *__restrict__ log_pi, const float *__restrict__ reward,
                                                    const float *__restrict__ not_done, const double *__restrict__ alpha,
-                                                   float discount, float *__restrict__ out, int B)
+                                                   int alpha_is_log, float discount, float *__restrict__ out, int B)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= B) return;
-    const float al = (float)alpha[0];
+    const float al = (float)(alpha_is_log ? exp(alpha[0]) : alpha[0]); // SAC.alpha = log_alpha.exp() in float64
     const float v = fminf(tq1[i], tq2[i]) - al * log_pi[i];
     out[i] = reward[i] + (not_done[i] * discount) * v;
 }
@@ -136,6 +136,89 @@ __global__ __launch_bounds__(256) void k_q_loss_bwd(const float *__restrict__ q1
     const float scale = (g[0] * w[s]) * (2.0f / (float)M);
     dq1[i] = scale * (q1[i] - yy);
     dq2[i] = scale * (q2[i] - yy);
+}
+
+// block-wide sum of one float per thread (256 threads), fixed-order tree: deterministic
+__device__ __forceinline__ float block_sum_256(float v, float *red)
+{
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    const float r = red[0];
+    __syncthreads();
+    return r;
+}
+
+// actor loss (src/algorithms/sac.py:119-131): mean_i(alpha * log_pi_i - min(Q1_i, Q2_i)), alpha = float(exp(log_alpha))
+__global__ __launch_bounds__(256) void k_actor_loss_fwd(const float *__restrict__ log_pi, const float *__restrict__ q1,
+                                                        const float *__restrict__ q2, const double *__restrict__ log_alpha,
+                                                        float *__restrict__ out, int B)
+{
+    __shared__ float red[256];
+    const float al = (float)exp(log_alpha[0]);
+    float a = 0.0f;
+    for (int i = threadIdx.x; i < B; i += 256) a += al * log_pi[i] - fminf(q1[i], q2[i]);
+    const float tot = block_sum_256(a, red);
+    if (threadIdx.x == 0) out[0] = tot / (float)B;
+}
+
+// its backward: d/dlog_pi = g alpha / B; d/dQ of -min(Q1, Q2): -g/B to the smaller one (ties: half each, as ATen's
+// minimum backward does)
+__global__ __launch_bounds__(256) void k_actor_loss_bwd(const float *__restrict__ q1, const float *__restrict__ q2,
+                                                        const double *__restrict__ log_alpha, const float *__restrict__ g,
+                                                        float *__restrict__ d_log_pi, float *__restrict__ dq1,
+                                                        float *__restrict__ dq2, int B)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B) return;
+    const float gi = g[0] / (float)B;
+    d_log_pi[i] = gi * (float)exp(log_alpha[0]);
+    const float a = q1[i], b = q2[i];
+    dq1[i] = a < b ? -gi : (a == b ? -gi * 0.5f : 0.0f);
+    dq2[i] = b < a ? -gi : (a == b ? -gi * 0.5f : 0.0f);
+}
+
+// temperature update (sac.py:137-146) in one launch: alpha_loss = mean(alpha * (-log_pi - target_entropy)) with
+// alpha = float(exp(log_alpha)) (a 0-dim float64 tensor times a float32 batch stays float32), its gradient with respect
+// to the float64 log_alpha, and torch.optim.Adam's step on that scalar in float64.
+// state = {exp_avg, exp_avg_sq, step, grad}; mode bit 0: loss + gradient (-> state[3]), bit 1: Adam step from state[3]
+// (data parallel: the gradient is averaged over ranks between the two).  out = {alpha_loss, alpha before the step}.
+__global__ __launch_bounds__(256) void k_alpha_step(double *__restrict__ log_alpha, const float *__restrict__ log_pi,
+                                                    int B, float target_entropy, double lr, double b1, double b2,
+                                                    double eps, double *__restrict__ state, float *__restrict__ out,
+                                                    int mode)
+{
+    __shared__ float red[256];
+    const double la = log_alpha[0];
+    const double alpha = exp(la);
+    if (mode & 1) {
+        const float al = (float)alpha;
+        float a = 0.0f, x = 0.0f;
+        for (int i = threadIdx.x; i < B; i += 256) {
+            const float xi = -log_pi[i] - target_entropy;
+            a += al * xi;
+            x += xi * (1.0f / (float)B);
+        }
+        const float loss = block_sum_256(a, red) / (float)B;
+        const float gal = block_sum_256(x, red); // d loss / d alpha (float32 reduction, like ATen's)
+        if (threadIdx.x == 0) {
+            state[3] = (double)gal * alpha;      // exp backward in float64
+            if (out) { out[0] = loss; out[1] = (float)alpha; }
+        }
+    }
+    if ((mode & 2) && threadIdx.x == 0) {
+        const double g = state[3];
+        const double step = state[2] + 1.0;
+        const double m = state[0] + (g - state[0]) * (1.0 - b1); // exp_avg.lerp_(grad, 1 - beta1)
+        const double v = state[1] * b2 + (1.0 - b2) * g * g;
+        const double bc1 = 1.0 - pow(b1, step), bc2 = 1.0 - pow(b2, step);
+        const double denom = sqrt(v) / sqrt(bc2) + eps;
+        log_alpha[0] = la - (lr / bc1) * (m / denom);
+        state[0] = m; state[1] = v; state[2] = step;
+    }
 }
 
 // RLProjection's tail (src/algorithms/modules.py:101-111): y = tanh(LayerNorm(x) * gamma + beta), rows of D <= 256.
@@ -291,15 +374,47 @@ int augcl_gauss_head_backward(const float *raw, const float *noise, const float 
 }
 
 int augcl_td_target_f32(const float *tq1, const float *tq2, const float *log_pi, const float *reward,
-                        const float *not_done, const double *alpha_dev, double discount, float *out, int B,
-                        augcl_stream_t stream)
+                        const float *not_done, const double *alpha_dev, int alpha_is_log, double discount, float *out,
+                        int B, augcl_stream_t stream)
 {
     const char *name = "augcl_td_target_f32";
     AUGCL_REQUIRE(B >= 0, "%s: bad shape", name);
     if (B == 0) return AUGCL_OK;
     AUGCL_REQUIRE(tq1 && tq2 && log_pi && reward && not_done && alpha_dev && out, "%s: null tensor", name);
     hipLaunchKernelGGL(k_td_target, dim3((B + 255) / 256), dim3(256), 0, as_stream(stream), tq1, tq2, log_pi, reward,
-                       not_done, alpha_dev, (float)discount, out, B);
+                       not_done, alpha_dev, alpha_is_log, (float)discount, out, B);
+    return augcl::check_launch(name);
+}
+
+int augcl_actor_loss_forward(const float *log_pi, const float *q1, const float *q2, const double *log_alpha, float *out,
+                             int B, augcl_stream_t stream)
+{
+    const char *name = "augcl_actor_loss_forward";
+    AUGCL_REQUIRE(B >= 1, "%s: bad shape", name);
+    AUGCL_REQUIRE(log_pi && q1 && q2 && log_alpha && out, "%s: null tensor", name);
+    hipLaunchKernelGGL(k_actor_loss_fwd, dim3(1), dim3(256), 0, as_stream(stream), log_pi, q1, q2, log_alpha, out, B);
+    return augcl::check_launch(name);
+}
+
+int augcl_actor_loss_backward(const float *q1, const float *q2, const double *log_alpha, const float *g, float *d_log_pi,
+                              float *dq1, float *dq2, int B, augcl_stream_t stream)
+{
+    const char *name = "augcl_actor_loss_backward";
+    AUGCL_REQUIRE(B >= 1, "%s: bad shape", name);
+    AUGCL_REQUIRE(q1 && q2 && log_alpha && g && d_log_pi && dq1 && dq2, "%s: null tensor", name);
+    hipLaunchKernelGGL(k_actor_loss_bwd, dim3((B + 255) / 256), dim3(256), 0, as_stream(stream), q1, q2, log_alpha, g,
+                       d_log_pi, dq1, dq2, B);
+    return augcl::check_launch(name);
+}
+
+int augcl_alpha_step_f64(double *log_alpha, const float *log_pi, int B, double target_entropy, double lr, double beta1,
+                         double beta2, double eps, double *state, float *out, int mode, augcl_stream_t stream)
+{
+    const char *name = "augcl_alpha_step_f64";
+    AUGCL_REQUIRE(B >= 1 && mode >= 1 && mode <= 3, "%s: bad argument", name);
+    AUGCL_REQUIRE(log_alpha && state && (log_pi || !(mode & 1)), "%s: null tensor", name);
+    hipLaunchKernelGGL(k_alpha_step, dim3(1), dim3(256), 0, as_stream(stream), log_alpha, log_pi, B, (float)target_entropy,
+                       lr, beta1, beta2, eps, state, out, mode);
     return augcl::check_launch(name);
 }
 

@@ -32,6 +32,15 @@ class GradReducer:
             dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group)
         return 1.0 / self.world
 
+    def allreduce_sum_async(self, flat_grad):
+        """The same SUM, issued without waiting for it: the collective runs on the backend's own stream (RCCL) / thread
+        (gloo) behind everything already queued on the current stream; `.wait()` on the returned handle (None for one
+        rank) makes the current stream wait for the result.  What lets the all-reduce of the heads' gradients -- 97 % of
+        a critic's bucket -- run under the conv stack's backward."""
+        if self.world > 1:
+            return dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        return None
+
     def allreduce_mean_(self, t):
         if self.world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)

@@ -10,6 +10,23 @@ import torch
 from . import _lib
 
 
+def critic_order(named_params):
+    """Order of a Critic's parameters inside its flat buffer: the encoder first (nn.Module order), then the twin Q
+    trunks INTERLEAVED -- Q1.trunk.0.weight, Q2.trunk.0.weight, Q1.trunk.0.bias, Q2.trunk.0.bias, ... -- so that every
+    (Q1.x, Q2.x) pair sits at a fixed distance and head_ops.twin_q can address both as one (2, ...) strided view with
+    no copy.  The "Q" tensors stay one contiguous run (soft update with critic_tau, flat.FlatGroup.segment)."""
+    named = list(named_params)
+    rest = [(n, p) for n, p in named if not (n.startswith("Q1.") or n.startswith("Q2."))]
+    q1 = [(n, p) for n, p in named if n.startswith("Q1.")]
+    q2 = {n[3:]: (n, p) for n, p in named if n.startswith("Q2.")}
+    twins = []
+    for n, p in q1:
+        twins.append((n, p))
+        if n[3:] in q2:
+            twins.append(q2.pop(n[3:]))
+    return rest + twins + list(q2.values())
+
+
 class FlatGroup:
     """Owns flat param / grad buffers for an ordered list of (name, nn.Parameter)."""
 
@@ -27,6 +44,7 @@ class FlatGroup:
             self.shapes[n] = tuple(p.shape)
             off = (off + k + align - 1) // align * align  # keep every tensor 16-byte aligned
         self.numel = off
+        self.cut_index = 0  # see mark_cut()
         self.param = torch.zeros(off, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
         self.params = []
@@ -36,6 +54,16 @@ class FlatGroup:
             p.data = self.param[a:b].view(self.shapes[n])
             p.grad = None
             self.params.append(p)
+
+    def mark_cut(self, below):
+        """Declare the leading run of tensors for which below(name) holds as the part of the network UNDER a cut (the
+        conv stack under the CNN's output features): FlatAdam.backward_begin can then finish and all-reduce everything
+        above the cut before the backward pass below it has run."""
+        k = 0
+        while k < len(self.names) and below(self.names[k]):
+            k += 1
+        assert not any(below(n) for n in self.names[k:]), "tensors under the cut must lead the group"
+        self.cut_index = k
 
     def rebind(self):
         """Re-point parameters at the flat buffers (after something replaced .data/.grad)."""
@@ -50,10 +78,13 @@ class FlatGroup:
         of the parameters that have NO gradient (torch.optim.Adam skips those: no moment decay, no step)."""
         return self.scatter_into_bucket([p.grad for p in self.params])
 
-    def scatter_into_bucket(self, grads):
+    def scatter_into_bucket(self, grads, names=None):
         g = self
         views, srcs, missing = [], [], []
-        for n, t in zip(g.names, grads):
+        names = g.names if names is None else names
+        if all(t is None for t in grads):
+            return list(names)  # nothing to copy; the caller skips these tensors (no zero-fill launches either)
+        for n, t in zip(names, grads):
             a, b = g.slices[n]
             if t is None:
                 missing.append(n)
@@ -118,13 +149,46 @@ class FlatAdam:
         for p in self.group.params:
             p.grad = None
 
-    def backward_step(self, loss):
+    def backward_step(self, loss, cut=None):
         """zero_grad(); loss.backward(); step() of the reference in one go: gradients are taken ONLY with respect to
         this group's parameters (torch.autograd.grad prunes every other weight-gradient branch, e.g. the critic's
         weights inside the actor loss, sac.py:119-133) and land in the flat bucket by one multi-tensor copy."""
-        g = self.group
-        grads = torch.autograd.grad(loss, g.params, allow_unused=True)
-        self._apply(g.scatter_into_bucket(grads))
+        self.backward_finish(self.backward_begin(loss, cut))
+
+    def backward_begin(self, loss, cut=None):
+        """The backward half of backward_step: gradients into the bucket, the data-parallel exchange STARTED.
+        cut = the activations under which the group's leading `cut_index` tensors sit (the CNN's output features): with
+        several ranks the backward pass then runs in two pieces -- everything above the cut first, whose slice of the
+        bucket (the projection and the Q / policy heads: 97 % of the bytes) is all-reduced on the side while the conv
+        stack's backward runs; the small conv slice follows.  Returns what backward_finish() needs."""
+        g, r = self.group, self.reducer
+        cut = [t for t in (cut or []) if t.requires_grad]
+        overlap = (r is not None and r.world > 1 and cut and 0 < g.cut_index < len(g.params)
+                   and not (g.param.is_cuda and torch.cuda.is_current_stream_capturing()))
+        if not overlap:
+            grads = torch.autograd.grad(loss, g.params, allow_unused=True)
+            return g.scatter_into_bucket(grads), []
+        k = g.cut_index
+        split = g.slices[g.names[k]][0]
+        grads = torch.autograd.grad(loss, g.params[k:] + cut, allow_unused=True)
+        missing = g.scatter_into_bucket(grads[:len(g.params) - k], g.names[k:])
+        pending = [r.allreduce_sum_async(g.grad[split:])]
+        d_cut = grads[len(g.params) - k:]
+        live = [(t, d) for t, d in zip(cut, d_cut) if d is not None]
+        if live:
+            below = torch.autograd.grad([t for t, _ in live], g.params[:k], grad_outputs=[d for _, d in live], allow_unused=True)
+        else:
+            below = [None] * k
+        missing += g.scatter_into_bucket(below, g.names[:k])
+        pending.append(r.allreduce_sum_async(g.grad[:split]))
+        return missing, pending
+
+    def backward_finish(self, begun):
+        missing, pending = begun
+        for h in pending:
+            if h is not None:
+                h.wait()
+        self._apply(missing, reduced=bool(pending))
 
     def step(self):
         self._apply(self.group.gather_grads())
@@ -157,16 +221,16 @@ class FlatAdam:
             else:
                 runs.append((a, b, self._tensor_steps[n]))
         self._step_count = max(self._tensor_steps.values())
-        st = _lib.current_stream(g.param.device)
         for a, b, k in runs:
-            _lib.call("augcl_adam_f32", g.param.data_ptr() + 4 * a, g.grad.data_ptr() + 4 * a, self.exp_avg.data_ptr() + 4 * a,
-                      self.exp_avg_sq.data_ptr() + 4 * a, b - a, self.lr, self.betas[0], self.betas[1], self.eps, k, scale, st)
+            self._launch_adam(a, b, k, scale)
 
-    def _apply(self, missing=()):
+    def _apply(self, missing=(), reduced=False):
         g = self.group
+        if len(missing) == len(g.names):
+            return  # no tensor of the group received a gradient (the same on every rank): nothing to exchange or step
         scale = 1.0
-        if self.reducer is not None:
-            scale = self.reducer.allreduce_sum_(g.grad)  # returns 1/world_size
+        if self.reducer is not None:  # reduced: backward_begin already exchanged the bucket (in two overlapped pieces)
+            scale = 1.0 / self.reducer.world if reduced else self.reducer.allreduce_sum_(g.grad)  # 1/world_size
         if missing or self._tensor_steps is not None:
             return self._apply_partial(list(missing), scale)
         if self.step_state is not None:
@@ -175,9 +239,14 @@ class FlatAdam:
                       self.step_state.data_ptr(), scale, _lib.current_stream(g.param.device))
             return
         self._step_count += 1
-        _lib.call("augcl_adam_f32", g.param.data_ptr(), g.grad.data_ptr(), self.exp_avg.data_ptr(),
-                  self.exp_avg_sq.data_ptr(), g.numel, self.lr, self.betas[0], self.betas[1], self.eps,
-                  self._step_count, scale, _lib.current_stream(g.param.device))
+        self._launch_adam(0, g.numel, self._step_count, scale)
+
+    def _launch_adam(self, a, b, step, scale):
+        """One fused Adam launch over elements [a, b) of the flat buffers (the only device-specific line of the class)."""
+        g = self.group
+        _lib.call("augcl_adam_f32", g.param.data_ptr() + 4 * a, g.grad.data_ptr() + 4 * a, self.exp_avg.data_ptr() + 4 * a,
+                  self.exp_avg_sq.data_ptr() + 4 * a, b - a, self.lr, self.betas[0], self.betas[1], self.eps, step, scale,
+                  _lib.current_stream(g.param.device))
 
     def state_dict(self):
         return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "lr": self.lr,
@@ -187,6 +256,58 @@ class FlatAdam:
         self.step_count = int(sd["step"])
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+
+
+class ScalarAdam:
+    """torch.optim.Adam([log_alpha], lr, betas) for SAC's float64 temperature scalar (src/algorithms/sac.py:54-56) with
+    its state on the device: `fused_step` computes the temperature loss, its gradient and the Adam step in ONE launch
+    (augcl_alpha_step_f64; the ATen chain is ~25 launches on a single scalar) and can be captured in a hipGraph as is.
+    state = float64 [exp_avg, exp_avg_sq, step, grad]."""
+
+    def __init__(self, param, lr, betas=(0.9, 0.999), eps=1e-8):
+        assert param.dtype == torch.float64 and param.numel() == 1
+        self.param, self.lr, self.betas, self.eps = param, float(lr), (float(betas[0]), float(betas[1])), float(eps)
+        self.state = torch.zeros(4, dtype=torch.float64, device=param.device)
+        self._out = torch.zeros(2, dtype=torch.float32, device=param.device)
+
+    def fused_step(self, log_pi, target_entropy, reducer=None):
+        """Returns (alpha_loss, alpha) as 0-dim float32 views (valid until the next call)."""
+        lp = log_pi.detach().contiguous()
+        args = (self.param.data_ptr(), lp.data_ptr(), lp.shape[0], float(target_entropy), self.lr, self.betas[0],
+                self.betas[1], self.eps, self.state.data_ptr(), self._out.data_ptr())
+        st = _lib.current_stream(self.param.device)
+        if reducer is not None and reducer.world > 1:  # every rank's gradient of ITS shard's mean, averaged, then the step
+            _lib.call("augcl_alpha_step_f64", *args, 1, st)
+            reducer.allreduce_mean_(self.state[3:4])
+            _lib.call("augcl_alpha_step_f64", *args, 2, st)
+        else:
+            _lib.call("augcl_alpha_step_f64", *args, 3, st)
+        return self._out[0], self._out[1]
+
+    def zero_grad(self, set_to_none=True):
+        self.param.grad = None
+
+    def step(self):
+        """Plain step from param.grad (the non-fused path: the same arithmetic through the same kernel)."""
+        self.state[3] = self.param.grad.detach().to(torch.float64).reshape(())
+        _lib.call("augcl_alpha_step_f64", self.param.data_ptr(), None, 1, 0.0, self.lr, self.betas[0], self.betas[1], self.eps,
+                  self.state.data_ptr(), None, 2, _lib.current_stream(self.param.device))
+
+    def state_dict(self):
+        """torch.optim.Adam.state_dict() layout."""
+        st = {}
+        if float(self.state[2]) > 0:
+            st[0] = {"step": self.state[2].detach().cpu().float().reshape(()), "exp_avg": self.state[0].detach().cpu().reshape(()),
+                     "exp_avg_sq": self.state[1].detach().cpu().reshape(())}
+        return {"state": st, "param_groups": [{"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": 0,
+                                               "amsgrad": False, "params": [0]}]}
+
+    def load_state_dict(self, sd):
+        self.state.zero_()
+        for st in sd.get("state", {}).values():
+            self.state[0] = float(torch.as_tensor(st["exp_avg"]))
+            self.state[1] = float(torch.as_tensor(st["exp_avg_sq"]))
+            self.state[2] = float(torch.as_tensor(st["step"]))
 
 
 def ema_(target_flat, src_flat, begin, end, tau):

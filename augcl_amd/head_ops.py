@@ -81,17 +81,48 @@ def ln_tanh(x, gamma, beta, eps=1e-5):
     return _LnTanh.apply(x, gamma, beta, eps)
 
 
-def td_target(tq1, tq2, log_pi, reward, not_done, alpha, discount):
-    """reward + (not_done * discount) * (min(tq1, tq2) - alpha * log_pi); alpha: 0-dim float64 device tensor."""
+def td_target(tq1, tq2, log_pi, reward, not_done, alpha, discount, log_alpha=None):
+    """reward + (not_done * discount) * (min(tq1, tq2) - alpha * log_pi); alpha: 0-dim float64 device tensor, or
+    log_alpha= the 0-dim float64 tensor it is the exponential of (saves the exp launch: the kernel takes it)."""
     B = tq1.shape[0]
     out = torch.empty((B, 1), dtype=torch.float32, device=tq1.device)
-    a = alpha.detach()
+    a = (alpha if log_alpha is None else log_alpha).detach()
     if a.dtype != torch.float64:
         a = a.double()
     _lib.call("augcl_td_target_f32", tq1.contiguous().data_ptr(), tq2.contiguous().data_ptr(), log_pi.contiguous().data_ptr(),
-              reward.contiguous().data_ptr(), not_done.contiguous().data_ptr(), a.data_ptr(), float(discount),
-              out.data_ptr(), B, _lib.current_stream(tq1.device))
+              reward.contiguous().data_ptr(), not_done.contiguous().data_ptr(), a.data_ptr(), 0 if log_alpha is None else 1,
+              float(discount), out.data_ptr(), B, _lib.current_stream(tq1.device))
     return out
+
+
+class _ActorLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, log_pi, q1, q2, log_alpha):
+        log_pi, q1, q2 = log_pi.contiguous(), q1.contiguous(), q2.contiguous()
+        B = log_pi.shape[0]
+        out = torch.empty(1, dtype=torch.float32, device=log_pi.device)
+        la = log_alpha.detach()
+        _lib.call("augcl_actor_loss_forward", log_pi.data_ptr(), q1.data_ptr(), q2.data_ptr(), la.data_ptr(), out.data_ptr(), B,
+                  _lib.current_stream(log_pi.device))
+        ctx.save_for_backward(q1, q2, la)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        q1, q2, la = ctx.saved_tensors
+        B = q1.shape[0]
+        buf = torch.empty((3, B, 1), dtype=torch.float32, device=q1.device)
+        g = g.contiguous().float()
+        _lib.call("augcl_actor_loss_backward", q1.data_ptr(), q2.data_ptr(), la.data_ptr(), g.data_ptr(), buf[0].data_ptr(),
+                  buf[1].data_ptr(), buf[2].data_ptr(), B, _lib.current_stream(q1.device))
+        return buf[0], buf[1], buf[2], None
+
+
+def actor_loss(log_pi, q1, q2, log_alpha):
+    """mean(alpha.detach() * log_pi - min(q1, q2)) with alpha = exp(log_alpha) (src/algorithms/sac.py:119-131): one launch
+    forward, one backward; log_alpha (0-dim float64) receives no gradient, exactly like the reference's .detach()."""
+    assert log_alpha.dtype == torch.float64 and log_pi.shape[0] == q1.shape[0] == q2.shape[0]
+    return _ActorLoss.apply(log_pi, q1, q2, log_alpha)
 
 
 class _QLoss(torch.autograd.Function):
@@ -126,3 +157,66 @@ def q_loss(q1, q2, y, weights=(1.0,)):
     """(total, per-segment losses): segment s = mse(q1[sM:(s+1)M], y) + mse(q2[...], y), total = sum w[s] seg[s].
     No gradient reaches y (it is a detached target everywhere on this path)."""
     return _QLoss.apply(q1, q2, y, tuple(weights))
+
+
+# ---- twin Q trunks as ONE batched network -----------------------------------------------------------------------------
+def _stacked(p1, p2):
+    """(2, *shape) view over two same-shaped tensors that live at a fixed distance in ONE storage (the flat parameter
+    buffer lays Q1.x / Q2.x out next to each other, flat.critic_order); a stacked COPY otherwise."""
+    p1, p2 = p1.detach(), p2.detach()
+    if (p1.untyped_storage().data_ptr() == p2.untyped_storage().data_ptr() and p1.is_contiguous() and p2.is_contiguous()):
+        delta = p2.storage_offset() - p1.storage_offset()
+        if delta >= p1.numel():
+            return torch.as_strided(p1, (2, *p1.shape), (delta, *p1.stride()))
+    return torch.stack([p1, p2])
+
+
+class _TwinQ(torch.autograd.Function):
+    """Q1(h, a), Q2(h, a) of src/algorithms/modules.py:247-276 -- two identical 3-layer MLPs over the same input -- as ONE
+    batched network: layer 1 is a single GEMM against the two weight matrices side by side, layers 2 and 3 are batched
+    GEMMs over the twin dimension, forward and backward.  6 launches forward / 13 backward (7 when only the input
+    gradient is wanted: the actor step) instead of 14 / 26 for two nn.Sequential trunks; the same additions in the same
+    order inside every dot product's GEMM, so values agree with the two-trunk form to GEMM rounding."""
+
+    @staticmethod
+    def forward(ctx, h, a, w1a, b1a, w2a, b2a, w3a, b3a, w1b, b1b, w2b, b2b, w3b, b3b):
+        B, H = h.shape[0], w1a.shape[0]
+        x = torch.cat([h, a], dim=1)
+        W1, b1, W2, b2, W3, b3 = (_stacked(p, q) for p, q in ((w1a, w1b), (b1a, b1b), (w2a, w2b), (b2a, b2b), (w3a, w3b), (b3a, b3b)))
+        if W1.is_contiguous() and b1.is_contiguous():  # one GEMM for both first layers: (B, D) x (D, 2H)
+            z1 = torch.addmm(b1.reshape(2 * H), x, W1.reshape(2 * H, -1).t())
+            a1 = torch.relu_(z1).view(B, 2, H).transpose(0, 1)  # (2, B, H), row stride 2H
+        else:
+            a1 = torch.relu_(torch.baddbmm(b1.unsqueeze(1), x.unsqueeze(0).expand(2, B, -1), W1.transpose(1, 2)))
+        a2 = torch.relu_(torch.baddbmm(b2.unsqueeze(1), a1, W2.transpose(1, 2)))
+        q = torch.baddbmm(b3.unsqueeze(1), a2, W3.transpose(1, 2))  # (2, B, 1)
+        ctx.save_for_backward(x, a1, a2, W1, W2, W3)
+        ctx.n_h = h.shape[1]
+        return q[0], q[1]
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        x, a1, a2, W1, W2, W3 = ctx.saved_tensors
+        B = x.shape[0]
+        want_w = any(ctx.needs_input_grad[2:])
+        dq = torch.stack([g1, g2])                                       # (2, B, 1)
+        dz2 = torch.ops.aten.threshold_backward(torch.bmm(dq, W3), a2, 0)  # (2, B, H): ReLU gate of layer 2
+        dz1 = torch.ops.aten.threshold_backward(torch.bmm(dz2, W2), a1, 0)
+        dx = torch.bmm(dz1, W1).sum(0) if (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) else None
+        gw = [None] * 12
+        if want_w:
+            dW3, db3 = torch.bmm(dq.transpose(1, 2), a2), dq.sum(1)
+            dW2, db2 = torch.bmm(dz2.transpose(1, 2), a1), dz2.sum(1)
+            dW1, db1 = torch.bmm(dz1.transpose(1, 2), x.unsqueeze(0).expand(2, B, -1)), dz1.sum(1)
+            for t in (0, 1):
+                gw[6 * t:6 * t + 6] = [dW1[t], db1[t], dW2[t], db2[t], dW3[t], db3[t]]
+        dh = dx[:, :ctx.n_h] if dx is not None and ctx.needs_input_grad[0] else None
+        da = dx[:, ctx.n_h:] if dx is not None and ctx.needs_input_grad[1] else None
+        return (dh, da, *gw)
+
+
+def twin_q(h, a, q1, q2):
+    """(Q1(h, a), Q2(h, a)) for two modules.QFunction with 3-layer trunks (Linear, ReLU, Linear, ReLU, Linear)."""
+    t1, t2 = q1.trunk, q2.trunk
+    return _TwinQ.apply(h, a, t1[0].weight, t1[0].bias, t1[2].weight, t1[2].bias, t1[4].weight, t1[4].bias,
+                        t2[0].weight, t2[0].bias, t2[2].weight, t2[2].bias, t2[4].weight, t2[4].bias)

@@ -179,8 +179,21 @@ int augcl_gauss_head_backward(const float *raw, const float *noise, const float 
 /* SAC.calculate_target_Q (src/algorithms/sac.py:94-101):
  *   out = reward + (not_done * discount) * (min(tq1,tq2) - alpha * log_pi); alpha read from a device double. */
 int augcl_td_target_f32(const float *tq1, const float *tq2, const float *log_pi, const float *reward,
-                        const float *not_done, const double *alpha_dev, double discount, float *out, int B,
-                        augcl_stream_t stream);
+                        const float *not_done, const double *alpha_dev /* float64 scalar on the device */,
+                        int alpha_is_log /* 1: alpha_dev holds log_alpha (SAC.alpha = log_alpha.exp()) */,
+                        double discount, float *out, int B, augcl_stream_t stream);
+/* actor loss (src/algorithms/sac.py:119-131): out[0] = mean_i(alpha * log_pi_i - min(q1_i, q2_i)), alpha =
+ * float(exp(*log_alpha)); backward: d_log_pi = g alpha / B, -g/B to the smaller of (q1_i, q2_i) (ties: half each). */
+int augcl_actor_loss_forward(const float *log_pi, const float *q1, const float *q2, const double *log_alpha, float *out,
+                             int B, augcl_stream_t stream);
+int augcl_actor_loss_backward(const float *q1, const float *q2, const double *log_alpha, const float *g, float *d_log_pi,
+                              float *dq1, float *dq2, int B, augcl_stream_t stream);
+/* temperature update (sac.py:137-146) in one launch: alpha_loss = mean(alpha * (-log_pi - target_entropy)), its gradient
+ * with respect to the float64 log_alpha and torch.optim.Adam's step on that scalar, all on the device.
+ * state = double[4] {exp_avg, exp_avg_sq, step, grad}; mode bit 0 = loss + gradient into state[3], bit 1 = Adam step
+ * from state[3] (data parallel: average state[3] over ranks in between); out (may be NULL) = {alpha_loss, alpha}. */
+int augcl_alpha_step_f64(double *log_alpha, const float *log_pi, int B, double target_entropy, double lr, double beta1,
+                         double beta2, double eps, double *state, float *out, int mode, augcl_stream_t stream);
 /* Twin-Q loss (sac.py:108-110; svea.py:37-56 with S = 2 segments of one 2B batch against the same M targets):
  *   seg[s] = mse(q1[sM:(s+1)M], y) + mse(q2[...], y); out = {sum_s w[s] seg[s], seg[0..S)}; S <= 4; w on the host.
  * One workgroup, fixed-order tree sum (deterministic).  backward: dq = g_total * w[s] * 2 (q - y) / M. */

@@ -122,3 +122,78 @@ def test_flat_group_views_and_segments():
 def test_single_process_has_no_reducer(monkeypatch):
     monkeypatch.setenv("WORLD_SIZE", "1")
     assert apdist.init_from_env() is None and apdist.default_reducer() is None
+
+
+# ---- two optimiser groups, two steps, overlapped exchange ------------------------------------------------------------
+class _TorchAdamLaunch(flat.FlatAdam):
+    """FlatAdam with its ONE device-specific line (the fused HIP launch) replaced by the same arithmetic in torch, so that
+    everything around it -- bucket layout, the two-piece overlapped exchange, 1/world scaling, missing gradients -- runs
+    on the CPU under gloo exactly as it does on the GPUs under RCCL."""
+
+    def _launch_adam(self, a, b, step, scale):
+        g = self.group
+        grad = g.grad[a:b] * scale
+        b1, b2 = self.betas
+        self.exp_avg[a:b].mul_(b1).add_(grad, alpha=1 - b1)
+        self.exp_avg_sq[a:b].mul_(b2).addcmul_(grad, grad, value=1 - b2)
+        denom = (self.exp_avg_sq[a:b].sqrt() / (1 - b2 ** step) ** 0.5).add_(self.eps)
+        g.param[a:b].addcdiv_(self.exp_avg[a:b], denom, value=-self.lr / (1 - b1 ** step))
+
+
+def _two_group_trajectory(red, x, y, steps=2):
+    """A critic-like group (trunk under the cut + head h1) and an actor-like group (head h2 over the DETACHED trunk), each
+    with its own optimiser, `steps` updates in the order of SAC.update: critic step, then the actor step on the
+    updated trunk.  Returns the final parameters of both groups."""
+    torch.manual_seed(0)
+    m = TwoHeads()
+    ga = flat.FlatGroup([(n, p) for n, p in m.named_parameters() if not n.startswith("h2.")])
+    ga.mark_cut(lambda n: n.startswith("trunk."))
+    gb = flat.FlatGroup([(n, p) for n, p in m.named_parameters() if n.startswith("h2.")])
+    oa = _TorchAdamLaunch(ga, 1e-2, (0.9, 0.999), reducer=red)
+    ob = _TorchAdamLaunch(gb, 1e-2, (0.5, 0.999), reducer=red)
+    waits = []
+    if red is not None:  # count the exchanges and check they were issued asynchronously in two pieces
+        real = red.allreduce_sum_async
+        red.allreduce_sum_async = lambda t: (waits.append(t.numel()), real(t))[1]
+    for _ in range(steps):
+        t = m.trunk(x)
+        loss_a = nn.functional.mse_loss(m.h1(t), y)  # batch MEAN, like sac.py:109
+        oa.backward_step(loss_a, cut=[t])
+        loss_b = nn.functional.mse_loss(m.h2(m.trunk(x).detach()), y)
+        ob.backward_step(loss_b)
+    return ga.param.clone(), gb.param.clone(), waits, ga
+
+
+def _worker2(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    red = apdist.init_from_env(backend="gloo")
+    _, x, y = _model_and_data()
+    a, b = red.shard(x.shape[0])
+    pa, pb, waits, ga = _two_group_trajectory(red, x[a:b], y[a:b])
+    split = ga.slices[ga.names[ga.cut_index]][0]
+    assert waits == [ga.numel - split, split] * 2, waits  # per critic step: the heads' slice first, then the trunk's
+    apdist.seed_all(7)
+    q.put((rank, pa.numpy(), pb.numpy(), float(torch.rand(1)), apdist.sample_base(red, 4)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_groups_two_steps_overlapped_exchange_matches_single_process():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker2, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    _, x, y = _model_and_data()
+    want_a, want_b, _, _ = _two_group_trajectory(None, x, y)
+    for rank, pa, pb, draw, base in res:
+        np.testing.assert_allclose(pa, want_a.numpy(), rtol=2e-5, atol=1e-7)
+        np.testing.assert_allclose(pb, want_b.numpy(), rtol=2e-5, atol=1e-7)
+        assert base == 4 * rank  # rank r's first sample in the global batch (augmentations.set_sample_base)
+    np.testing.assert_array_equal(res[0][1], res[1][1])  # replicas stay bit-identical
+    assert res[0][3] != res[1][3]  # ... while their noise streams differ (dist.seed_all: seed + rank)

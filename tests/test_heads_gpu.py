@@ -105,3 +105,101 @@ def test_ln_tanh_matches_aten(cuda, B, D):
         scale = max(1.0, float(truth.abs().max()))
         e_aten, e_fused = float((aten - truth).abs().max()), float((fused - truth).abs().max())
         assert e_fused <= max(3.0 * e_aten, 3e-6 * scale), (e_fused, e_aten)
+
+
+@pytest.mark.parametrize("B,A,flat_layout", [(1, 1, True), (37, 6, True), (512, 6, True), (64, 2, False)])
+def test_twin_q_matches_two_trunks(cuda, B, A, flat_layout):
+    """Q1, Q2 (src/algorithms/modules.py:247-276) as ONE batched network (head_ops.twin_q: stacked views of the flat
+    parameter buffer, one GEMM for both first layers, batched GEMMs after) against the two nn.Sequential trunks:
+    values, every parameter gradient and the input gradients, judged against the same trunks in float64."""
+    from augcl_amd import flat
+    torch.manual_seed(B + A)
+    D, Hd = 100 + A, 1024
+    q1, q2 = m.QFunction(100, A, Hd).to(cuda), m.QFunction(100, A, Hd).to(cuda)
+    for p in list(q1.parameters()) + list(q2.parameters()):
+        p.data.add_(0.05 * torch.randn_like(p))  # non-zero biases
+    if flat_layout:  # what the agents do: every (Q1.x, Q2.x) pair at a fixed distance in one buffer
+        named = [(f"Q1.{n}", p) for n, p in q1.named_parameters()] + [(f"Q2.{n}", p) for n, p in q2.named_parameters()]
+        grp = flat.FlatGroup(flat.critic_order(named))
+        assert grp.names[:4] == ["Q1.trunk.0.weight", "Q2.trunk.0.weight", "Q1.trunk.0.bias", "Q2.trunk.0.bias"]
+        W = head_ops._stacked(q1.trunk[0].weight, q2.trunk[0].weight)
+        assert W.data_ptr() == q1.trunk[0].weight.data_ptr() and W.is_contiguous()  # a view, not a copy
+    g = torch.Generator(device=cuda).manual_seed(1)
+    h0 = torch.tanh(torch.randn(B, 100, device=cuda, generator=g))
+    a0 = torch.rand(B, A, device=cuda, generator=g) * 2 - 1
+    go1, go2 = torch.randn(B, 1, device=cuda, generator=g), torch.randn(B, 1, device=cuda, generator=g)
+    res = []
+    for mode in ("f64", "aten", "fused"):
+        dt = torch.float64 if mode == "f64" else torch.float32
+        ps = [p.detach().to(dt).clone().requires_grad_(True) for p in list(q1.parameters()) + list(q2.parameters())]
+        h, a = h0.to(dt).clone().requires_grad_(True), a0.to(dt).clone().requires_grad_(True)
+        if mode == "fused":
+            for p in list(q1.parameters()) + list(q2.parameters()):
+                p.grad = None
+            o1, o2 = head_ops.twin_q(h, a, q1, q2)
+        else:
+            def trunk(x, w):
+                x = torch.relu(F.linear(x, w[0], w[1]))
+                x = torch.relu(F.linear(x, w[2], w[3]))
+                return F.linear(x, w[4], w[5])
+            x = torch.cat([h, a], dim=1)
+            o1, o2 = trunk(x, ps[:6]), trunk(x, ps[6:])
+        ((o1 * go1.to(dt)).sum() + (o2 * go2.to(dt)).sum() * 0.7).backward()
+        grads = [p.grad for p in (list(q1.parameters()) + list(q2.parameters()) if mode == "fused" else ps)]
+        res.append([t.detach().double() for t in [o1, o2, h.grad, a.grad] + grads])
+    for i, (truth, aten, fused) in enumerate(zip(*res)):
+        scale = max(1e-3, float(truth.abs().max()))
+        e_aten, e_fused = float((aten - truth).abs().max()), float((fused - truth).abs().max())
+        assert e_fused <= max(3.0 * e_aten, 3e-6 * scale), (i, e_fused, e_aten)
+    # only the input gradient (the actor step: critic weights are not differentiated)
+    h = h0.clone().requires_grad_(True)
+    o1, o2 = head_ops.twin_q(h, a0, q1, q2)
+    (gh,) = torch.autograd.grad((o1 * go1).sum() + (o2 * go2).sum() * 0.7, [h])
+    assert torch.equal(gh.double(), res[2][2])  # the same launches as the full backward's input-gradient chain
+
+
+def test_actor_loss_and_alpha_step_match_aten(cuda):
+    """sac.py:119-146: the actor loss as one launch each way, and the temperature update (loss, gradient, Adam on the
+    float64 scalar) as ONE launch, against the literal ATen chain + torch.optim.Adam over several steps."""
+    from augcl_amd import flat
+    g = torch.Generator(device=cuda).manual_seed(2)
+    B = 256
+    lp0 = torch.randn(B, 1, device=cuda, generator=g) * 5
+    qa0 = torch.randn(B, 1, device=cuda, generator=g) * 20
+    qb0 = qa0 + torch.randn(B, 1, device=cuda, generator=g)
+    qb0[:5] = qa0[:5]  # ties: the gradient is split like ATen's minimum backward
+    log_alpha = torch.tensor(np.log(0.1), device=cuda, requires_grad=True)
+    res = []
+    for fused in (False, True):
+        lp, qa, qb = (t.clone().requires_grad_(True) for t in (lp0, qa0, qb0))
+        loss = head_ops.actor_loss(lp, qa, qb, log_alpha) if fused else (log_alpha.exp().detach() * lp - torch.min(qa, qb)).mean()
+        (loss * 1.3).backward()
+        res.append((loss.detach(), lp.grad, qa.grad, qb.grad))
+    for a, b in zip(*res):
+        assert float((a - b).abs().max()) <= 1e-6 * max(1.0, float(a.abs().max()))
+    assert log_alpha.grad is None
+    # temperature: 6 steps, fresh log_pi each
+    ref = torch.tensor(np.log(0.1), device=cuda, requires_grad=True)
+    opt = torch.optim.Adam([ref], lr=1e-4, betas=(0.5, 0.999))
+    mine = torch.tensor(np.log(0.1), device=cuda, requires_grad=True)
+    fopt = flat.ScalarAdam(mine, 1e-4, (0.5, 0.999))
+    for k in range(6):
+        lp = torch.randn(B, 1, device=cuda, generator=g) * 3 - 2
+        opt.zero_grad()
+        want_loss = (ref.exp() * (-lp - (-6.0)).detach()).mean()
+        want_alpha = float(ref.exp())
+        want_loss.backward()
+        opt.step()
+        loss, alpha = fopt.fused_step(lp, -6.0)
+        assert float(loss) == pytest.approx(float(want_loss), rel=2e-6, abs=1e-7) and float(alpha) == pytest.approx(want_alpha, rel=1e-6)
+        assert float(mine) == pytest.approx(float(ref), rel=1e-9), k
+    sd = fopt.state_dict()
+    opt2 = torch.optim.Adam([torch.nn.Parameter(mine.detach().cpu().clone())], lr=1e-4, betas=(0.5, 0.999))
+    opt2.load_state_dict(sd)  # torch's own Adam accepts the layout
+    assert float(sd["state"][0]["step"]) == 6.0
+    # td_target reads log_alpha directly
+    tq1, tq2 = qa0, qb0
+    rew, nd = torch.rand(B, 1, device=cuda, generator=g), torch.ones(B, 1, device=cuda)
+    a = head_ops.td_target(tq1, tq2, lp0, rew, nd, mine.exp(), 0.99)
+    b = head_ops.td_target(tq1, tq2, lp0, rew, nd, None, 0.99, log_alpha=mine)
+    assert torch.equal(a, b)
