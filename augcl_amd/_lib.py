@@ -74,7 +74,9 @@ _SIGS = {
     "augcl_gauss_head_forward": [_P, _P, _P, _P, _P, _P, _I, _I, _D, _D, _P],
     "augcl_gauss_head_backward": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _D, _D, _P],
     "augcl_ln_tanh_forward": [_P, _P, _P, _P, _I, _I, _D, _P],
-    "augcl_ln_tanh_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _D, _P],
+    "augcl_ln_tanh_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _D, _P],
+    "augcl_proj_ln_tanh_workspace_slabs": [_I, _I, _I],
+    "augcl_proj_ln_tanh_forward": [_P, _P, _P, _P, _P, _P, _P, _P, _SZ, _I, _I, _I, _D, _P],
     "augcl_td_target_f32": [_P, _P, _P, _P, _P, _P, _I, _D, _P, _I, _P],
     "augcl_actor_loss_forward": [_P, _P, _P, _P, _P, _I, _P],
     "augcl_actor_loss_backward": [_P, _P, _P, _P, _P, _P, _P, _I, _P],

@@ -149,7 +149,10 @@ class RLProjection(nn.Module):
     def forward(self, x):
         lin, ln = self.projection[0], self.projection[1]
         if head_ops._ok(x) and ln.weight.is_cuda and self.out_dim <= 256:
-            # Linear (hipBLASLt) then LayerNorm + tanh as one launch forward / two backward
+            out = head_ops.proj_ln_tanh(x, lin, ln)  # the whole projection: split-K MFMA GEMM + LN + tanh, 2 launches
+            if out is not None:
+                return out
+            # shapes the fused GEMM does not cover: Linear (hipBLASLt), then LayerNorm + tanh as one launch
             return head_ops.ln_tanh(lin(x), ln.weight, ln.bias, ln.eps)
         return self.projection(x)
 

@@ -314,24 +314,153 @@ __global__ __launch_bounds__(256) void k_ln_tanh_bwd(const float *__restrict__ x
     }
 }
 
-// column sums over the batch, fixed order: dgamma[j] = sum_rows g1x, dbeta[j] = sum_rows g1 (one thread per column pair)
-__global__ __launch_bounds__(256) void k_colsum2(const float *__restrict__ g1, const float *__restrict__ g1x,
-                                                 float *__restrict__ dbeta, float *__restrict__ dgamma, int B, int D)
+// column sums over the batch, fixed order: dgamma[j] = sum_rows g1x, dbeta[j] = sum_rows g1 and (optionally) the bias
+// gradient db[j] = sum_rows dx of the Linear in front.  One workgroup = 32 columns of one source; 8 row groups of 32
+// lanes each sum every 8th row, then the 8 partial sums are added in a fixed order (deterministic).  (The first version
+// walked all B rows with one thread per column: 30 us at B = 512 for 3 x 100 sums.)
+__global__ __launch_bounds__(256) void k_colsum3(const float *__restrict__ g1, const float *__restrict__ g1x,
+                                                 const float *__restrict__ dx, float *__restrict__ dbeta,
+                                                 float *__restrict__ dgamma, float *__restrict__ db, int B, int D)
 {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= 2 * D) return;
-    const float *src = j < D ? g1x : g1;
-    const int c = j < D ? j : j - D;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int r = 0;
-    for (; r + 3 < B; r += 4) {
-        s0 += src[(size_t)r * D + c];
-        s1 += src[(size_t)(r + 1) * D + c];
-        s2 += src[(size_t)(r + 2) * D + c];
-        s3 += src[(size_t)(r + 3) * D + c];
+    __shared__ float red[8][33];
+    const int which = blockIdx.y; // 0: g1x -> dgamma, 1: g1 -> dbeta, 2: dx -> db
+    const float *src = which == 0 ? g1x : which == 1 ? g1 : dx;
+    float *dst = which == 0 ? dgamma : which == 1 ? dbeta : db;
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31), rg = threadIdx.x >> 5;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < D) {
+        int r = rg;
+        for (; r + 8 < B; r += 16) {
+            s0 += src[(size_t)r * D + c];
+            s1 += src[(size_t)(r + 8) * D + c];
+        }
+        if (r < B) s0 += src[(size_t)r * D + c];
     }
-    for (; r < B; ++r) s0 += src[(size_t)r * D + c];
-    (j < D ? dgamma : dbeta)[c] = (s0 + s1) + (s2 + s3);
+    red[rg][threadIdx.x & 31] = s0 + s1;
+    __syncthreads();
+    if (rg == 0 && c < D) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x & 31];
+        dst[c] = t;
+    }
+}
+
+// ---- RLProjection as a whole (src/algorithms/modules.py:101-111): y = x W^T + b (K = 32*21*21 = 14112 -> N = 100), then
+// LayerNorm + tanh.  A skinny GEMM: hipBLASLt spends 35-44 us on it (one 16x16 macro-tile kernel); it is 29 MB of
+// activations against 1.8 GFLOP on the f32 MFMA pipe (N padded to 128), i.e. ~12 us of matrix-core time.
+// k_proj_partial: split-K over S slabs.  A workgroup owns 32 batch rows x all N (<= 128) outputs x one K slab and walks
+// the slab in steps of 32: the x tile (32 x 32) and the W tile (128 x 32) are fetched with fully coalesced float4 loads
+// (8 threads per 128-B row segment), parked in registers while the previous step's MFMAs run, then written to LDS
+// k-major so that a v_mfma_f32_32x32x2_f32 operand is one conflict-free ds_read_b32 per lane: A = W[n][k] (n on lanes),
+// B = x[m][k] (batch row on lanes).  Wave t owns output columns 32t..32t+31.  (Feeding the MFMAs straight from global
+// memory, each lane reading 16 B of its own row, measured 27 us: every 128-B line was pulled into L1 four times.)
+// Each slab's 32 x N partial goes to P[s][m][n]; k_proj_reduce_ln_tanh adds the slabs in slab order, the bias, and
+// applies LayerNorm + tanh: every sum in a fixed order -> bitwise reproducible.
+typedef float f32x16h __attribute__((ext_vector_type(16)));
+
+struct ProjArgs {
+    const float *x, *w;
+    float *part; // [S][M][N]
+    int M, K, N, S, iters; // iters = 32-wide k steps per slab
+};
+
+__global__ __launch_bounds__(256) void k_proj_partial(ProjArgs a)
+{
+    __shared__ float xs[32][33];   // [k][m]
+    __shared__ float wsm[32][129]; // [k][n]; reused as [m][n] for the transposed store at the end
+    const int mb = blockIdx.x, s = blockIdx.y, tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6, l31 = lane & 31, h = lane >> 5;
+    // loader role: thread -> (row, 16-B segment) of the 32-float step
+    const int lr = tid >> 3, lq = tid & 7;
+    const size_t kbase = (size_t)s * a.iters * 32;
+    const float4 *xg = reinterpret_cast<const float4 *>(a.x + (size_t)min(mb * 32 + lr, a.M - 1) * a.K + kbase) + lq;
+    const float4 *wg[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        wg[j] = reinterpret_cast<const float4 *>(a.w + (size_t)min(lr + 32 * j, a.N - 1) * a.K + kbase) + lq;
+    f32x16h acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    float4 xr = xg[0], wr[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wr[j] = wg[j][0];
+    for (int it = 0; it < a.iters; ++it) {
+        if (it) __syncthreads(); // the previous step's operand reads are done
+        {
+            const float xe[4] = {xr.x, xr.y, xr.z, xr.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xs[4 * lq + e][lr] = xe[e];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float we[4] = {wr[j].x, wr[j].y, wr[j].z, wr[j].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) wsm[4 * lq + e][lr + 32 * j] = we[e];
+            }
+        }
+        if (it + 1 < a.iters) { // next step's loads fly under this step's MFMAs
+            xr = xg[8 * (it + 1)];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wr[j] = wg[j][8 * (it + 1)];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kp = 0; kp < 16; ++kp)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wsm[2 * kp + h][32 * wv + l31], xs[2 * kp + h][l31], acc, 0, 0, 0);
+    }
+    __syncthreads();
+    float(*out)[129] = reinterpret_cast<float(*)[129]>(&wsm[0][0]); // [m][n], 32 x 129 floats: fits exactly
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[l31][32 * wv + (r & 3) + 8 * (r >> 2) + 4 * h] = acc[r];
+    __syncthreads();
+    const int rows = min(32, a.M - mb * 32);
+    float *dst = a.part + ((size_t)s * a.M + (size_t)mb * 32) * a.N;
+    for (int i = tid; i < rows * a.N; i += 256) {
+        const int mm = i / a.N, n = i - mm * a.N;
+        dst[i] = out[mm][n];
+    }
+}
+
+// y[m][n] = bias[n] + sum_s part[s][m][n] (slab order, four interleaved running sums combined in a fixed order),
+// z = tanh(LayerNorm(y) * gamma + beta).  Two rows per workgroup, 128 threads per row, one output column per thread:
+// the S loads of a thread are independent (all in flight at once) and coalesced across the row.  N <= 128.
+__global__ __launch_bounds__(256) void k_proj_reduce_ln_tanh(const float *__restrict__ part, const float *__restrict__ bias,
+                                                             const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                             float *__restrict__ y, float *__restrict__ z, int M, int N, int S,
+                                                             float eps)
+{
+    __shared__ float red[2][2][2]; // [row in block][wave of the row][sum | sum of squares]
+    const int half = threadIdx.x >> 7, j = threadIdx.x & 127, wv = (threadIdx.x >> 6) & 1;
+    const int row = blockIdx.x * 2 + half;
+    const bool live = row < M && j < N;
+    float t = 0.0f;
+    if (live) {
+        const float *p = part + (size_t)row * N + j;
+        const size_t st = (size_t)M * N;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int k = 0;
+        for (; k + 3 < S; k += 4) {
+            s0 += p[(size_t)k * st];
+            s1 += p[(size_t)(k + 1) * st];
+            s2 += p[(size_t)(k + 2) * st];
+            s3 += p[(size_t)(k + 3) * st];
+        }
+        for (; k < S; ++k) s0 += p[(size_t)k * st];
+        t = ((s0 + s1) + (s2 + s3)) + bias[j];
+        y[(size_t)row * N + j] = t;
+    }
+    float sum = live ? t : 0.0f;
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    if ((threadIdx.x & 63) == 0) red[half][wv][0] = sum;
+    __syncthreads();
+    const float mean = (red[half][0][0] + red[half][1][0]) / (float)N;
+    const float d = live ? t - mean : 0.0f;
+    float q = d * d;
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    if ((threadIdx.x & 63) == 0) red[half][wv][1] = q;
+    __syncthreads();
+    const float rstd = 1.0f / sqrtf((red[half][0][1] + red[half][1][1]) / (float)N + eps);
+    if (live) z[(size_t)row * N + j] = tanhf((d * rstd) * gamma[j] + beta[j]);
 }
 
 } // namespace augcl
@@ -455,7 +584,8 @@ int augcl_ln_tanh_forward(const float *x, const float *gamma, const float *beta,
 }
 
 int augcl_ln_tanh_backward(const float *x, const float *gamma, const float *y, const float *gy, float *dx, float *dgamma,
-                           float *dbeta, float *workspace /* 2*B*D floats */, int B, int D, double eps, augcl_stream_t stream)
+                           float *dbeta, float *dbias, float *workspace /* 2*B*D floats */, int B, int D, double eps,
+                           augcl_stream_t stream)
 {
     const char *name = "augcl_ln_tanh_backward";
     AUGCL_REQUIRE(B >= 1 && D >= 1 && D <= 256, "%s: bad shape (D <= 256)", name);
@@ -463,7 +593,41 @@ int augcl_ln_tanh_backward(const float *x, const float *gamma, const float *y, c
     float *g1 = workspace, *g1x = workspace + (size_t)B * D;
     hipStream_t s = as_stream(stream);
     hipLaunchKernelGGL(k_ln_tanh_bwd, dim3((B + 3) / 4), dim3(256), 0, s, x, gamma, y, gy, dx, g1, g1x, B, D, (float)eps);
-    hipLaunchKernelGGL(k_colsum2, dim3((2 * D + 255) / 256), dim3(256), 0, s, g1, g1x, dbeta, dgamma, B, D);
+    hipLaunchKernelGGL(k_colsum3, dim3((D + 31) / 32, dbias ? 3 : 2), dim3(256), 0, s, g1, g1x, dx, dbeta, dgamma, dbias, B, D);
+    return augcl::check_launch(name);
+}
+
+int augcl_proj_ln_tanh_workspace_slabs(int M, int K, int N)
+{
+    if (M < 1 || N < 1 || N > 128 || K < 32 || (K & 31)) return 0;
+    const int steps = K / 32;
+    const int cand[8] = {63, 49, 32, 21, 16, 9, 8, 7};
+    const int want = M >= 1024 ? 24 : 64; // wave tasks = (M/32) * S * 4: about 4 per SIMD without an oversized workspace
+    int best = 0;
+    for (int i = 0; i < 8; ++i) {
+        if (steps % cand[i] != 0) continue;
+        if (cand[i] <= want) return cand[i]; // the largest admissible slab count within the budget
+        best = cand[i];                      // otherwise the smallest admissible one
+    }
+    return best;
+}
+
+int augcl_proj_ln_tanh_forward(const float *x, const float *w, const float *bias, const float *gamma, const float *beta,
+                               float *y, float *z, float *workspace, size_t workspace_bytes, int M, int K, int N, double eps,
+                               augcl_stream_t stream)
+{
+    const char *name = "augcl_proj_ln_tanh_forward";
+    const int S = augcl_proj_ln_tanh_workspace_slabs(M, K, N);
+    AUGCL_REQUIRE(S > 0, "%s: shape (M=%d, K=%d, N=%d) not covered (N <= 128, K/32 divisible by one of 63,49,32,21,16,9,8,7)", name, M, K, N);
+    AUGCL_REQUIRE(x && w && bias && gamma && beta && y && z && workspace, "%s: null tensor", name);
+    AUGCL_REQUIRE(aligned16(x) && aligned16(w), "%s: x and w must be 16-byte aligned", name);
+    AUGCL_REQUIRE(workspace_bytes >= (size_t)S * M * N * sizeof(float), "%s: workspace too small (%zu < %zu)", name,
+                  workspace_bytes, (size_t)S * M * N * sizeof(float));
+    ProjArgs a{x, w, workspace, M, K, N, S, K / 32 / S};
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(k_proj_partial, dim3((M + 31) / 32, S), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_proj_reduce_ln_tanh, dim3((M + 1) / 2), dim3(256), 0, s, workspace, bias, gamma, beta, y, z, M, N, S,
+                       (float)eps);
     return augcl::check_launch(name);
 }
 

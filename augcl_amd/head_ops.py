@@ -72,8 +72,58 @@ class _LnTanh(torch.autograd.Function):
         dgb = torch.empty((2, D), dtype=torch.float32, device=x.device)
         ws = torch.empty(2 * B * D, dtype=torch.float32, device=x.device)
         _lib.call("augcl_ln_tanh_backward", x.data_ptr(), gamma.data_ptr(), y.data_ptr(), gy.data_ptr(), dx.data_ptr(),
-                  dgb[0].data_ptr(), dgb[1].data_ptr(), ws.data_ptr(), B, D, ctx.eps, _lib.current_stream(x.device))
+                  dgb[0].data_ptr(), dgb[1].data_ptr(), None, ws.data_ptr(), B, D, ctx.eps, _lib.current_stream(x.device))
         return dx, dgb[0], dgb[1], None
+
+
+class _ProjLnTanh(torch.autograd.Function):
+    """RLProjection (src/algorithms/modules.py:101-111) as one node: forward = split-K f32-MFMA GEMM + (slab reduction,
+    bias, LayerNorm, tanh) in two launches (augcl_proj_ln_tanh_forward); backward = the fused LN/tanh backward, whose
+    column-sum launch also yields the Linear's bias gradient, and two library GEMMs (dW, and dx when it is wanted)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, gamma, beta, eps, slabs):
+        x = x.contiguous()
+        M, K = x.shape
+        N = w.shape[0]
+        yz = torch.empty((2, M, N), dtype=torch.float32, device=x.device)
+        ws = torch.empty(slabs * M * N, dtype=torch.float32, device=x.device)
+        _lib.call("augcl_proj_ln_tanh_forward", x.data_ptr(), w.data_ptr(), b.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                  yz[0].data_ptr(), yz[1].data_ptr(), ws.data_ptr(), ws.numel() * 4, M, K, N, float(eps),
+                  _lib.current_stream(x.device))
+        ctx.save_for_backward(x, w, gamma, yz)
+        ctx.eps = float(eps)
+        return yz[1]
+
+    @staticmethod
+    def backward(ctx, gz):
+        x, w, gamma, yz = ctx.saved_tensors
+        M, N = yz.shape[1], yz.shape[2]
+        gz = gz.contiguous()
+        dy = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        small = torch.empty((3, N), dtype=torch.float32, device=x.device)  # dgamma, dbeta, dbias
+        ws = torch.empty(2 * M * N, dtype=torch.float32, device=x.device)
+        _lib.call("augcl_ln_tanh_backward", yz[0].data_ptr(), gamma.data_ptr(), yz[1].data_ptr(), gz.data_ptr(), dy.data_ptr(),
+                  small[0].data_ptr(), small[1].data_ptr(), small[2].data_ptr(), ws.data_ptr(), M, N, ctx.eps,
+                  _lib.current_stream(x.device))
+        dw = dy.t().mm(x) if ctx.needs_input_grad[1] else None
+        dx = dy.mm(w) if ctx.needs_input_grad[0] else None
+        return dx, dw, small[2], small[0], small[1], None, None
+
+
+def proj_ln_tanh(x, lin, ln):
+    """tanh(LayerNorm(Linear(x))) for an nn.Linear / nn.LayerNorm pair, or None when the fused kernels do not cover the
+    shape (the caller then runs the Linear through the GEMM library and `ln_tanh`)."""
+    if lin.bias is None or x.dim() != 2 or not x.is_contiguous() and x.stride(-1) != 1:
+        return None
+    M, K = x.shape
+    N = lin.weight.shape[0]
+    if not lin.weight.is_contiguous() or x.data_ptr() % 16 or lin.weight.data_ptr() % 16:
+        return None
+    slabs = _lib.load().augcl_proj_ln_tanh_workspace_slabs(int(M), int(K), int(N))
+    if slabs <= 0:
+        return None
+    return _ProjLnTanh.apply(x, lin.weight, lin.bias, ln.weight, ln.bias, ln.eps, slabs)
 
 
 def ln_tanh(x, gamma, beta, eps=1e-5):

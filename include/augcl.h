@@ -207,7 +207,16 @@ int augcl_q_loss_backward(const float *q1, const float *q2, const float *y, cons
 int augcl_ln_tanh_forward(const float *x, const float *gamma, const float *beta, float *y, int B, int D, double eps,
                           augcl_stream_t stream);
 int augcl_ln_tanh_backward(const float *x, const float *gamma, const float *y, const float *gy, float *dx, float *dgamma,
-                           float *dbeta, float *workspace, int B, int D, double eps, augcl_stream_t stream);
+                           float *dbeta, float *dbias /* may be NULL: column sums of dx = the bias gradient of the Linear in front */,
+                           float *workspace /* 2*B*D floats */, int B, int D, double eps, augcl_stream_t stream);
+/* RLProjection forward as a whole (src/algorithms/modules.py:101-111): y = x W^T + bias on the f32 MFMA pipe (split-K, every
+ * partial sum added in a fixed order: bitwise reproducible), z = tanh(LayerNorm(y) * gamma + beta).  x (M,K), w (N,K)
+ * row-major, N <= 128, K a multiple of 32 with K/32 divisible by one of {63,49,32,21,16,9,8,7} (14112 = 32*21*21 is).
+ * workspace: slabs(M,K,N) * M * N floats; augcl_proj_ln_tanh_workspace_slabs returns 0 for an uncovered shape. */
+int augcl_proj_ln_tanh_workspace_slabs(int M, int K, int N);
+int augcl_proj_ln_tanh_forward(const float *x, const float *w, const float *bias, const float *gamma, const float *beta,
+                               float *y, float *z, float *workspace, size_t workspace_bytes, int M, int K, int N, double eps,
+                               augcl_stream_t stream);
 
 /* ---- target-network update: utils.soft_update_params (src/utils.py:76-78), called from
  * SAC.soft_update_critic_target (src/algorithms/sac.py:148-153):

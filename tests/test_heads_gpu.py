@@ -203,3 +203,40 @@ def test_actor_loss_and_alpha_step_match_aten(cuda):
     a = head_ops.td_target(tq1, tq2, lp0, rew, nd, mine.exp(), 0.99)
     b = head_ops.td_target(tq1, tq2, lp0, rew, nd, None, 0.99, log_alpha=mine)
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("M", [1, 2, 33, 256, 512, 1024])
+def test_projection_fused_gemm_ln_tanh(cuda, M):
+    """RLProjection (modules.py:101-111) through the split-K MFMA GEMM + LN/tanh kernels: values and all five gradients
+    against the float64 chain, as close as the ATen float32 chain; bitwise reproducible run to run."""
+    torch.manual_seed(M)
+    K, N = 14112, 100
+    proj = m.RLProjection((K,), N).to(cuda)
+    proj.projection[0].bias.data.normal_(0, 0.1)
+    proj.projection[1].weight.data.uniform_(0.5, 1.5)
+    proj.projection[1].bias.data.normal_(0, 0.1)
+    lin, ln = proj.projection[0], proj.projection[1]
+    g = torch.Generator(device=cuda).manual_seed(7)
+    x0 = torch.relu(torch.randn(M, K, device=cuda, generator=g)) * 0.2  # CNN features: non-negative, sparse-ish
+    gz = torch.randn(M, N, device=cuda, generator=g)
+    assert head_ops.proj_ln_tanh(x0, lin, ln) is not None  # this shape is covered
+    res = []
+    for mode in ("f64", "aten", "fused"):
+        dt = torch.float64 if mode == "f64" else torch.float32
+        x = x0.to(dt).clone().requires_grad_(True)
+        ps = [p.detach().to(dt).clone().requires_grad_(True) for p in (lin.weight, lin.bias, ln.weight, ln.bias)]
+        if mode == "fused":
+            for p in proj.parameters():
+                p.grad = None
+            z = proj(x)
+        else:
+            z = torch.tanh(F.layer_norm(F.linear(x, ps[0], ps[1]), (N,), ps[2], ps[3], 1e-5))
+        (z * gz.to(dt)).sum().backward()
+        grads = [p.grad for p in ((lin.weight, lin.bias, ln.weight, ln.bias) if mode == "fused" else ps)]
+        res.append([t.detach().double() for t in [z, x.grad] + grads])
+    for i, (truth, aten, fused) in enumerate(zip(*res)):
+        scale = max(1e-6, float(truth.abs().max()))
+        e_aten, e_fused = float((aten - truth).abs().max()), float((fused - truth).abs().max())
+        assert e_fused <= max(3.0 * e_aten, 3e-6 * scale), (i, e_fused, e_aten, scale)
+    with torch.no_grad():
+        assert torch.equal(proj(x0), proj(x0))  # fixed-order split-K: the same bits every time

@@ -363,12 +363,17 @@ def test_update_against_f64_referee(cuda, monkeypatch, algo, data_aug, A, B, hpo
     watched = [agent.critic.encoder.shared_cnn] + ([agent.critic_weak.encoder.shared_cnn] if algo == "augcl" else [])
     hooks = [mod.register_forward_hook(lambda _m, _i, out: seen_feat.append(out.detach())) for mod in watched]
     rec = GateRecorder()
-    rec.watch("Q1", agent.critic.Q1.trunk)
-    rec.watch("Q2", agent.critic.Q2.trunk)
     rec.watch("mlp", agent.actor.mlp)
-    if algo == "augcl":
-        rec.watch("wQ1", agent.critic_weak.Q1.trunk)
-        rec.watch("wQ2", agent.critic_weak.Q2.trunk)
+    # the twin Q trunks run as one batched network (head_ops.twin_q) whose two ReLUs are in-place torch.relu_ calls:
+    # layer 1 on a (B, 2H) tensor [Q1 | Q2], layer 2 on (2, B, H); record every call's gates in order
+    twin_relu, real_relu_ = [], torch.relu_
+
+    def relu_rec(t):
+        out = real_relu_(t)
+        twin_relu.append((out > 0).cpu())
+        return out
+
+    monkeypatch.setattr(torch, "relu_", relu_rec)
 
     calls = {"shift": 0}
 
@@ -409,21 +414,31 @@ def test_update_against_f64_referee(cuda, monkeypatch, algo, data_aug, A, B, hpo
     got = torch.cat([f.reshape(-1, 32, 21, 21) for f in seen_feat])[:sum(f.shape[0] for f in want_feats)]
     assert torch.equal(got, torch.cat(want_feats)), "encoder features inside update() differ from the C-ABI forward"
 
-    # assemble the gate sets per oracle pass
-    def head_gates(tag, call, rows=None):
-        g = [rec.calls[(tag, i)][call] for i in (0, 1)]
-        return g if rows is None else [t[rows[0]:rows[1]] for t in g]
+    # assemble the gate sets per oracle pass.  twin_q calls in update() order: the target pass(es) (no gradient: not
+    # forced), then the critic passes (AugCL: weak first), last the actor step's critic call.
+    Hd = hp["hidden_dim"]
+    twin = []
+    for l1, l2 in zip(twin_relu[0::2], twin_relu[1::2]):
+        rows = l1.shape[0]
+        twin.append(([l1.view(rows, 2, Hd)[:, t] for t in (0, 1)], [l2[t] for t in (0, 1)]))  # per trunk: layer-1, layer-2 gates
+
+    def q_gates(call, rows=None):
+        l1, l2 = twin[call]
+        cut = (lambda t: t) if rows is None else (lambda t: t[rows[0]:rows[1]])
+        return {"Q1": [cut(l1[0]), cut(l2[0])], "Q2": [cut(l1[1]), cut(l2[1])]}
 
     n_pass = len(critic_inputs)
-    forced = {"critic": [], "actor": {"mlp": [rec.calls[("mlp", i)][-1] for i in (0, 1)]}}
-    one_call = algo == "svea"  # SVEA's two halves go through the critic as ONE 2B batch
-    for k in range(n_pass):
-        rows = (k * B, (k + 1) * B) if one_call else None
-        call = 0 if one_call else k
-        forced["critic"].append({"cnn": crit_cnn[k][0], "Q1": head_gates("Q1", call, rows), "Q2": head_gates("Q2", call, rows)})
-    forced["actor_q"] = {"Q1": head_gates("Q1", -1), "Q2": head_gates("Q2", -1)}
+    first = M if algo == "drq" else 1               # index of the first gradient-carrying twin_q call
+    forced = {"critic": [], "actor": {"mlp": [rec.calls[("mlp", i)][-1] for i in (0, 1)]}, "actor_q": q_gates(-1)}
     if algo == "augcl":
-        forced["weak"] = [{"cnn": weak_cnn[0][0], "Q1": head_gates("wQ1", 0), "Q2": head_gates("wQ2", 0)}]
+        forced["weak"] = [dict(cnn=weak_cnn[0][0], **q_gates(first))]
+        first += 1
+    for k in range(n_pass):
+        if algo == "svea":  # SVEA's two halves go through the critic as ONE 2B batch
+            forced["critic"].append(dict(cnn=crit_cnn[k][0], **q_gates(first, (k * B, (k + 1) * B))))
+        else:
+            forced["critic"].append(dict(cnn=crit_cnn[k][0], **q_gates(first + k)))
+    assert len(twin) == first + (1 if algo == "svea" else n_pass) + 1, len(twin)
 
     # Between the critic and the actor phase the forced referee takes over the product's critic parameters: Adam's
     # first step is lr*sign(g), so the handful of elements whose gradient is ~0 land 2*lr apart in ANY two float32/64
