@@ -50,8 +50,18 @@ class SAC(object):
                         critic_beta=args.critic_beta, alpha_lr=args.alpha_lr, alpha_beta=args.alpha_beta)
         self._build_groups()
         self._graph = None
+        self._act = None
         self.train()
         self.critic_target.train()
+
+    def __getstate__(self):
+        """torch.save(agent) (src/train.py:229): captured graphs are process-local, the modes they belong to survive."""
+        st = dict(self.__dict__)
+        if st.get("_graph") is not None:
+            st["_graph"] = dict(st["_graph"], graphs={}, static=None, pool=None, seen=0)
+        if st.get("_act") is not None:
+            st["_act"] = dict(x=None, graphs={}, pinned=None)
+        return st
 
     # ---- flat groups / optimisers ------------------------------------------------------------
     def _build_groups(self):
@@ -94,16 +104,56 @@ class SAC(object):
         return _obs.unsqueeze(0).contiguous()
 
     def select_action(self, obs):
+        """sac.py:73-78"""
+        if self._act is not None:
+            return self._act_replay(obs, sample=False)
         _obs = self._obs_to_input(obs)
         with torch.no_grad():
             mu, _, _, _ = self.actor(_obs, compute_pi=False, compute_log_pi=False)
         return mu.cpu().data.numpy().flatten()
 
     def sample_action(self, obs):
+        """sac.py:87-92"""
+        if self._act is not None:
+            return self._act_replay(obs, sample=True)
         _obs = self._obs_to_input(obs)
         with torch.no_grad():
             mu, pi, _, _ = self.actor(_obs, compute_log_pi=False)
         return pi.cpu().data.numpy().flatten()
+
+    def enable_action_graphs(self):
+        """Batch-1 acting (one call per environment step, sac.py:73-92) as a captured hipGraph: the observation is copied
+        into a static device tensor, ONE graph launch replays the conv stack, projection, policy MLP and head (~20
+        kernels whose CPU launch cost dominates at batch 1), the action comes back through a pinned buffer.  The
+        graphs read the live parameter buffers, so training in between needs no re-capture."""
+        if self._act is None:
+            self._act = dict(x=None, graphs={}, pinned=None)
+
+    def _act_replay(self, obs, sample):
+        A = self._act
+        src = torch.as_tensor(np.asarray(obs))
+        if A["x"] is None or tuple(A["x"].shape[1:]) != tuple(src.shape):
+            A.update(x=torch.zeros((1, *src.shape), dtype=torch.float32, device=self.device), graphs={},
+                     pinned=torch.empty((1, *src.shape), dtype=src.dtype).pin_memory())
+        A["pinned"][0].copy_(src)
+        A["x"].copy_(A["pinned"], non_blocking=True)  # H2D + the .float() of _obs_to_input on the device
+        if sample not in A["graphs"]:
+            def run():
+                with torch.no_grad():
+                    mu, pi, _, _ = self.actor(A["x"], compute_pi=sample, compute_log_pi=False)
+                return pi if sample else mu
+            for _ in range(2):  # eager warm-up: lazy initialisation (GEMM heuristics) must not happen inside a capture
+                run()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = run()
+            A["graphs"][sample] = (g, out, torch.empty(out.shape, dtype=out.dtype).pin_memory())
+        g, out, host = A["graphs"][sample]
+        g.replay()
+        host.copy_(out, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        return host.numpy().flatten().copy()
 
     # ---- learning ----------------------------------------------------------------------------
     def calculate_target_Q(self, next_obs, reward, not_done):

@@ -90,3 +90,30 @@ def run(dev, dist, world, rank, steps=20, warmup=4, B=256, A=6, algo="svea", dat
             "dtype": "f32" if precision == "f32" else "bf16 conv stack (f32 accumulate, f32 heads/optimizer)",
             "approx_TFLOP/s_per_gpu": flops * steps / wall / 1e12, "encoder_backend": "hip",
             "hip_graph": bool(graph), "world": world}
+
+
+def action_latency(dev, A=6, calls=300):
+    """Batch-1 select_action (src/algorithms/sac.py:73-78: one host frame stack in, one action out) in microseconds per
+    call, eager and replayed from the captured hipGraph (SAC.enable_action_graphs)."""
+    import numpy as np
+
+    from . import utils as au
+    from .algorithms import make_agent
+    hp = dict(discount=0.99, critic_tau=0.01, encoder_tau=0.05, actor_update_freq=2, critic_target_update_freq=2,
+              num_shared_layers=11, num_head_layers=0, num_filters=32, projection_dim=100, hidden_dim=1024,
+              actor_log_std_min=-10.0, actor_log_std_max=2.0, init_temperature=0.1, actor_lr=1e-3, actor_beta=0.9,
+              critic_lr=1e-3, critic_beta=0.9, alpha_lr=1e-4, alpha_beta=0.5, svea_alpha=0.5, svea_beta=0.5, drq_k=1, drq_m=1)
+    agent = make_agent((9, 84, 84), (A,), au.dotdict(algorithm="sac", data_aug="identity", aug_params=None, **hp))
+    obs = np.random.RandomState(0).randint(0, 256, (9, 84, 84)).astype(np.uint8)
+    out = {}
+    for mode in ("eager", "graph"):
+        if mode == "graph":
+            agent.enable_action_graphs()
+        for _ in range(20):
+            agent.select_action(obs)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(calls):
+            agent.select_action(obs)
+        out[mode] = (time.perf_counter() - t0) / calls * 1e6
+    return out

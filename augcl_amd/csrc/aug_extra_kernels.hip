@@ -104,15 +104,70 @@ __global__ __launch_bounds__(256) void k_splice(const float *__restrict__ x, con
     }
 }
 
+// VideoWrapper._interpolate_bg (src/env/wrappers.py:336-340): the video frame as float / 255, F.interpolate(bilinear,
+// align_corners=False) to the observation size, * 255, .byte().  The trailing uint8 cast TRUNCATES, so matching the
+// reference bit for bit needs ATen's float32 arithmetic operation by operation (pinned against the reference's own
+// function run on this torch build, tests/golden/make_golden.py:make_eval): source coordinate = fma(scale, dst + 0.5,
+// -0.5) clamped at 0 with scale = float(in) / float(out), weights (1 - l, l) with l = coordinate - floor, and
+// w0 * a + w1 * b evaluated as fma(w0, a, w1 * b) on both axes, horizontal first.  This file is compiled with
+// -ffp-contract=off: the fmas below are exactly the ones written.
+struct BgAxis {
+    int i0, i1;
+    float l0, l1;
+};
+__device__ __forceinline__ BgAxis bg_axis(int d, int n_in, int n_out, float scale)
+{
+    BgAxis a;
+    if (n_in == n_out) { // ATen: identical sizes copy through (index d, weights 1 / 0)
+        a.i0 = a.i1 = d;
+        a.l0 = 1.0f;
+        a.l1 = 0.0f;
+        return a;
+    }
+    float src = __builtin_fmaf(scale, (float)d + 0.5f, -0.5f);
+    src = src < 0.0f ? 0.0f : src;
+    a.i0 = min((int)floorf(src), n_in - 1);
+    a.i1 = min(a.i0 + 1, n_in - 1);
+    a.l1 = fminf(fmaxf(src - (float)a.i0, 0.0f), 1.0f);
+    a.l0 = 1.0f - a.l1;
+    return a;
+}
+__device__ __forceinline__ uint8_t bg_pixel(const uint8_t *__restrict__ plane, int Wb, const BgAxis &ay, const BgAxis &ax)
+{
+    const float p00 = (float)plane[ay.i0 * Wb + ax.i0] / 255.0f, p01 = (float)plane[ay.i0 * Wb + ax.i1] / 255.0f;
+    const float p10 = (float)plane[ay.i1 * Wb + ax.i0] / 255.0f, p11 = (float)plane[ay.i1 * Wb + ax.i1] / 255.0f;
+    const float top = __builtin_fmaf(ax.l0, p00, ax.l1 * p01);
+    const float bot = __builtin_fmaf(ax.l0, p10, ax.l1 * p11);
+    return (uint8_t)(__builtin_fmaf(ay.l0, top, ay.l1 * bot) * 255.0f);
+}
+
+__global__ __launch_bounds__(256) void k_interpolate_bg(const uint8_t *__restrict__ bg, uint8_t *__restrict__ out, int Hb,
+                                                        int Wb, int H, int W)
+{
+    const size_t f = blockIdx.y;
+    const float sh = (float)Hb / (float)H, sw = (float)Wb / (float)W;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < H * W; p += gridDim.x * 256) {
+        const int y = p / W, x = p - y * W;
+        const BgAxis ay = bg_axis(y, Hb, H, sh), ax = bg_axis(x, Wb, W, sw);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out[(f * 3 + c) * H * W + p] = bg_pixel(bg + (f * 3 + c) * (size_t)Hb * Wb, Wb, ay, ax);
+    }
+}
+
 // do_green_screen (src/env/wrappers.py:209-260): a pixel whose HSV (python colorsys arithmetic in DOUBLE, as the
 // reference's per-pixel Python loop computes it) falls in h*360 in [100,185], s*255 in [80,255], v*255 in [70,255]
 // is replaced by the background pixel.  uint8 in, uint8 out: bit-exact.
+// RESIZE: bg is the raw (3,Hb,Wb) video frame and the keyed-in pixel is _interpolate_bg's value computed on the spot
+// (VideoWrapper._greenscreen = _interpolate_bg + do_green_screen, wrappers.py:342-348, in one launch).
+template <bool RESIZE>
 __global__ __launch_bounds__(256) void k_green_screen(const uint8_t *__restrict__ x, const uint8_t *__restrict__ bg,
-                                                      uint8_t *__restrict__ out, int n /* H*W */)
+                                                      uint8_t *__restrict__ out, int n /* H*W */, int W, int Hb, int Wb)
 {
     const size_t f = blockIdx.y; // frame
-    const uint8_t *px = x + f * 3 * n, *pb = bg + f * 3 * n;
+    const uint8_t *px = x + f * 3 * n, *pb = bg + f * 3 * (RESIZE ? (size_t)Hb * Wb : (size_t)n);
     uint8_t *po = out + f * 3 * n;
+    const int H = n / W;
+    const float sh = RESIZE ? (float)Hb / (float)H : 1.0f, sw = RESIZE ? (float)Wb / (float)W : 1.0f;
     for (int p = blockIdx.x * 256 + threadIdx.x; p < n; p += gridDim.x * 256) {
         const uint8_t r8 = px[p], g8 = px[n + p], b8 = px[2 * n + p];
         const double r = r8 / 255.0, g = g8 / 255.0, b = b8 / 255.0;
@@ -130,9 +185,21 @@ __global__ __launch_bounds__(256) void k_green_screen(const uint8_t *__restrict_
         }
         const double hh = h * 360, ss = s * 255, vv = maxc * 255;
         const bool key = 100 <= hh && hh <= 185 && 80 <= ss && ss <= 255 && 70 <= vv && vv <= 255;
-        po[p] = key ? pb[p] : r8;
-        po[n + p] = key ? pb[n + p] : g8;
-        po[2 * n + p] = key ? pb[2 * n + p] : b8;
+        uint8_t k0 = r8, k1 = g8, k2 = b8;
+        if (key) {
+            if (RESIZE) {
+                const int y = p / W, xx = p - y * W;
+                const BgAxis ay = bg_axis(y, Hb, H, sh), ax = bg_axis(xx, Wb, W, sw);
+                k0 = bg_pixel(pb, Wb, ay, ax);
+                k1 = bg_pixel(pb + (size_t)Hb * Wb, Wb, ay, ax);
+                k2 = bg_pixel(pb + 2 * (size_t)Hb * Wb, Wb, ay, ax);
+            } else {
+                k0 = pb[p]; k1 = pb[n + p]; k2 = pb[2 * n + p];
+            }
+        }
+        po[p] = k0;
+        po[n + p] = k1;
+        po[2 * n + p] = k2;
     }
 }
 
@@ -204,7 +271,32 @@ int augcl_green_screen_u8(const uint8_t *x, const uint8_t *bg, uint8_t *out, int
     AUGCL_REQUIRE(x && bg && out, "%s: null tensor", name);
     const int n = H * W;
     const int gx = (n + 255) / 256 < 64 ? (n + 255) / 256 : 64;
-    hipLaunchKernelGGL(k_green_screen, dim3(gx, N), dim3(256), 0, as_stream(stream), x, bg, out, n);
+    hipLaunchKernelGGL(k_green_screen<false>, dim3(gx, N), dim3(256), 0, as_stream(stream), x, bg, out, n, W, 0, 0);
+    return augcl::check_launch(name);
+}
+
+int augcl_interpolate_bg_u8(const uint8_t *bg, uint8_t *out, int N, int Hb, int Wb, int H, int W, augcl_stream_t stream)
+{
+    const char *name = "augcl_interpolate_bg_u8";
+    AUGCL_REQUIRE(N >= 0 && H > 0 && W > 0 && Hb > 0 && Wb > 0, "%s: bad shape", name);
+    if (N == 0) return AUGCL_OK;
+    AUGCL_REQUIRE(bg && out, "%s: null tensor", name);
+    const int n = H * W;
+    const int gx = (n + 255) / 256 < 64 ? (n + 255) / 256 : 64;
+    hipLaunchKernelGGL(k_interpolate_bg, dim3(gx, N), dim3(256), 0, as_stream(stream), bg, out, Hb, Wb, H, W);
+    return augcl::check_launch(name);
+}
+
+int augcl_green_screen_resize_u8(const uint8_t *x, const uint8_t *bg_raw, uint8_t *out, int N, int H, int W, int Hb, int Wb,
+                                 augcl_stream_t stream)
+{
+    const char *name = "augcl_green_screen_resize_u8";
+    AUGCL_REQUIRE(N >= 0 && H > 0 && W > 0 && Hb > 0 && Wb > 0, "%s: bad shape", name);
+    if (N == 0) return AUGCL_OK;
+    AUGCL_REQUIRE(x && bg_raw && out, "%s: null tensor", name);
+    const int n = H * W;
+    const int gx = (n + 255) / 256 < 64 ? (n + 255) / 256 : 64;
+    hipLaunchKernelGGL(k_green_screen<true>, dim3(gx, N), dim3(256), 0, as_stream(stream), x, bg_raw, out, n, W, Hb, Wb);
     return augcl::check_launch(name);
 }
 

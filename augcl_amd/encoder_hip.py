@@ -13,6 +13,10 @@ def _workspace(dev, c_in, count=1):
     """count > 1: one slice per layer, so the stack backward can reduce every layer's slabs in one batched launch."""
     key = (dev, c_in, count)
     if key not in _ws:
+        if dev.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            raise _lib.AugclError("encoder workspace requested for the first time inside a hipGraph capture: it would live "
+                                  "in the graph's private pool and be reused by eager calls; run one eager update first "
+                                  "(SAC.enable_hip_graphs keeps warmup >= 1)")
         n = _lib.load().augcl_enc_wgrad_workspace_bytes(int(c_in))
         _ws[key] = torch.empty(n // 4 * count, dtype=torch.float32, device=dev)
     return _ws[key]

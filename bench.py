@@ -414,6 +414,7 @@ def main():
 
         res["sac"] = leg("f32")  # the parity path
         res["sac"]["bf16_mode"] = leg("bf16")
+        res["sac"]["select_action_us"] = bench_update.action_latency(dev)  # batch-1 acting, eager vs captured graph
 
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         res["cpu_baseline"] = cpu_baseline(args.cpu_seconds)

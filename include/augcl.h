@@ -124,6 +124,13 @@ int augcl_splice_f32(const float *x, const float *imgs, float *out, int B, int f
  * reference runs as a per-pixel Python loop: x, bg, out = (N,3,H,W) uint8; a pixel whose HSV (double arithmetic,
  * colorsys formulas) lies in h*360 in [100,185], s*255 in [80,255], v*255 in [70,255] takes the bg pixel. */
 int augcl_green_screen_u8(const uint8_t *x, const uint8_t *bg, uint8_t *out, int N, int H, int W, augcl_stream_t stream);
+/* VideoWrapper._interpolate_bg (src/env/wrappers.py:336-340): (N,3,Hb,Wb) uint8 video frames -> (N,3,H,W) uint8 through
+ * float/255, bilinear (align_corners=False), *255, truncating cast -- ATen's float32 arithmetic operation by operation
+ * (uint8-exact vs the reference's function).  _resize_: VideoWrapper._greenscreen (L342-348) = that resize + the keying
+ * above in one launch: bg_raw is the raw video frame, only keyed-in pixels are interpolated. */
+int augcl_interpolate_bg_u8(const uint8_t *bg, uint8_t *out, int N, int Hb, int Wb, int H, int W, augcl_stream_t stream);
+int augcl_green_screen_resize_u8(const uint8_t *x, const uint8_t *bg_raw, uint8_t *out, int N, int H, int W, int Hb, int Wb,
+                                 augcl_stream_t stream);
 
 /* ---- fused SVEA/AugCL front end: src/algorithms/svea.py:68 + :49 (random_shift, then
  * apply_aug=random_conv on the shifted clone) in one pass over the uint8/f32 observation:

@@ -266,3 +266,38 @@ def green_screen_np(x, bg):
     hh, ss, vv = h * 360, s * 255, maxc * 255
     key = (100 <= hh) & (hh <= 185) & (80 <= ss) & (ss <= 255) & (70 <= vv) & (vv <= 255)
     return np.where(key[..., None, :, :], bg, x).astype(np.uint8)
+
+
+def interpolate_bg_np(bg, size):
+    """VideoWrapper._interpolate_bg (src/env/wrappers.py:336-340): uint8 (...,3,Hb,Wb) -> uint8 (...,3,H,W) through
+    float32 / 255, F.interpolate(bilinear, align_corners=False), * 255 and a TRUNCATING uint8 cast.  The cast makes the
+    result sensitive to the last bit, so this restates ATen's float32 arithmetic operation by operation (pinned against
+    the reference's function on this torch build, tests/golden/eval_golden.npz): source coordinate
+    fma(scale, dst + 0.5, -0.5) clamped at 0 with scale = float32(in) / float32(out); weights (1 - l, l);
+    w0 * a + w1 * b as fma(w0, a, w1 * b), horizontal pass first.  (A float32 fma = the float64 product-sum rounded
+    once: exact, because a float32 product fits a float64 and the sum of two such terms rounds correctly here.)"""
+    f = np.float32
+    bg = np.asarray(bg)
+    Hb, Wb = bg.shape[-2:]
+    H, W = int(size[0]), int(size[1])
+    fma = lambda a, b, c: (np.asarray(a, np.float64) * np.asarray(b, np.float64) + np.asarray(c, np.float64)).astype(f)  # noqa: E731
+
+    def axis(n_in, n_out):
+        d = np.arange(n_out)
+        if n_in == n_out:
+            return d, d, np.ones(n_out, f), np.zeros(n_out, f)
+        scale = f(n_in) / f(n_out)
+        src = np.maximum(fma(np.full(n_out, scale, f), (d.astype(f) + f(0.5)).astype(f), np.full(n_out, -0.5, f)), f(0)).astype(f)
+        i0 = np.minimum(np.floor(src).astype(np.int64), n_in - 1)
+        i1 = np.minimum(i0 + 1, n_in - 1)
+        l1 = np.clip((src - i0.astype(f)).astype(f), 0, 1).astype(f)
+        return i0, i1, (f(1) - l1).astype(f), l1
+
+    y0, y1, hy0, hy1 = axis(Hb, H)
+    x0, x1, wx0, wx1 = axis(Wb, W)
+    x = (bg.astype(f) / f(255.0)).astype(f)
+    rows0, rows1 = x[..., y0, :], x[..., y1, :]
+    top = fma(wx0, rows0[..., x0], (wx1 * rows0[..., x1]).astype(f))
+    bot = fma(wx0, rows1[..., x0], (wx1 * rows1[..., x1]).astype(f))
+    out = fma(hy0[:, None], top, (hy1[:, None] * bot).astype(f))
+    return (out * f(255.0)).astype(np.uint8)

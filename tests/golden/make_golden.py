@@ -334,6 +334,17 @@ def make_eval():
         frac = float((y != x).any(axis=0).mean())
         assert 0.1 < frac < 0.9, frac
         out[f"gs{i}_out"] = y
+    # VideoWrapper._interpolate_bg (wrappers.py:336-340) and _greenscreen (L342-348) = resize + keying: the reference's
+    # own methods (unbound: they do not touch `self`) on seeded video-frame-like backgrounds of several sizes
+    for i, (seed, Hb, Wb, H, W) in enumerate(((51, 240, 320, 84, 84), (52, 360, 640, 100, 100), (53, 100, 100, 84, 84),
+                                              (54, 84, 84, 84, 84), (55, 128, 256, 100, 100))):
+        bg = gi.obs_u8(seed, 1, C=3, H=Hb, W=Wb)[0]
+        bg[:, :Hb // 4, :Wb // 4] = 77  # flat areas: k/255*255 lands within an ulp of an integer before the truncating cast
+        r = wr.VideoWrapper._interpolate_bg(None, bg.copy(), (H, W))
+        assert r.shape == (3, H, W) and r.dtype == np.uint8
+        out[f"ib{i}_out"] = r
+        x = gi.green_frame_u8(seed + 10, H, W)
+        out[f"gsr{i}_out"] = wr.do_green_screen(x.copy(), r.copy())
     np.savez_compressed(os.path.join(HERE, "eval_golden.npz"), **out)
     print("wrote eval_golden.npz", {k: v.shape for k, v in out.items()})
 

@@ -407,3 +407,25 @@ def test_green_screen_golden_and_all_colours(cuda, golden_eval):
     got = host(eval_ops.green_screen(dev(x, cuda), dev(bg, cuda)))
     assert np.array_equal(got, orc.green_screen_np(x, bg))
     assert 0.05 < float((got[:, 0] == 7).mean()) < 0.5
+
+
+def test_interpolate_bg_and_fused_greenscreen(cuda, golden_eval):
+    """VideoWrapper._interpolate_bg / _greenscreen (src/env/wrappers.py:336-348): uint8-exact against goldens minted from
+    the reference's own methods, against the oracle on further sizes, and the one-launch resize+key == the two steps."""
+    from augcl_amd import eval_ops
+    for i, (seed, Hb, Wb, H, W) in enumerate(((51, 240, 320, 84, 84), (52, 360, 640, 100, 100), (53, 100, 100, 84, 84),
+                                              (54, 84, 84, 84, 84), (55, 128, 256, 100, 100))):
+        bg = gi.obs_u8(seed, 1, C=3, H=Hb, W=Wb)[0]
+        bg[:, :Hb // 4, :Wb // 4] = 77
+        r = eval_ops.interpolate_bg(dev(bg, cuda), (H, W))
+        assert np.array_equal(host(r), golden_eval[f"ib{i}_out"]), i
+        x = gi.green_frame_u8(seed + 10, H, W)
+        fused = eval_ops.greenscreen(dev(x, cuda), dev(bg, cuda))
+        assert np.array_equal(host(fused), golden_eval[f"gsr{i}_out"]), i
+        assert torch.equal(fused, eval_ops.green_screen(dev(x, cuda), r))
+    rs = np.random.RandomState(9)
+    for Hb, Wb, H, W in ((480, 854, 84, 84), (101, 203, 100, 100), (84, 100, 100, 84), (720, 1280, 84, 84)):
+        bgs = rs.randint(0, 256, (4, 3, Hb, Wb)).astype(np.uint8)  # a batch: one background per frame
+        bgs[0] = 200
+        got = host(eval_ops.interpolate_bg(dev(bgs, cuda), (H, W)))
+        assert got.shape == (4, 3, H, W) and np.array_equal(got, orc.interpolate_bg_np(bgs, (H, W))), (Hb, Wb, H, W)

@@ -125,3 +125,15 @@ def test_green_screen_bit_exact(golden_eval):
         x = gi.green_frame_u8(seed, H, W)
         bg = gi.obs_u8(seed + 100, 1, C=3, H=H, W=W)[0]
         assert np.array_equal(orc.green_screen_np(x, bg), golden_eval[f"gs{i}_out"])
+
+
+def test_interpolate_bg_and_greenscreen_bit_exact(golden_eval):
+    # VideoWrapper._interpolate_bg / _greenscreen run on seeded frames (tests/golden/make_golden.py: make_eval)
+    for i, (seed, Hb, Wb, H, W) in enumerate(((51, 240, 320, 84, 84), (52, 360, 640, 100, 100), (53, 100, 100, 84, 84),
+                                              (54, 84, 84, 84, 84), (55, 128, 256, 100, 100))):
+        bg = gi.obs_u8(seed, 1, C=3, H=Hb, W=Wb)[0]
+        bg[:, :Hb // 4, :Wb // 4] = 77
+        r = orc.interpolate_bg_np(bg, (H, W))
+        assert np.array_equal(r, golden_eval[f"ib{i}_out"]), i
+        x = gi.green_frame_u8(seed + 10, H, W)
+        assert np.array_equal(orc.green_screen_np(x, r), golden_eval[f"gsr{i}_out"]), i

@@ -290,6 +290,40 @@ def test_data_parallel_rank_draws_its_shard_of_the_global_augmentation(cuda):
     assert not torch.equal(whole[:B // 2], whole[B // 2:B])
 
 
+def test_action_graphs_match_eager_and_follow_training(cuda, tmp_path):
+    """select_action / sample_action (src/algorithms/sac.py:73-92) replayed from a captured hipGraph: the same action as
+    the eager path bit for bit, still so after an update() has moved the weights (the graph reads the live flat buffers),
+    stochastic actions bounded and varying, and the agent still pickles."""
+    args = au.dotdict(algorithm="svea", data_aug="conv", aug_params=None, **so.DEFAULTS)
+    torch.manual_seed(5)
+    agent = make_agent(T.OBS, (6,), args)
+    rs = np.random.RandomState(3)
+    frames = [rs.randint(0, 256, (9, 84, 84)).astype(np.uint8) for _ in range(4)]
+    eager = [agent.select_action(f) for f in frames]
+    agent.enable_action_graphs()
+    for f, e in zip(frames, eager):
+        assert np.array_equal(agent.select_action(f), e)
+    assert np.array_equal(agent.select_action(au.LazyFrames([frames[0][:3], frames[0][3:6], frames[0][6:]])), eager[0])
+    s1, s2 = agent.sample_action(frames[0]), agent.sample_action(frames[0])
+    assert s1.shape == (6,) and np.all(np.abs(s1) <= 1) and not np.array_equal(s1, s2)
+    B = 8
+    g = torch.Generator(device=cuda).manual_seed(1)
+    batch = (torch.randint(0, 256, (B, 9, 84, 84), device=cuda, generator=g).float(), torch.rand(B, 6, device=cuda) * 2 - 1,
+             torch.rand(B, 1, device=cuda), torch.randint(0, 256, (B, 9, 84, 84), device=cuda, generator=g).float(),
+             torch.ones(B, 1, device=cuda))
+    for step in range(2):
+        agent.update(FakeBuffer(batch), None, step)
+    after = agent.select_action(frames[1])
+    assert not np.array_equal(after, eager[1])
+    agent._act = None
+    assert np.array_equal(agent.select_action(frames[1]), after)  # eager on the trained weights == the old graph
+    agent.enable_action_graphs()
+    agent.select_action(frames[1])
+    torch.save(agent, tmp_path / "a.pt")
+    loaded = torch.load(tmp_path / "a.pt", weights_only=False)  # our own file
+    assert np.array_equal(loaded.select_action(frames[1]), after)
+
+
 def test_agent_pickle_roundtrip_and_state_dict_names(cuda, tmp_path):
     """train.py:229 saves the whole agent with torch.save; eval.py reloads it.  Flat-buffer views must survive."""
     args = au.dotdict(algorithm="svea", data_aug="conv", aug_params=None, **so.DEFAULTS)
