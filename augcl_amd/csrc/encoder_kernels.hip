@@ -807,7 +807,16 @@ static int conv32_forward_impl(const float *in, const float *w, const float *bia
     a.w2 = w2; a.bias2 = bias2; a.dual = w2 != nullptr;
     a.in = in; a.w = w; a.bias = bias; a.mask = nullptr; a.out = out;
     a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ho = Hi - 2; a.Wo = Wi - 2; a.relu = relu;
-    a.RT = pick_rt(a.Ho, 32 * Wi, 2, kBufLds, &a.S, augcl::extra_strips(0, Wi));
+    int extra = augcl::extra_strips(0, Wi);
+    {   // tiny batches (acting: B = 1): the few big strips of the throughput setting leave most CUs idle and make one
+        // layer ~20 us; cut the image into as many strips as there are CUs to go around (a strip re-reads two halo rows
+        // -- irrelevant at this size).  Any strip count gives the same values.
+        int s0 = 0;
+        const int rt0 = pick_rt(a.Ho, 32 * Wi, 2, kBufLds, &s0, extra);
+        const int cus = grid_for(1 << 30, 1);
+        if (rt0 > 0 && B * s0 * 2 <= cus) extra += std::min(a.Ho, cus / (2 * B)) - s0;
+    }
+    a.RT = pick_rt(a.Ho, 32 * Wi, 2, kBufLds, &a.S, extra);
     AUGCL_REQUIRE(a.RT > 0, "%s: image row too wide for LDS (W=%d)", name, Wi);
     a.n_items = B * a.S;
     const size_t bufw = (size_t)32 * (((a.RT + 2) * Wi + 3) & ~3);

@@ -44,7 +44,7 @@ BYTES_PER_OBS = {  # algorithmic bytes per observation
     "color_jitter_f32": 2 * OBS_ELEMS * 4,
     "shift_conv_u8_f32": OBS_ELEMS * 9,  # u8 in, two f32 outputs
     "replay_sample_f32": 2 * OBS_ELEMS * 5,  # obs + next_obs: u8 ring in, f32 out
-    "replay_shift_conv_u8_f32": OBS_ELEMS * 9,  # u8 ring in (gathered in-kernel), two f32 outputs
+    "replay_shift_conv_u8_f32": OBS_ELEMS * 14,  # whole SVEA sample: obs u8 ring -> [shift; shift+conv] f32, next_obs u8 -> f32
 }
 
 
