@@ -58,6 +58,11 @@ def parse(argv=None):
     ap.add_argument("--no-extras", action="store_true", help="headline metric only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline work (s)")
+    ap.add_argument("--no-sac", action="store_true", help="skip the update() legs (profiling the augmentation kernels)")
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="NOT a measurement: run the N ranks of --gpus N on GPU 0 with the gloo backend, to exercise the "
+                         "multi-rank code path (launcher, sharding, overlapped gradient exchange) on a one-GPU box")
+    ap.add_argument("--min-timed-s", type=float, default=MIN_TIMED_S, help="repeat the K-step block until this much is timed")
     return ap.parse_args(argv)
 
 
@@ -274,6 +279,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP path is the only path (no CPU fallback)")
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.rehearse_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -286,7 +293,10 @@ def main():
         saved = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", device_id=dev)
+            if args.rehearse_one_gpu:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=dev)
             probe = torch.ones(1, device=dev)
             dist.all_reduce(probe)  # SUM of ones = the number of ranks RCCL actually connected
             rccl_ranks = int(probe.item())
@@ -322,7 +332,7 @@ def main():
         k = i % R
         call("augcl_random_conv_f32", p(ring_f32[k]), p(outs[k]), B, 3, 84, 84, p(weights), 0, 0, 0, stream)
 
-    t = timed(conv_step, args.steps, args.warmup, dist, torch)
+    t = timed(conv_step, args.steps, args.warmup, dist, torch, min_s=args.min_timed_s)
     wall, dev_ms = t["wall"], t["dev_ms"]
     value = world * B * args.steps / wall
     ach = BYTES_PER_OBS["random_conv_f32"] * B / (dev_ms * 1e-3) / 1e9
@@ -333,6 +343,7 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "repeats": t["repeats"], "timed_s": t["timed_s"], "value_min": world * B * args.steps / t["wall_max"],
         "value_max": world * B * args.steps / t["wall_min"], "rccl_ranks": rccl_ranks,
+        **({"rehearsal": "ranks share GPU 0 over gloo: exercises the multi-rank path, measures nothing"} if args.rehearse_one_gpu else {}),
         "config": {"workload": "walker_walk SVEA strong augmentation: random_conv f32->f32 drop-in on (256,9,84,84) "
                                "per GPU, explicit per-sample 3x3x3x3 weights, ring of %d batches (> L3)" % R,
                    "batch_per_gpu": B, "obs_shape": [9, 84, 84], "parallelism": f"dp{world} (batch-sharded, no collective)"},
@@ -355,7 +366,7 @@ def main():
         n2 = max(20, args.steps // 4)
 
         def rate(name, fn):
-            t_ = timed(fn, n2, 10, dist, torch, min_s=0.25)
+            t_ = timed(fn, n2, 10, dist, torch, min_s=min(0.25, args.min_timed_s))
             a_ = BYTES_PER_OBS[name] * B / (t_["dev_ms"] * 1e-3) / 1e9
             extras[name] = {"obs_per_s": world * B * n2 / t_["wall"], "GB/s": a_, "frac": a_ / HBM_PEAK_GBS,
                             "avg_launch_ms": t_["dev_ms"], "repeats": t_["repeats"]}
@@ -388,11 +399,12 @@ def main():
             rate("replay_shift_conv_u8_f32", lambda i: rb.sample_shift_conv())
         res["extras"] = extras
 
+    if not args.no_extras and not args.no_sac:
         from augcl_amd import bench_update
         n_upd = max(10, args.steps // 20)
         # update() replayed from captured hipGraphs (SAC.enable_hip_graphs); the eager figure beside it.
         # With several ranks the graphs contain the gradient all-reduce: checked by a pre-flight first.
-        use_graph = dist is None or graph_collectives_ok(dist, dev, torch)
+        use_graph = dist is None or (not args.rehearse_one_gpu and graph_collectives_ok(dist, dev, torch))
         busy = load_profile_json("r02_mfma_busy.json")
 
         def leg(precision):

@@ -1,51 +1,89 @@
 #!/usr/bin/env python3
-"""Turn rocprofv3 output dirs (gpurun_out/...) into the small summaries committed under profiles/.
-usage: tools/summarize_profiles.py ROUND stats_dir pmc_fetch_dir pmc_write_dir [update_stats_dir]"""
-import collections, csv, glob, json, os, sys
+"""Build the tracked summaries under profiles/ from the small per-run files the on-box tools leave in gpurun_out/
+(tools/prof_summary.py -> *.csv / *.json of `rocprofv3 --kernel-trace --stats`; tools/pmc_summary.py -> *.json of the
+`rocprofv3 --pmc ...` passes, one counter group per pass as MI355X_MICROARCH.md prescribes).
 
-rnd, stats_dir, fetch_dir, write_dir = sys.argv[1:5]
-upd_dir = sys.argv[5] if len(sys.argv) > 5 else None
+usage: tools/summarize_profiles.py ROUND   (reads gpurun_out/{ROUND}_bench.csv, _fetch.json, _write.json,
+       _update_f32.csv, _update_bf16.csv, _mfma_f32.json, _mfma_bf16.json where ROUND is e.g. r2)"""
+import csv, json, os, shutil, sys
+
+rnd = sys.argv[1]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = lambda n: os.path.join(ROOT, "gpurun_out", f"{rnd}_{n}")  # noqa: E731
+tag = "r%02d" % int(rnd[1:])
 out = os.path.join(ROOT, "profiles")
-os.makedirs(out, exist_ok=True)
+CLK_HZ, SIMDS = 2.4e9, 256 * 4  # MI355X engine clock (peak), 256 CUs x 4 SIMDs
 
+for src, dst in (("bench.csv", f"{tag}_bench_kernel_stats.csv"), ("update_f32.csv", f"{tag}_update_kernel_stats.csv"),
+                 ("update_bf16.csv", f"{tag}_update_bf16_kernel_stats.csv")):
+    if os.path.exists(G(src)):
+        shutil.copy(G(src), os.path.join(out, dst))
 
-def stats(d, dst, top=30):
-    f = glob.glob(os.path.join(d, "*", "*_kernel_stats.csv"))[0]
-    rows = list(csv.DictReader(open(f)))
-    with open(dst, "w") as o:
-        o.write("# rocprofv3 --kernel-trace --stats (top kernels)\nname,calls,total_us,avg_us,min_us,max_us,pct\n")
-        for r in rows[:top]:
-            o.write('"%s",%s,%.1f,%.2f,%.2f,%.2f,%s\n' % (r["Name"][:110], r["Calls"], float(r["TotalDurationNs"]) / 1e3,
-                                                     float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, r["Percentage"]))
-    return rows
+# ---- HBM traffic per launch of every augmentation / replay kernel (B = 256)
+if os.path.exists(G("fetch.json")) and os.path.exists(G("write.json")):
+    fetch, write = json.load(open(G("fetch.json"))), json.load(open(G("write.json")))
+    OBS = 9 * 84 * 84
+    algo = {  # algorithmic bytes per launch at B = 256
+        "k_conv<84, 84, 12, 256, float, false, false": 256 * (2 * OBS * 4 + 324),
+        "k_conv<84, 84, 12, 256, unsigned char, true, false": 256 * OBS * 9,
+        "k_conv<84, 84, 12, 256, unsigned char, true, true": 256 * OBS * 9,
+        "k_random_shift<84, 84, 12, float, float>": 256 * 2 * OBS * 4,
+        "k_random_shift<84, 84, 12, unsigned char, float>": 256 * OBS * 5,
+        "k_random_overlay": 256 * (2 * OBS * 4 + 3 * 84 * 84 * 4),
+        "k_color_jitter_reg": 256 * 2 * OBS * 4,
+        "k_replay_sample<float>": 256 * 2 * OBS * 5,
+    }
+    kernels = {}
+    for k in sorted(set(fetch) | set(write)):
+        f_kb = fetch.get(k, {}).get("FETCH_SIZE", {}).get("avg")
+        w_kb = write.get(k, {}).get("WRITE_SIZE", {}).get("avg")
+        ent = {"FETCH_SIZE_KiB_raw": f_kb, "WRITE_SIZE_KiB_raw": w_kb}
+        if f_kb is not None and w_kb is not None:
+            # MI355X_MICROARCH.md (HBM): units are KiB; on gfx950 FETCH_SIZE reads exactly 1/2 of a wide coalesced stream
+            # (16 B/lane) -> doubled; WRITE_SIZE is exact for 16-B/lane streaming stores.  (uint8 inputs are read 4 B per
+            # lane -- an access width the guide calls uncalibrated: their figures are indicative.)
+            ent["hbm_bytes_per_launch"] = int(2 * f_kb * 1024 + w_kb * 1024)
+            a = [v for n, v in algo.items() if n in k]
+            if a:
+                ent["algorithmic_bytes_per_launch"] = a[0]
+                ent["traffic_over_algorithmic"] = round(ent["hbm_bytes_per_launch"] / a[0], 3)
+        kernels[k] = ent
+    res = {"round": tag, "batch": 256, "note": "FETCH_SIZE doubled (gfx950 correction), separate --pmc passes", "kernels": kernels}
+    key = [k for k in kernels if "k_conv<84, 84, 12, 256, float, false" in k]
+    if key:
+        res["k_random_conv"] = {"batch": 256, **kernels[key[0]]}
+    json.dump(res, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
+    print("pmc_traffic.json:", {k[:60]: v.get("traffic_over_algorithmic") for k, v in kernels.items()})
 
-
-def pmc(d, counter):
-    f = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))[0]
-    agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(f)):
-        if r["Counter_Name"] == counter and "augcl::" in r["Kernel_Name"]:
-            agg[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
-    return {k: sum(v) / len(v) for k, v in agg.items()}
-
-
-rows = stats(stats_dir, os.path.join(out, f"{rnd}_bench_kernel_stats.csv"))
-if upd_dir:
-    stats(upd_dir, os.path.join(out, f"{rnd}_update_kernel_stats.csv"), top=40)
-fetch, write = pmc(fetch_dir, "FETCH_SIZE"), pmc(write_dir, "WRITE_SIZE")
-traffic = {}
-for k in sorted(set(fetch) | set(write)):
-    f_kb, w_kb = fetch.get(k), write.get(k)
-    # MI355X_MICROARCH.md (HBM): units are KiB; on gfx950 FETCH_SIZE reads exactly 1/2 of a wide coalesced stream
-    # (16 B/lane) -> doubled; WRITE_SIZE is exact for 16-B/lane streaming stores.
-    ent = {"FETCH_SIZE_KiB_raw": f_kb, "WRITE_SIZE_KiB_raw": w_kb}
-    if f_kb is not None and w_kb is not None:
-        ent["hbm_bytes_per_launch"] = int(2 * f_kb * 1024 + w_kb * 1024)
-    traffic[k] = ent
-key = [k for k in traffic if "k_conv<84, 84, 12, 256, float, false" in k]
-res = {"round": rnd, "batch": 256, "note": "FETCH_SIZE doubled (gfx950 correction), separate --pmc passes", "kernels": traffic}
-if key:
-    res["k_random_conv"] = {"batch": 256, **traffic[key[0]]}
-json.dump(res, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
-print(json.dumps(res.get("k_random_conv"), indent=1))
+# ---- MFMA-busy of the encoder kernels inside update()
+busy = {"round": tag, "formula": "whole_launch = SQ_VALU_MFMA_BUSY_CYCLES / (launch duration x 2.4 GHz x 1024 SIMDs); "
+        "while_cu_busy = SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES).  SQ_VALU_MFMA_BUSY_CYCLES sums every SIMD's busy "
+        "cycles (checked on k_proj_partial: 16 x 63 x 4 x 7 x 16 MFMAs x 64 cycles = the counter to 0.3 %); durations from the "
+        "rocprofv3 --kernel-trace --stats run of the same command; f32 / bf16 = time-weighted over the kernels listed."}
+for prec in ("f32", "bf16"):
+    if not (os.path.exists(G(f"mfma_{prec}.json")) and os.path.exists(G(f"update_{prec}.csv"))):
+        continue
+    pm = json.load(open(G(f"mfma_{prec}.json")))
+    dur = {}
+    for r in csv.reader(l for l in open(G(f"update_{prec}.csv")) if not l.startswith("#")):
+        if r and r[0] != "name":
+            dur[r[0]] = (float(r[3]), int(r[1]))  # avg_us, calls
+    per, num, den = {}, 0.0, 0.0
+    for k, v in pm.items():
+        mf = v.get("SQ_VALU_MFMA_BUSY_CYCLES", {}).get("avg", 0.0)
+        if mf <= 0:
+            continue
+        match = [d for n, d in dur.items() if n.split("(")[0].strip()[:60] == k[:60]]
+        if not match:
+            continue
+        avg_us, calls = match[0]
+        cap = avg_us * 1e-6 * CLK_HZ * SIMDS
+        per[k] = {"mfma_busy_cycles": mf, "avg_us": avg_us, "calls_in_trace": calls, "whole_launch": round(mf / cap, 3),
+                  "while_cu_busy": round(mf / (4.0 * v["SQ_BUSY_CU_CYCLES"]["avg"]), 3)}
+        num += mf * calls
+        den += cap * calls
+    busy[prec] = round(num / den, 3) if den else None
+    busy[f"{prec}_kernels"] = per
+if "f32" in busy or "bf16" in busy:
+    json.dump(busy, open(os.path.join(out, f"{tag}_mfma_busy.json"), "w"), indent=1)
+    print("mfma_busy:", busy.get("f32"), busy.get("bf16"))
