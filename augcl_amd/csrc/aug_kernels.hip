@@ -58,6 +58,7 @@ struct Quad<W, float> {
     {
         v = *reinterpret_cast<const f32x4u *>(row + base);
     }
+
     __device__ __forceinline__ float4 get(int d) const
     {
         float4 o = make_float4(v.x, v.y, v.z, v.w);
@@ -82,6 +83,7 @@ struct Quad<W, uint8_t> {
     {
         v = *reinterpret_cast<const u32u *>(row + base);
     }
+
     __device__ __forceinline__ uint32_t packed(int d) const
     {
         uint32_t o = v;
@@ -265,7 +267,7 @@ __device__ __forceinline__ void conv_compute_store(const ConvSmem<H, W, R> &sm, 
 //   SLOWER, 31.4 vs 26.7 us at B=256: the prefetch registers cut occupancy to 4-5 waves per SIMD and the two barriers
 //   per strip serialise each workgroup, while eight independent short workgroups per CU desynchronise by themselves
 //   and keep loads, FMAs and stores of different strips overlapped; tools/kbench2.hip has both.)
-template <int H, int W, int R, int NT, typename TIn, bool SHIFT, bool GATHER, int EXP = (sizeof(TIn) == 1 ? 3 : 2)>
+template <int H, int W, int R, int NT, typename TIn, bool SHIFT, bool GATHER, int EXP = (sizeof(TIn) == 1 ? 7 : 2)>
 __global__ __launch_bounds__(NT) void k_conv(const TIn *__restrict__ in, float *__restrict__ out_shift,
                                              float *__restrict__ out_aug, int n_frames, int frames, int pad,
                                              const int32_t *__restrict__ oy, const int32_t *__restrict__ ox,
@@ -309,13 +311,16 @@ __global__ __launch_bounds__(NT) void k_conv(const TIn *__restrict__ in, float *
     }
 
     // EXP bit 0: raise the wave priority while the strip's loads are issued (uint8 front end: 31.1 -> 30.0 us at B=256; it
-    // costs the f32 kernel 0.9 us, whose prologue is 4x the bytes); bit 1: x/255 without the +-inf pass-through.
+    // costs the f32 kernel 0.9 us, whose prologue is 4x the bytes); bit 1: x/255 without the +-inf pass-through; bit 2:
+    // branch-free load issue.  (Non-temporal LOADS of the input changed nothing: 25.4 us either way.)  Measured with
+    // tools/kbench2.hip; all variants within ~3 % -- at B=256 the launch is ramp/drain-bound (plain copy: 23.9 us).
     if (EXP & 1) __builtin_amdgcn_s_setprio(3);
     Quad<W, TIn> raw[NI];
 #pragma unroll
     for (int k = 0; k < NI; ++k) {
-        const int j = threadIdx.x + k * NT;
-        if (j < NQ) {
+        const int j0 = threadIdx.x + k * NT;
+        const int j = (EXP & 4) ? min(j0, NQ - 1) : j0; // bit 2: branch-free issue (lanes past the strip re-load its last quad)
+        if ((EXP & 4) || j < NQ) {
             const int ch = j / ((R + 2) * W4);
             const int rem = j - ch * ((R + 2) * W4);
             const int rr = rem / W4;

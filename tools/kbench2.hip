@@ -251,7 +251,7 @@ int main(int argc, char **argv)
 #define EXPV(E) \
     vs.push_back({"conv f32 EXP=" #E, f2f, [&](int k) { launch_new<12, 256, float, false, E>(fin[k % RING], nullptr, fout[k % RING], B, nullptr, nullptr, w); }}); \
     vs.push_back({"shift_conv u8 EXP=" #E, u2, [&](int k) { launch_new<12, 256, uint8_t, true, E>(uin[k % RING8], fout[k % RING], fout2[k & 1], B, oy, ox, w); }});
-    EXPV(1) EXPV(2) EXPV(3)
+    EXPV(0) EXPV(2) EXPV(3) EXPV(6) EXPV(7)
     vs.push_back({"conv f32 R=12 NT=256 again", f2f, [&](int k) { launch_new<12, 256, float, false>(fin[k % RING], nullptr, fout[k % RING], B, nullptr, nullptr, w); }});
     vs.push_back({"conv f32 philox R=12", f2f, [&](int k) { launch_new<12, 256, float, false>(fin[k % RING], nullptr, fout[k % RING], B, nullptr, nullptr, nullptr); }});
     {
