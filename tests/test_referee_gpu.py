@@ -236,11 +236,14 @@ class RecLogger:
         self.rows[key] = float(value.item() if torch.is_tensor(value) else value)
 
 
-CASES = [  # (algo, data_aug, A, B, hp overrides): BASELINE configs 2, 3, 4 (config 4's global batch on one GPU) + DrQ K=M=2
-    ("svea", "conv", 6, 256, {}),
-    ("drq", "identity", 2, 512, {}),
-    ("augcl", "conv-overlay", 6, 1024, {}),
-    ("drq", "identity", 2, 128, dict(drq_k=2, drq_m=2)),
+CASES = [  # (algo, data_aug, A, B, hp overrides, init): BASELINE configs 2, 3, 4 (config 4's global batch on one GPU) + DrQ
+    # K=M=2; "delta" = the reference's real initial state, "he" = He-scaled weights (a net in mid-training)
+    ("svea", "conv", 6, 256, {}, "he"),
+    ("svea", "conv", 6, 256, {}, "delta"),
+    ("drq", "identity", 2, 512, {}, "he"),
+    ("drq", "identity", 2, 512, {}, "delta"),
+    ("augcl", "conv-overlay", 6, 1024, {}, "he"),
+    ("drq", "identity", 2, 128, dict(drq_k=2, drq_m=2), "he"),
 ]
 
 
@@ -268,8 +271,7 @@ class GateRecorder:
             h.remove()
 
 
-@pytest.mark.parametrize("init", ["he", "delta"])
-@pytest.mark.parametrize("algo,data_aug,A,B,hpo", CASES)
+@pytest.mark.parametrize("algo,data_aug,A,B,hpo,init", CASES)
 def test_update_against_f64_referee(cuda, monkeypatch, algo, data_aug, A, B, hpo, init):
     """One full update() (critic, actor + alpha, target EMA) at the configs' batch sizes, on real-init / He-scaled nets.
     The referee is run twice: FREE (its own ReLU gates) -- reported next to the float32 oracle's deviation, which shows
