@@ -59,6 +59,9 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline work (s)")
     ap.add_argument("--no-sac", action="store_true", help="skip the update() legs (profiling the augmentation kernels)")
+    ap.add_argument("--dp-graph", action="store_true",
+                    help="with --gpus N > 1 also try update() replayed from hipGraphs that contain the RCCL all-reduce "
+                         "(pre-flighted; default: the eager multi-rank path only)")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="NOT a measurement: run the N ranks of --gpus N on GPU 0 with the gloo backend, to exercise the "
                          "multi-rank code path (launcher, sharding, overlapped gradient exchange) on a one-GPU box")
@@ -404,7 +407,7 @@ def main():
         n_upd = max(10, args.steps // 20)
         # update() replayed from captured hipGraphs (SAC.enable_hip_graphs); the eager figure beside it.
         # With several ranks the graphs contain the gradient all-reduce: checked by a pre-flight first.
-        use_graph = dist is None or (not args.rehearse_one_gpu and graph_collectives_ok(dist, dev, torch))
+        use_graph = dist is None or (args.dp_graph and not args.rehearse_one_gpu and graph_collectives_ok(dist, dev, torch))
         busy = load_profile_json("r02_mfma_busy.json")
 
         def leg(precision):
