@@ -15,11 +15,18 @@ def make_agent(obs_shape, action_shape, args):
         cls = algorithm[args.algorithm]
     except KeyError:
         raise KeyError(f"algorithm {args.algorithm!r} is not on the accelerated path; have {sorted(algorithm)}") from None
+    def opt(name, default=None):  # extension flags, absent from the reference's arguments.py
+        try:
+            return getattr(args, name)
+        except (AttributeError, KeyError):
+            return default
+
+    if opt("precision") is not None:  # "f32" (parity path) / "bf16" (performance mode of the conv stack), process-wide
+        from .. import encoder_ops
+        encoder_ops.set_precision(opt("precision"))
     agent = cls(obs_shape, action_shape, args)
-    try:  # extension flag (absent from the reference's arguments.py): replay update() as captured hipGraphs
-        want_graph = bool(args.hip_graph)
-    except (AttributeError, KeyError):
-        want_graph = False
-    if want_graph:
+    if opt("hip_graph"):    # replay update() as captured hipGraphs
         agent.enable_hip_graphs()
+    if opt("action_graph"):  # replay batch-1 select_action / sample_action as captured hipGraphs
+        agent.enable_action_graphs()
     return agent
