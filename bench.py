@@ -400,6 +400,24 @@ def main():
         rate("replay_sample_f32", lambda i: rb.sample())
         if hasattr(rb, "sample_shift_conv"):  # gather -> random_shift -> random_conv in one pass over the uint8 ring
             rate("replay_shift_conv_u8_f32", lambda i: rb.sample_shift_conv())
+        # BASELINE config 4's batch (1024 per launch): the same kernels once the launch is long enough for ramp / drain and
+        # workgroup-count quantisation (color_jitter: 3 frames per CU on 2 slots at B=256) not to matter
+        B4 = 1024
+        x4 = [torch.randint(0, 256, (B4, 9, 84, 84), dtype=torch.uint8, device=dev, generator=g).float() for _ in range(3)]
+        y4 = [torch.empty_like(x4[0]) for _ in range(3)]
+        w4 = torch.randn((B4, 81), device=dev, generator=g)
+
+        def rate4(name, key, fn):
+            t_ = timed(fn, max(10, n2 // 4), 5, dist, torch, min_s=min(0.25, args.min_timed_s))
+            a_ = BYTES_PER_OBS[key] * B4 / (t_["dev_ms"] * 1e-3) / 1e9
+            extras[name] = {"obs_per_s": world * B4 * max(10, n2 // 4) / t_["wall"], "GB/s": a_, "frac": a_ / HBM_PEAK_GBS,
+                            "avg_launch_ms": t_["dev_ms"], "batch": B4}
+
+        rate4("random_conv_f32_B1024", "random_conv_f32", lambda i: call("augcl_random_conv_f32", p(x4[i % 3]), p(y4[i % 3]), B4, 3, 84,
+                                                                           84, p(w4), 0, 0, 0, stream))
+        rate4("color_jitter_f32_B1024", "color_jitter_f32", lambda i: call("augcl_color_jitter_f32", p(y4[i % 3]), B4, 3, 84, 84, None, 0,
+                                                                             order_p, 1.2, 0.8, 0.1, 1.0, 255.0, stream))
+        del x4, y4, w4
         res["extras"] = extras
 
     if not args.no_extras and not args.no_sac:

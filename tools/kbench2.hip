@@ -260,6 +260,7 @@ int main(int argc, char **argv)
         const int npx = 84 * 84;
         vs.push_back({"jitter product", f2f, [&](int k) { static int32_t ord[4] = {1, 2, 3, 0}; augcl_color_jitter_f32(fout[k % RING], B, 3, 84, 84, nullptr, 0, ord, 1.2, 0.8, 0.1, 1.0f, 255.0f, 0); }});
         vs.push_back({"jitter reg<1024,2,4>", f2f, [&, npx](int k) { hipLaunchKernelGGL((k_color_jitter_reg<1024, 2, 4>), dim3(B * 3), dim3(1024), 0, 0, fout[k % RING], npx, (const int32_t *)nullptr, 0, jp); }});
+        vs.push_back({"jitter reg<896,2,7>", f2f, [&, npx](int k) { hipLaunchKernelGGL((k_color_jitter_reg<896, 2, 7, true>), dim3(B * 3), dim3(896), 0, 0, fout[k % RING], npx, (const int32_t *)nullptr, 0, jp); }});
         vs.push_back({"jitter reg<512,4,4>", f2f, [&, npx](int k) { hipLaunchKernelGGL((k_color_jitter_reg<512, 4, 4>), dim3(B * 3), dim3(512), 0, 0, fout[k % RING], npx, (const int32_t *)nullptr, 0, jp); }});
         vs.push_back({"jitter reg<256,7,2>", f2f, [&, npx](int k) { hipLaunchKernelGGL((k_color_jitter_reg<256, 7, 2>), dim3(B * 3), dim3(256), 0, 0, fout[k % RING], npx, (const int32_t *)nullptr, 0, jp); }});
     }
