@@ -29,6 +29,20 @@ def test_bad_arguments_are_reported_not_crashed():
     rc = lib.augcl_color_jitter_f32(1 << 20, 1, 3, 84, 84, None, 0, ctypes.cast(order, ctypes.c_void_p), 1.0, 1.0,
                                     0.0, 1.0, 1.0, None)
     assert rc == -1 and b"permutation" in lib.augcl_last_error()
+    # round-2 entry points: argument checks come before any launch, so they answer without a GPU too
+    assert lib.augcl_replay_shift_conv_u8_f32(None, None, None, 6, None, None, 0, 3, 84, 84, 4, None, None, None, 0, 0, 0, None) == 0  # B = 0
+    assert lib.augcl_replay_shift_conv_u8_f32(None, None, None, 6, None, None, 2, 3, 84, 84, 4, None, None, None, 0, 0, 0, None) == -1
+    assert lib.augcl_replay_shift_conv_u8_f32(16, None, None, 6, 16, 16, 2, 3, 84, 84, 4, None, None, None, 0, 0, 0, None) == -1
+    assert b"slot table" in lib.augcl_last_error()
+    assert lib.augcl_shift_conv_u8_f32(16, 16, 16, 2, 3, 50, 50, 4, None, None, None, 0, 0, 0, None) == -1 and b"84x84" in lib.augcl_last_error()
+    assert lib.augcl_proj_ln_tanh_workspace_slabs(512, 14112, 100) == 63 and lib.augcl_proj_ln_tanh_workspace_slabs(1024, 14112, 100) == 21
+    assert lib.augcl_proj_ln_tanh_workspace_slabs(8, 14112, 300) == 0 and lib.augcl_proj_ln_tanh_workspace_slabs(8, 1000, 100) == 0
+    assert lib.augcl_proj_ln_tanh_forward(None, None, None, None, None, None, None, None, 0, 8, 1000, 100, 1e-5, None) == -1
+    assert b"not covered" in lib.augcl_last_error()
+    assert lib.augcl_interpolate_bg_u8(None, None, 0, 240, 320, 84, 84, None) == 0 and lib.augcl_interpolate_bg_u8(None, None, 1, 240, 320, 84, 84, None) == -1
+    assert lib.augcl_green_screen_resize_u8(None, None, None, 1, 84, 84, 0, 320, None) == -1
+    assert lib.augcl_alpha_step_f64(None, None, 4, -6.0, 1e-4, 0.5, 0.999, 1e-8, None, None, 3, None) == -1
+    assert lib.augcl_actor_loss_forward(None, None, None, None, None, 4, None) == -1
 
 
 def test_ops_fail_loudly_without_gpu_tensor():
