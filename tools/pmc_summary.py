@@ -9,8 +9,8 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if every or "augcl::" in k:
-            agg[k.split("(")[0].strip()][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if every or "augcl::" in k:  # one entry per (kernel, launch grid): the same kernel runs at several batch sizes
+            agg[k.split("(")[0].strip() + " [grid %s]" % r.get("Grid_Size", "?")][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {k: {c: {"avg": sum(v) / len(v), "n": len(v)} for c, v in cs.items()} for k, cs in agg.items()}
 json.dump(out, open(d + ".json", "w"), indent=1)
 shutil.rmtree(d)

@@ -21,7 +21,19 @@ for src, dst in (("bench.csv", f"{tag}_bench_kernel_stats.csv"), ("update_f32.cs
 
 # ---- HBM traffic per launch of every augmentation / replay kernel (B = 256)
 if os.path.exists(G("fetch.json")) and os.path.exists(G("write.json")):
-    fetch, write = json.load(open(G("fetch.json"))), json.load(open(G("write.json")))
+    def smallest_grid(d):
+        """{kernel [grid N]: counters} -> {kernel: counters of its SMALLEST launch grid} (the B = 256 launches; the bench
+        also runs some kernels at B = 1024)"""
+        best = {}
+        for k, v in d.items():
+            name, _, g = k.partition(" [grid ")
+            grid = int(g.rstrip("]")) if g.rstrip("]").isdigit() else 0
+            # (k_replay_sample: its LARGEST grid is the full obs + next_obs sample; the half grid is the next_obs-only call)
+            if name not in best or ((grid > best[name][0]) if "k_replay_sample" in name else (grid < best[name][0])):
+                best[name] = (grid, v)
+        return {n: v for n, (_, v) in best.items()}
+
+    fetch, write = smallest_grid(json.load(open(G("fetch.json")))), smallest_grid(json.load(open(G("write.json"))))
     OBS = 9 * 84 * 84
     algo = {  # algorithmic bytes per launch at B = 256 (SURVEY.md 8d)
         "k_conv<84, 84, 12, 256, float, false, false": 256 * (2 * OBS * 4 + 324),
@@ -63,7 +75,13 @@ busy = {"round": tag, "formula": "whole_launch = SQ_VALU_MFMA_BUSY_CYCLES / (lau
 for prec in ("f32", "bf16"):
     if not (os.path.exists(G(f"mfma_{prec}.json")) and os.path.exists(G(f"update_{prec}.csv"))):
         continue
-    pm = json.load(open(G(f"mfma_{prec}.json")))
+    pm = {}
+    for k, v in json.load(open(G(f"mfma_{prec}.json"))).items():  # merge the launch grids of one kernel (count-weighted)
+        name = k.partition(" [grid ")[0]
+        for c, x in v.items():
+            e = pm.setdefault(name, {}).setdefault(c, {"avg": 0.0, "n": 0})
+            e["avg"] = (e["avg"] * e["n"] + x["avg"] * x["n"]) / (e["n"] + x["n"])
+            e["n"] += x["n"]
     dur = {}
     for r in csv.reader(l for l in open(G(f"update_{prec}.csv")) if not l.startswith("#")):
         if r and r[0] != "name":
