@@ -445,9 +445,14 @@ def main():
                                 "SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES per conv kernel, time-weighted)" if busy.get(precision) else None}
             return best
 
-        res["sac"] = leg("f32")  # the parity path
-        res["sac"]["bf16_mode"] = leg("bf16")
-        res["sac"]["select_action_us"] = bench_update.action_latency(dev)  # batch-1 acting, eager vs captured graph
+        try:
+            res["sac"] = leg("f32")  # the parity path
+            res["sac"]["bf16_mode"] = leg("bf16")
+            res["sac"]["select_action_us"] = bench_update.action_latency(dev)  # batch-1 acting, eager vs captured graph
+        except Exception as e:  # noqa: BLE001 -- the headline above is measured: report the failure, do not lose the line
+            import traceback
+            traceback.print_exc()
+            res.setdefault("sac", {})["error"] = repr(e)
 
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         res["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
