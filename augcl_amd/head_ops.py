@@ -234,8 +234,8 @@ class _TwinQ(torch.autograd.Function):
         x = torch.cat([h, a], dim=1)
         W1, b1, W2, b2, W3, b3 = (_stacked(p, q) for p, q in ((w1a, w1b), (b1a, b1b), (w2a, w2b), (b2a, b2b), (w3a, w3b), (b3a, b3b)))
         if W1.is_contiguous() and b1.is_contiguous():  # one GEMM for both first layers: (B, D) x (D, 2H)
-            z1 = torch.addmm(b1.reshape(2 * H), x, W1.reshape(2 * H, -1).t())
-            a1 = torch.relu_(z1).view(B, 2, H).transpose(0, 1)  # (2, B, H), row stride 2H
+            # bias + ReLU in the GEMM's epilogue (one launch): torch._addmm_activation(bias, x, W^T) = relu(x W^T + bias)
+            a1 = torch._addmm_activation(b1.reshape(2 * H), x, W1.reshape(2 * H, -1).t()).view(B, 2, H).transpose(0, 1)
         else:
             a1 = torch.relu_(torch.baddbmm(b1.unsqueeze(1), x.unsqueeze(0).expand(2, B, -1), W1.transpose(1, 2)))
         a2 = torch.relu_(torch.baddbmm(b2.unsqueeze(1), a1, W2.transpose(1, 2)))
