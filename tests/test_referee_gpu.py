@@ -366,7 +366,7 @@ def test_update_against_f64_referee(cuda, monkeypatch, algo, data_aug, A, B, hpo
     hooks = [mod.register_forward_hook(lambda _m, _i, out: seen_feat.append(out.detach())) for mod in watched]
     rec = GateRecorder()
     rec.watch("mlp", agent.actor.mlp)
-    # the twin Q trunks run as one batched network (head_ops.twin_q) whose two ReLUs are in-place torch.relu_ calls:
+    # the twin Q trunks run as one batched network (head_ops.twin_q) whose two ReLUs are a torch._addmm_activation epilogue and an in-place torch.relu_:
     # layer 1 on a (B, 2H) tensor [Q1 | Q2], layer 2 on (2, B, H); record every call's gates in order
     twin_relu, real_relu_ = [], torch.relu_
 
@@ -376,6 +376,14 @@ def test_update_against_f64_referee(cuda, monkeypatch, algo, data_aug, A, B, hpo
         return out
 
     monkeypatch.setattr(torch, "relu_", relu_rec)
+    real_addmm_act = torch._addmm_activation  # layer 1: bias + ReLU in the GEMM epilogue (head_ops._TwinQ.forward)
+
+    def addmm_act_rec(*a, **k):
+        out = real_addmm_act(*a, **k)
+        twin_relu.append((out > 0).cpu())
+        return out
+
+    monkeypatch.setattr(torch, "_addmm_activation", addmm_act_rec)
 
     calls = {"shift": 0}
 
