@@ -44,6 +44,7 @@ _c = ctypes
 _P = _c.c_void_p
 _I = _c.c_int
 _U64 = _c.c_uint64
+_I64 = _c.c_int64
 _SZ = _c.c_size_t
 _F = _c.c_float
 _D = _c.c_double
@@ -74,9 +75,9 @@ _SIGS = {
     "augcl_interpolate_bg_u8": [_P, _P, _I, _I, _I, _I, _I, _P],
     "augcl_green_screen_resize_u8": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "augcl_gauss_head_forward": [_P, _P, _P, _P, _P, _P, _I, _I, _D, _D, _P],
-    "augcl_gauss_head_backward": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _D, _D, _P],
+    "augcl_gauss_head_backward": [_P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _D, _D, _P],
     "augcl_ln_tanh_forward": [_P, _P, _P, _P, _I, _I, _D, _P],
-    "augcl_ln_tanh_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _D, _P],
+    "augcl_ln_tanh_backward": [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _D, _P],
     "augcl_proj_ln_tanh_workspace_slabs": [_I, _I, _I],
     "augcl_proj_ln_tanh_forward": [_P, _P, _P, _P, _P, _P, _P, _P, _SZ, _I, _I, _I, _D, _P],
     "augcl_td_target_f32": [_P, _P, _P, _P, _P, _P, _I, _D, _P, _I, _P],
@@ -86,8 +87,13 @@ _SIGS = {
     "augcl_q_loss_forward": [_P, _P, _P, _I, _I, _P, _P, _P],
     "augcl_q_loss_backward": [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
     "augcl_adam_f32": [_P, _P, _P, _P, _SZ, _D, _D, _D, _D, _c.c_int64, _D, _P],
-    "augcl_adam_f32_devstep": [_P, _P, _P, _P, _SZ, _D, _D, _D, _D, _P, _D, _P],
+    "augcl_adam_f32_devstep": [_P, _P, _P, _P, _SZ, _D, _D, _D, _D, _P, _I, _D, _P],
+    "augcl_gather_f32": [_P, _P, _P, _I, _P, _P, _D, _D, _D, _P],
     "augcl_ema_f32": [_P, _P, _SZ, _D, _P],
+    "augcl_ema2_f32": [_P, _P, _SZ, _D, _P, _P, _SZ, _D, _P],
+    "augcl_mlp_out_forward": [_P, _P, _I64, _P, _I64, _P, _I64, _P, _I, _I, _I, _P],
+    "augcl_mlp_out_backward": [_P, _P, _P, _P, _I64, _P, _P, _P, _P, _I, _I, _I, _P],
+    "augcl_mask_colsum": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
     "augcl_enc_bf16_conv_first_forward": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
     "augcl_enc_bf16_conv32_forward": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "augcl_enc_bf16_conv32_backward_data": [_P, _P, _P, _P, _I, _I, _I, _P],

@@ -194,7 +194,8 @@ class Actor(nn.Module):
 
     def forward(self, x, compute_pi=True, compute_log_pi=True, detach=False, features=None):
         x = self.encoder(x, detach, features=features)
-        raw = self.mlp(x)
+        # the three Linears with bias + ReLU in the GEMM epilogues and fused gate / bias-gradient launches backward
+        raw = head_ops.mlp3(x, self.mlp) if (head_ops._ok(x) and x.dim() == 2) else self.mlp(x)
         if head_ops._ok(raw) and (compute_pi or not compute_log_pi):
             # one launch forward / one backward for everything below (same operation order inside)
             noise = torch.randn_like(raw[:, :raw.shape[1] // 2]) if compute_pi else None
@@ -236,14 +237,16 @@ class Critic(nn.Module):
         self.Q1 = QFunction(self.encoder.out_dim, action_shape[0], hidden_dim)
         self.Q2 = QFunction(self.encoder.out_dim, action_shape[0], hidden_dim)
 
-    def _twin(self, h, action):
+    def _twin(self, h, action, freeze=False):
         assert h.size(0) == action.size(0)
         if head_ops._ok(h, action):  # both trunks as one batched network (head_ops.twin_q); nn.Sequential otherwise
-            return head_ops.twin_q(h, action, self.Q1, self.Q2)
+            return head_ops.twin_q(h, action, self.Q1, self.Q2, freeze=freeze)
         return self.Q1(h, action), self.Q2(h, action)
 
-    def forward(self, x, action, detach=False, features=None):
-        return self._twin(self.encoder(x, detach, features=features), action)
+    def forward(self, x, action, detach=False, features=None, freeze_q=False):
+        """freeze_q (not in the reference's signature): the Q trunks' weights enter as constants -- the actor step only
+        needs the gradient with respect to the action."""
+        return self._twin(self.encoder(x, detach, features=features), action, freeze_q)
 
     def forward_Q(self, x_encoded, action):
         return self._twin(x_encoded, action)

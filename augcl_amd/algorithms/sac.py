@@ -211,7 +211,7 @@ class SAC(object):
             feat = self.actor.encoder.features(obs)
         same_cnn = critic.encoder.shared_cnn is self.actor.encoder.shared_cnn
         _, pi, log_pi, log_std = self.actor(obs, detach=True, features=feat)
-        actor_Q1, actor_Q2 = critic(obs, pi, detach=True, features=feat if same_cnn else None)
+        actor_Q1, actor_Q2 = critic(obs, pi, detach=True, features=feat if same_cnn else None, freeze_q=True)
         fused = head_ops._ok(log_pi, actor_Q1, actor_Q2)
         if fused:  # alpha * log_pi - min(Q1, Q2), mean: one launch forward, one backward
             actor_loss = head_ops.actor_loss(log_pi, actor_Q1, actor_Q2, self.log_alpha)
@@ -242,12 +242,11 @@ class SAC(object):
 
     def _soft_update_from(self, src_group):
         """sac.py:148-153: Q1,Q2 with critic_tau, encoder (CNN + projection) with encoder_tau -- two fused
-        launches over the flat segments instead of ~40 per-tensor updates."""
+        segments of the flat buffers in ONE launch instead of ~40 per-tensor updates."""
         tg = self.target_group
         ea, eb = tg.segment("encoder.")
         qa, qb = tg.segment("Q")
-        flat.ema_(tg.param, src_group.param, ea, eb, self.encoder_tau)
-        flat.ema_(tg.param, src_group.param, qa, qb, self.critic_tau)
+        flat.ema2_(tg.param, src_group.param, (ea, eb, self.encoder_tau), (qa, qb, self.critic_tau))
 
     def soft_update_critic_target(self):
         self._soft_update_from(self.critic_group)
@@ -309,9 +308,13 @@ class SAC(object):
         G["shapes"] = tuple(batch[1].shape)
         if G["static"] is None:
             G["static"] = tuple(x.clone() if torch.is_tensor(x) else x for x in t)
-        for dst, src in zip(G["static"], t):
-            if torch.is_tensor(src) and dst.data_ptr() != src.data_ptr():
-                dst.copy_(src)
+        pairs = [(dst, src) for dst, src in zip(G["static"], t) if torch.is_tensor(src) and dst.data_ptr() != src.data_ptr()]
+        small = [(d, s_) for d, s_ in pairs if d.numel() <= (1 << 18)]
+        if len(small) > 1:  # refill the graphs' static inputs: the (B, 1)-sized ones in one multi-tensor launch
+            torch._foreach_copy_([d for d, _ in small], [s_ for _, s_ in small])
+            pairs = [p for p in pairs if p[0].numel() > (1 << 18)]
+        for d, s_ in pairs:
+            d.copy_(s_)
         key = (bool(do_actor), bool(do_target), L is not None)
         if key not in G["graphs"]:
             sink = _LogSink()

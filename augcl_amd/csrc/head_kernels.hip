@@ -15,6 +15,7 @@ struct GaussArgs {
     const float *g_mu_t, *g_pi_t, *g_log_pi, *g_log_std; // backward: incoming gradients (any may be null)
     float *g_raw;                                        // backward: (B, 2A)
     int B, A;
+    int g_pi_ld; // row stride of g_pi_t in floats (>= A): it may be a column slice of a wider matrix
     float lo, k, c; // log_std = lo + k * (tanh(raw) + 1); c = 0.5 * log(2 pi) * A
 };
 
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(256) void k_gauss_head_bwd(GaussArgs a)
             const float pt = tanhf(m + n * sd);
             const float u = 1.0f - pt * pt;
             // d/d pi_t of -sum log(relu(1 - pi_t^2) + 1e-6) = (u > 0) * 2 pi_t / (u + 1e-6)
-            float g_pt = a.g_pi_t ? a.g_pi_t[e] : 0.0f;
+            float g_pt = a.g_pi_t ? a.g_pi_t[(size_t)r * a.g_pi_ld + j] : 0.0f;
             if (u > 0.0f) g_pt += (glp / (u + 1e-6f)) * (2.0f * pt);
             const float d_p = g_pt * u;
             d_m += d_p;
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(256) void k_ln_tanh_fwd(const float *__restrict__ x
 __global__ __launch_bounds__(256) void k_ln_tanh_bwd(const float *__restrict__ x, const float *__restrict__ gamma,
                                                      const float *__restrict__ y, const float *__restrict__ gy,
                                                      float *__restrict__ dx, float *__restrict__ g1_out,
-                                                     float *__restrict__ g1x_out, int B, int D, float eps)
+                                                     float *__restrict__ g1x_out, int B, int D, float eps, int gy_ld)
 {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= B) return;
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(256) void k_ln_tanh_bwd(const float *__restrict__ x
         if (j < D) {
             const size_t e = (size_t)row * D + j;
             const float yy = y[e];
-            const float g1 = gy[e] * (1.0f - yy * yy);
+            const float g1 = gy[(size_t)row * gy_ld + j] * (1.0f - yy * yy);
             xh[k] = (v[k] - mean) * rstd;
             dh[k] = g1 * gamma[j];
             g1_out[e] = g1;
@@ -463,6 +464,114 @@ __global__ __launch_bounds__(256) void k_proj_reduce_ln_tanh(const float *__rest
     if (live) z[(size_t)row * N + j] = tanhf((d * rstd) * gamma[j] + beta[j]);
 }
 
+// ---- the 3-layer MLP trunks (QFunction src/algorithms/modules.py:247-261, Actor.mlp :200-215) around their library
+// GEMMs: what ATen spreads over bias-broadcast copies, clamp launches, a (B,H)x(H,1) GEMV, threshold_backward launches and
+// one reduce launch per bias gradient.  T trunks side by side (the twin Q functions: T = 2); twin strides in floats.
+//
+// k_mlp_out_fwd: z (T,B,H) holds a1 W2^T (plain batched GEMM, no bias).  In place a2 = relu(z + b2[t]) and
+// q[t][b] = a2[t][b] . w3[t] + b3[t].  One wave per row, lanes stride the row, xor-tree sum: a fixed order.
+__global__ __launch_bounds__(256) void k_mlp_out_fwd(float *__restrict__ z, const float *__restrict__ b2, int64_t b2_ts,
+                                                     const float *__restrict__ w3, int64_t w3_ts,
+                                                     const float *__restrict__ b3, int64_t b3_ts, float *__restrict__ q,
+                                                     int T, int B, int H)
+{
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6); // = t * B + b
+    if (row >= T * B) return;
+    const int t = row / B;
+    float *zr = z + (size_t)row * H;
+    const float *bb = b2 + t * b2_ts, *ww = w3 + t * w3_ts;
+    float s = 0.0f;
+    for (int c = lane; c < H; c += 64) {
+        float v = zr[c] + bb[c];
+        v = v < 0.0f ? 0.0f : v; // relu (NaN stays NaN, like clamp_min)
+        zr[c] = v;
+        s = __builtin_fmaf(v, ww[c], s);
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) q[row] = s + b3[t * b3_ts];
+}
+
+// k_mlp_out_bwd: from g[t][b] = dL/dq: dz2[t][b][c] = (a2 > 0) ? g w3[t][c] : 0, and (when wanted) dw3[t][c] = sum_b g a2,
+// db2[t][c] = sum_b dz2, db3[t] = sum_b g.  One workgroup = 32 columns of one trunk x 32 row groups; each row group sums
+// every 32nd row, the 32 partial sums are added in row-group order (deterministic).
+__global__ __launch_bounds__(1024) void k_mlp_out_bwd(const float *__restrict__ g0, const float *__restrict__ g1,
+                                                      const float *__restrict__ a2, const float *__restrict__ w3,
+                                                      int64_t w3_ts, float *__restrict__ dz2, float *__restrict__ dw3,
+                                                      float *__restrict__ db3, float *__restrict__ db2, int B, int H)
+{
+    __shared__ float red[3][32][33];
+    const int t = blockIdx.y, cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    const float *g = t ? g1 : g0;
+    const float w = c < H ? w3[t * w3_ts + c] : 0.0f;
+    float sw = 0.0f, sb = 0.0f, sg = 0.0f;
+    if (c < H) {
+        const size_t base = (size_t)t * B * H + c;
+#pragma unroll 4
+        for (int r = rg; r < B; r += 32) {
+            const float gv = g[r], av = a2[base + (size_t)r * H];
+            const float d = av > 0.0f ? gv * w : 0.0f;
+            dz2[base + (size_t)r * H] = d;
+            sb += d;
+            sw = __builtin_fmaf(gv, av, sw);
+        }
+    }
+    if (db3 && blockIdx.x == 0 && cl == 0)
+        for (int r = rg; r < B; r += 32) sg += g[r];
+    red[0][rg][cl] = sw;
+    red[1][rg][cl] = sb;
+    red[2][rg][cl] = sg;
+    __syncthreads();
+    if (rg < 3) { // row group k of the first three finishes sum k
+        float tsum = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) tsum += red[rg][k][cl];
+        if (rg == 0 && dw3 && c < H) dw3[(size_t)t * H + c] = tsum;
+        if (rg == 1 && db2 && c < H) db2[(size_t)t * H + c] = tsum;
+        if (rg == 2 && db3 && blockIdx.x == 0 && cl == 0) db3[t] = tsum;
+    }
+}
+
+// k_mask_colsum: the ReLU gate of a hidden layer and the bias gradient of the Linear under it in one pass:
+// dz[b][c] = (a[b][c] > 0) ? dz[b][c] : 0 in place, db[c] = sum_b dz[b][c]; the extra workgroups column-sum a second,
+// narrow matrix ex (B,E) as it is (the output layer's bias gradient).  Same fixed-order sums as above.
+__global__ __launch_bounds__(1024) void k_mask_colsum(float *__restrict__ dz, const float *__restrict__ a,
+                                                      float *__restrict__ db, const float *__restrict__ ex,
+                                                      float *__restrict__ dex, int B, int N, int E, int nblk_main)
+{
+    __shared__ float red[32][33];
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const bool main_part = (int)blockIdx.x < nblk_main;
+    const int c = (main_part ? (int)blockIdx.x : (int)blockIdx.x - nblk_main) * 32 + cl;
+    float s = 0.0f;
+    if (main_part) {
+        if (c < N) {
+#pragma unroll 4
+            for (int r = rg; r < B; r += 32) {
+                const size_t i = (size_t)r * N + c;
+                const float d = a[i] > 0.0f ? dz[i] : 0.0f;
+                dz[i] = d;
+                s += d;
+            }
+        }
+    } else if (c < E) {
+        for (int r = rg; r < B; r += 32) s += ex[(size_t)r * E + c];
+    }
+    red[rg][cl] = s;
+    __syncthreads();
+    if (rg == 0) {
+        float tsum = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) tsum += red[k][cl];
+        if (main_part) {
+            if (db && c < N) db[c] = tsum;
+        } else if (c < E) {
+            dex[c] = tsum;
+        }
+    }
+}
+
 } // namespace augcl
 
 using namespace augcl;
@@ -487,16 +596,16 @@ int augcl_gauss_head_forward(const float *raw, const float *noise, float *mu_t, 
 }
 
 int augcl_gauss_head_backward(const float *raw, const float *noise, const float *g_mu_t, const float *g_pi_t,
-                              const float *g_log_pi, const float *g_log_std, float *g_raw, int B, int A,
+                              int g_pi_ld, const float *g_log_pi, const float *g_log_std, float *g_raw, int B, int A,
                               double log_std_min, double log_std_max, augcl_stream_t stream)
 {
     const char *name = "augcl_gauss_head_backward";
-    AUGCL_REQUIRE(B >= 0 && A >= 1, "%s: bad shape", name);
+    AUGCL_REQUIRE(B >= 0 && A >= 1 && (!g_pi_t || g_pi_ld >= A), "%s: bad shape", name);
     if (B == 0) return AUGCL_OK;
     AUGCL_REQUIRE(raw && g_raw, "%s: null tensor", name);
     GaussArgs a{};
     a.raw = raw; a.noise = noise; a.g_mu_t = g_mu_t; a.g_pi_t = g_pi_t; a.g_log_pi = g_log_pi; a.g_log_std = g_log_std;
-    a.g_raw = g_raw; a.B = B; a.A = A;
+    a.g_raw = g_raw; a.B = B; a.A = A; a.g_pi_ld = g_pi_ld;
     a.lo = (float)log_std_min; a.k = (float)(0.5 * (log_std_max - log_std_min));
     hipLaunchKernelGGL(k_gauss_head_bwd, dim3((B + 255) / 256), dim3(256), 0, as_stream(stream), a);
     return augcl::check_launch(name);
@@ -583,16 +692,17 @@ int augcl_ln_tanh_forward(const float *x, const float *gamma, const float *beta,
     return augcl::check_launch(name);
 }
 
-int augcl_ln_tanh_backward(const float *x, const float *gamma, const float *y, const float *gy, float *dx, float *dgamma,
-                           float *dbeta, float *dbias, float *workspace /* 2*B*D floats */, int B, int D, double eps,
-                           augcl_stream_t stream)
+int augcl_ln_tanh_backward(const float *x, const float *gamma, const float *y, const float *gy, int gy_ld, float *dx,
+                           float *dgamma, float *dbeta, float *dbias, float *workspace /* 2*B*D floats */, int B, int D,
+                           double eps, augcl_stream_t stream)
 {
     const char *name = "augcl_ln_tanh_backward";
-    AUGCL_REQUIRE(B >= 1 && D >= 1 && D <= 256, "%s: bad shape (D <= 256)", name);
+    AUGCL_REQUIRE(B >= 1 && D >= 1 && D <= 256 && gy_ld >= D, "%s: bad shape (D <= 256, gy_ld >= D)", name);
     AUGCL_REQUIRE(x && gamma && y && gy && dx && dgamma && dbeta && workspace, "%s: null tensor", name);
     float *g1 = workspace, *g1x = workspace + (size_t)B * D;
     hipStream_t s = as_stream(stream);
-    hipLaunchKernelGGL(k_ln_tanh_bwd, dim3((B + 3) / 4), dim3(256), 0, s, x, gamma, y, gy, dx, g1, g1x, B, D, (float)eps);
+    hipLaunchKernelGGL(k_ln_tanh_bwd, dim3((B + 3) / 4), dim3(256), 0, s, x, gamma, y, gy, dx, g1, g1x, B, D, (float)eps,
+                       gy_ld);
     hipLaunchKernelGGL(k_colsum3, dim3((D + 31) / 32, dbias ? 3 : 2), dim3(256), 0, s, g1, g1x, dx, dbeta, dgamma, dbias, B, D);
     return augcl::check_launch(name);
 }
@@ -628,6 +738,42 @@ int augcl_proj_ln_tanh_forward(const float *x, const float *w, const float *bias
     hipLaunchKernelGGL(k_proj_partial, dim3((M + 31) / 32, S), dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_proj_reduce_ln_tanh, dim3((M + 1) / 2), dim3(256), 0, s, workspace, bias, gamma, beta, y, z, M, N, S,
                        (float)eps);
+    return augcl::check_launch(name);
+}
+
+int augcl_mlp_out_forward(float *z, const float *b2, int64_t b2_twin_stride, const float *w3, int64_t w3_twin_stride,
+                          const float *b3, int64_t b3_twin_stride, float *q, int T, int B, int H, augcl_stream_t stream)
+{
+    const char *name = "augcl_mlp_out_forward";
+    AUGCL_REQUIRE(T >= 1 && B >= 0 && H >= 1 && (size_t)T * B < (1u << 30), "%s: bad shape", name);
+    if (B == 0) return AUGCL_OK;
+    AUGCL_REQUIRE(z && b2 && w3 && b3 && q, "%s: null tensor", name);
+    hipLaunchKernelGGL(k_mlp_out_fwd, dim3((T * B + 3) / 4), dim3(256), 0, as_stream(stream), z, b2, b2_twin_stride, w3,
+                       w3_twin_stride, b3, b3_twin_stride, q, T, B, H);
+    return augcl::check_launch(name);
+}
+
+int augcl_mlp_out_backward(const float *g0, const float *g1, const float *a2, const float *w3, int64_t w3_twin_stride,
+                           float *dz2, float *dw3, float *db3, float *db2, int T, int B, int H, augcl_stream_t stream)
+{
+    const char *name = "augcl_mlp_out_backward";
+    AUGCL_REQUIRE((T == 1 || T == 2) && B >= 1 && H >= 1, "%s: bad shape (T = 1 or 2 trunks, B >= 1)", name);
+    AUGCL_REQUIRE(g0 && (T == 1 || g1) && a2 && w3 && dz2, "%s: null tensor", name);
+    hipLaunchKernelGGL(k_mlp_out_bwd, dim3((H + 31) / 32, T), dim3(1024), 0, as_stream(stream), g0, g1, a2, w3,
+                       w3_twin_stride, dz2, dw3, db3, db2, B, H);
+    return augcl::check_launch(name);
+}
+
+int augcl_mask_colsum(float *dz, const float *a, float *db, const float *extra, float *dextra, int B, int N, int E,
+                      augcl_stream_t stream)
+{
+    const char *name = "augcl_mask_colsum";
+    AUGCL_REQUIRE(B >= 1 && N >= 1 && E >= 0, "%s: bad shape", name);
+    AUGCL_REQUIRE(dz && a, "%s: null tensor", name);
+    AUGCL_REQUIRE(E == 0 || (extra && dextra), "%s: extra matrix without its buffers", name);
+    const int nb = (N + 31) / 32;
+    hipLaunchKernelGGL(k_mask_colsum, dim3(nb + (E + 31) / 32), dim3(1024), 0, as_stream(stream), dz, a, db, extra, dextra, B,
+                       N, E, nb);
     return augcl::check_launch(name);
 }
 

@@ -5,6 +5,8 @@ EMA is one pass per tau segment (augcl_ema_f32) and (c) the data-parallel gradie
 single all-reduce of one bucket, with shared tensors (the CNN used by actor AND critic,
 src/algorithms/sac.py:17-32) appearing exactly once.
 """
+import ctypes
+
 import torch
 
 from . import _lib
@@ -45,6 +47,7 @@ class FlatGroup:
             off = (off + k + align - 1) // align * align  # keep every tensor 16-byte aligned
         self.numel = off
         self.cut_index = 0  # see mark_cut()
+        self.prepped = False  # a gather launch has advanced the optimiser's device-side step for the coming Adam launch
         self.param = torch.zeros(off, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
         self.params = []
@@ -73,14 +76,18 @@ class FlatGroup:
                 self.param[a:b].copy_(p.data.reshape(-1))
                 p.data = self.param[a:b].view(self.shapes[n])
 
-    def gather_grads(self):
-        """Copy the parameters' autograd gradients into the flat bucket (one multi-tensor launch).  Returns the names
-        of the parameters that have NO gradient (torch.optim.Adam skips those: no moment decay, no step)."""
-        return self.scatter_into_bucket([p.grad for p in self.params])
+    def gather_grads(self, step_prep=None):
+        """Copy the parameters' autograd gradients into the flat bucket (one launch).  Returns the names of the
+        parameters that have NO gradient (torch.optim.Adam skips those: no moment decay, no step)."""
+        return self.scatter_into_bucket([p.grad for p in self.params], step_prep=step_prep)
 
-    def scatter_into_bucket(self, grads, names=None):
+    def scatter_into_bucket(self, grads, names=None, step_prep=None):
+        """grads[i] -> the bucket slot of names[i] (default: all of the group's tensors, in order).  On the GPU one
+        augcl_gather_f32 launch (the pointer table rides in the kernel arguments); step_prep = (device step state, lr,
+        beta1, beta2) lets that launch also advance the optimiser's device-side step count -- `self.prepped` then tells
+        FlatAdam that its Adam launch needs no preparation launch of its own."""
         g = self
-        views, srcs, missing = [], [], []
+        dsts, srcs, missing = [], [], []
         names = g.names if names is None else names
         if all(t is None for t in grads):
             return list(names)  # nothing to copy; the caller skips these tensors (no zero-fill launches either)
@@ -92,10 +99,26 @@ class FlatGroup:
                 continue
             if t.data_ptr() == g.grad[a:b].data_ptr():
                 continue  # already in the bucket
-            views.append(g.grad[a:b].view(g.shapes[n]))
+            dsts.append((a, b))
             srcs.append(t)
-        if srcs:
-            torch._foreach_copy_(views, srcs)
+        if not srcs:
+            return missing
+        if g.grad.is_cuda and all(t.is_cuda and t.dtype == torch.float32 for t in srcs):
+            srcs = [t if t.is_contiguous() else t.contiguous() for t in srcs]
+            k = len(srcs)
+            ptrs = (ctypes.c_void_p * k)(*[t.data_ptr() for t in srcs])
+            offs = (ctypes.c_int64 * k)(*[a for a, _ in dsts])
+            lens = (ctypes.c_int64 * k)(*[b - a for a, b in dsts])
+            assert all(t.numel() == b - a for t, (a, b) in zip(srcs, dsts))
+            prep = step_prep if (step_prep is not None and not missing) else None
+            _lib.call("augcl_gather_f32", ctypes.cast(ptrs, ctypes.c_void_p), ctypes.cast(offs, ctypes.c_void_p),
+                      ctypes.cast(lens, ctypes.c_void_p), k, g.grad.data_ptr(), None if prep is None else prep[0],
+                      0.0 if prep is None else prep[1], 0.0 if prep is None else prep[2], 0.0 if prep is None else prep[3],
+                      _lib.current_stream(g.grad.device))
+            if prep is not None:
+                g.prepped = True
+        else:
+            torch._foreach_copy_([g.grad[a:b].view(t.shape) for (a, b), t in zip(dsts, srcs)], srcs)
         return missing
 
     def segment(self, prefix):
@@ -112,7 +135,7 @@ class FlatAdam:
 
     Gradients: zero_grad() drops the parameters' .grad (set_to_none), so autograd hands every parameter a fresh
     gradient tensor without an accumulate kernel; step() gathers them into the flat gradient bucket with one
-    multi-tensor copy (the bucket is what the data-parallel all-reduce and the fused Adam kernel consume).
+    launch (augcl_gather_f32; the bucket is what the data-parallel all-reduce and the fused Adam kernel consume).
     Pre-assigned .grad views would cost one `grad += new` launch per parameter per backward (~40 per step)."""
 
     def __init__(self, group, lr, betas=(0.9, 0.999), eps=1e-8, reducer=None):
@@ -123,6 +146,7 @@ class FlatAdam:
         self._tensor_steps = None  # per-tensor step counts, only once some parameter has missed a gradient
         self.step_state = None  # device-side {int64 step, 2 floats}: set by make_capturable()
         self.reducer = reducer  # data-parallel gradient exchange (dist.GradReducer) or None
+        self._unit = {}  # the backward pass's seed gradient d(loss)/d(loss) = 1, kept instead of one fill launch per step
 
     @property
     def step_count(self):
@@ -149,6 +173,13 @@ class FlatAdam:
         for p in self.group.params:
             p.grad = None
 
+    def _step_prep(self):
+        """What a gather launch needs to advance the device-side step on this optimiser's behalf (None: host-side steps,
+        or per-tensor step counts are in use)."""
+        if self.step_state is None or self._tensor_steps is not None:
+            return None
+        return (self.step_state.data_ptr(), self.lr, self.betas[0], self.betas[1])
+
     def backward_step(self, loss, cut=None):
         """zero_grad(); loss.backward(); step() of the reference in one go: gradients are taken ONLY with respect to
         this group's parameters (torch.autograd.grad prunes every other weight-gradient branch, e.g. the critic's
@@ -162,16 +193,20 @@ class FlatAdam:
         bucket (the projection and the Q / policy heads: 97 % of the bytes) is all-reduced on the side while the conv
         stack's backward runs; the small conv slice follows.  Returns what backward_finish() needs."""
         g, r = self.group, self.reducer
+        key = (tuple(loss.shape), loss.dtype, loss.device)
+        if key not in self._unit:
+            self._unit[key] = torch.ones_like(loss, requires_grad=False)
+        one = self._unit[key]
         cut = [t for t in (cut or []) if t.requires_grad]
         overlap = (r is not None and r.world > 1 and cut and 0 < g.cut_index < len(g.params)
                    and not (g.param.is_cuda and torch.cuda.is_current_stream_capturing()))
         if not overlap:
-            grads = torch.autograd.grad(loss, g.params, allow_unused=True)
-            return g.scatter_into_bucket(grads), []
+            grads = torch.autograd.grad(loss, g.params, grad_outputs=one, allow_unused=True)
+            return g.scatter_into_bucket(grads, step_prep=self._step_prep()), []
         k = g.cut_index
         split = g.slices[g.names[k]][0]
-        grads = torch.autograd.grad(loss, g.params[k:] + cut, allow_unused=True)
-        missing = g.scatter_into_bucket(grads[:len(g.params) - k], g.names[k:])
+        grads = torch.autograd.grad(loss, g.params[k:] + cut, grad_outputs=one, allow_unused=True)
+        missing = g.scatter_into_bucket(grads[:len(g.params) - k], g.names[k:], step_prep=self._step_prep())
         pending = [r.allreduce_sum_async(g.grad[split:])]
         d_cut = grads[len(g.params) - k:]
         live = [(t, d) for t, d in zip(cut, d_cut) if d is not None]
@@ -191,7 +226,7 @@ class FlatAdam:
         self._apply(missing, reduced=bool(pending))
 
     def step(self):
-        self._apply(self.group.gather_grads())
+        self._apply(self.group.gather_grads(self._step_prep()))
 
     def tensor_step(self, name):
         """Adam step count of one parameter (torch.optim.Adam keeps it per parameter)."""
@@ -234,9 +269,10 @@ class FlatAdam:
         if missing or self._tensor_steps is not None:
             return self._apply_partial(list(missing), scale)
         if self.step_state is not None:
+            advance, g.prepped = (0 if g.prepped else 1), False
             _lib.call("augcl_adam_f32_devstep", g.param.data_ptr(), g.grad.data_ptr(), self.exp_avg.data_ptr(),
                       self.exp_avg_sq.data_ptr(), g.numel, self.lr, self.betas[0], self.betas[1], self.eps,
-                      self.step_state.data_ptr(), scale, _lib.current_stream(g.param.device))
+                      self.step_state.data_ptr(), advance, scale, _lib.current_stream(g.param.device))
             return
         self._step_count += 1
         self._launch_adam(0, g.numel, self._step_count, scale)
@@ -308,6 +344,17 @@ class ScalarAdam:
             self.state[0] = float(torch.as_tensor(st["exp_avg"]))
             self.state[1] = float(torch.as_tensor(st["exp_avg_sq"]))
             self.state[2] = float(torch.as_tensor(st["step"]))
+
+
+def ema2_(target_flat, src_flat, seg0, seg1):
+    """Two (begin, end, tau) segments of the same flat buffers in one launch (SAC.soft_update_critic_target)."""
+    (a0, b0, t0), (a1, b1, t1) = seg0, seg1
+    n0, n1 = max(0, b0 - a0), max(0, b1 - a1)
+    if n0 == 0 and n1 == 0:
+        return
+    tp, sp = target_flat.data_ptr(), src_flat.data_ptr()
+    _lib.call("augcl_ema2_f32", tp + 4 * a0, sp + 4 * a0, n0, float(t0), tp + 4 * a1, sp + 4 * a1, n1, float(t1),
+              _lib.current_stream(target_flat.device))
 
 
 def ema_(target_flat, src_flat, begin, end, tau):

@@ -15,9 +15,26 @@ def _ok(*ts):
     return all(t.is_cuda and t.dtype == torch.float32 for t in ts)
 
 
+# Test instrumentation: when set, called as gate_hook(kind, a1, a2) with the post-ReLU hidden activations of every fused
+# MLP forward ("twin": a1 (B, 2H) = [Q1 | Q2], a2 (2, B, H); "mlp3": (B, H) each).  The ReLUs of these trunks run inside
+# GEMM epilogues and HIP kernels, where no nn.ReLU forward hook can see them (tests/test_referee_gpu.py reads the gates).
+gate_hook = None
+
+
+def _rows(t, width):
+    """(tensor, row stride in floats) for a (B, width) gradient the kernels can read in place: unit column stride, any
+    row stride >= width (a column slice of a wider matrix); anything else is made contiguous first."""
+    if t is None:
+        return None, width
+    if t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= width and t.dtype == torch.float32:
+        return t, t.stride(0)
+    return t.contiguous().float(), width
+
+
 class _GaussHead(torch.autograd.Function):
     @staticmethod
     def forward(ctx, raw, noise, lo, hi, want_log_pi):
+        ctx.set_materialize_grads(False)  # absent output gradients arrive as None, not as zero-filled tensors
         raw = raw.contiguous()
         B, A2 = raw.shape
         A = A2 // 2
@@ -39,9 +56,10 @@ class _GaussHead(torch.autograd.Function):
         raw, n = ctx.saved_tensors
         B, A2 = raw.shape
         c = lambda t: None if t is None else t.contiguous()  # noqa: E731
-        g_mu, g_pi, g_lp, g_ls = c(g_mu), c(g_pi), c(g_lp), c(g_ls)
+        g_mu, g_lp, g_ls = c(g_mu), c(g_lp), c(g_ls)
+        g_pi, ld = _rows(g_pi, A2 // 2)  # usually the action columns of the critic's input gradient: read in place
         g_raw = torch.empty_like(raw)
-        _lib.call("augcl_gauss_head_backward", raw.data_ptr(), _lib.ptr(n), _lib.ptr(g_mu), _lib.ptr(g_pi), _lib.ptr(g_lp),
+        _lib.call("augcl_gauss_head_backward", raw.data_ptr(), _lib.ptr(n), _lib.ptr(g_mu), _lib.ptr(g_pi), ld, _lib.ptr(g_lp),
                   _lib.ptr(g_ls), g_raw.data_ptr(), B, A2 // 2, ctx.lohi[0], ctx.lohi[1], _lib.current_stream(raw.device))
         return g_raw, None, None, None, None
 
@@ -67,11 +85,11 @@ class _LnTanh(torch.autograd.Function):
     def backward(ctx, gy):
         x, gamma, y = ctx.saved_tensors
         B, D = x.shape
-        gy = gy.contiguous()
+        gy, ld = _rows(gy, D)
         dx = torch.empty_like(x)
         dgb = torch.empty((2, D), dtype=torch.float32, device=x.device)
         ws = torch.empty(2 * B * D, dtype=torch.float32, device=x.device)
-        _lib.call("augcl_ln_tanh_backward", x.data_ptr(), gamma.data_ptr(), y.data_ptr(), gy.data_ptr(), dx.data_ptr(),
+        _lib.call("augcl_ln_tanh_backward", x.data_ptr(), gamma.data_ptr(), y.data_ptr(), gy.data_ptr(), ld, dx.data_ptr(),
                   dgb[0].data_ptr(), dgb[1].data_ptr(), None, ws.data_ptr(), B, D, ctx.eps, _lib.current_stream(x.device))
         return dx, dgb[0], dgb[1], None
 
@@ -99,11 +117,11 @@ class _ProjLnTanh(torch.autograd.Function):
     def backward(ctx, gz):
         x, w, gamma, yz = ctx.saved_tensors
         M, N = yz.shape[1], yz.shape[2]
-        gz = gz.contiguous()
+        gz, ld = _rows(gz, N)  # usually the feature columns of the critic's input gradient: read in place
         dy = torch.empty((M, N), dtype=torch.float32, device=x.device)
         small = torch.empty((3, N), dtype=torch.float32, device=x.device)  # dgamma, dbeta, dbias
         ws = torch.empty(2 * M * N, dtype=torch.float32, device=x.device)
-        _lib.call("augcl_ln_tanh_backward", yz[0].data_ptr(), gamma.data_ptr(), yz[1].data_ptr(), gz.data_ptr(), dy.data_ptr(),
+        _lib.call("augcl_ln_tanh_backward", yz[0].data_ptr(), gamma.data_ptr(), yz[1].data_ptr(), gz.data_ptr(), ld, dy.data_ptr(),
                   small[0].data_ptr(), small[1].data_ptr(), small[2].data_ptr(), ws.data_ptr(), M, N, ctx.eps,
                   _lib.current_stream(x.device))
         dw = dy.t().mm(x) if ctx.needs_input_grad[1] else None
@@ -178,6 +196,7 @@ def actor_loss(log_pi, q1, q2, log_alpha):
 class _QLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q1, q2, y, weights):
+        ctx.set_materialize_grads(False)
         q1, q2, y = q1.contiguous(), q2.contiguous(), y.contiguous()
         M, S = y.shape[0], len(weights)
         assert q1.shape[0] == M * S and q2.shape == q1.shape
@@ -193,6 +212,8 @@ class _QLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_total, _g_segs):
+        if g_total is None:
+            return None, None, None, None
         q1, q2, y = ctx.saved_tensors
         M, S = y.shape[0], len(ctx.w)
         w = (ctypes.c_double * S)(*ctx.w)
@@ -221,43 +242,72 @@ def _stacked(p1, p2):
     return torch.stack([p1, p2])
 
 
+def _mask_colsum(dz, a, want_db, extra=None):
+    """dz <- (a > 0) ? dz : 0 in place (ReLU's backward); returns (column sums of the gated dz | None, column sums of
+    `extra` | None): the bias gradients of the Linear under the ReLU and -- riding along -- of the output layer."""
+    B, N = dz.shape
+    E = 0 if extra is None else extra.shape[1]
+    sums = torch.empty(N + E, dtype=torch.float32, device=dz.device) if (want_db or E) else None
+    _lib.call("augcl_mask_colsum", dz.data_ptr(), a.data_ptr(), sums.data_ptr() if want_db else None, _lib.ptr(extra),
+              (sums.data_ptr() + 4 * N) if E else None, B, N, E, _lib.current_stream(dz.device))
+    return (sums[:N] if want_db else None), (sums[N:] if E else None)
+
+
 class _TwinQ(torch.autograd.Function):
     """Q1(h, a), Q2(h, a) of src/algorithms/modules.py:247-276 -- two identical 3-layer MLPs over the same input -- as ONE
-    batched network: layer 1 is a single GEMM against the two weight matrices side by side, layers 2 and 3 are batched
-    GEMMs over the twin dimension, forward and backward.  6 launches forward / 13 backward (7 when only the input
-    gradient is wanted: the actor step) instead of 14 / 26 for two nn.Sequential trunks; the same additions in the same
-    order inside every dot product's GEMM, so values agree with the two-trunk form to GEMM rounding."""
+    batched network.  Forward, 4 launches: concat, ONE GEMM for both first layers with bias + ReLU in its epilogue
+    ((B, D) x (D, 2H), torch._addmm_activation), the batched second-layer GEMM, and augcl_mlp_out_forward (second bias +
+    ReLU in place, the H -> 1 output layer as a fixed-order dot product per row).  Backward, 6 launches (4 when only the
+    input gradient is wanted): augcl_mlp_out_backward (dz2 and the sums dW3, db3, db2), the batched GEMM to layer 1 written
+    in the (B, 2H) layout, augcl_mask_colsum (ReLU gate + db1), then plain GEMMs over the 2H dimension for dx (both
+    trunks' contributions summed inside the GEMM), dW1 and the batched dW2.  Two nn.Sequential trunks are 14 + 26."""
 
     @staticmethod
     def forward(ctx, h, a, w1a, b1a, w2a, b2a, w3a, b3a, w1b, b1b, w2b, b2b, w3b, b3b):
+        ctx.set_materialize_grads(False)
         B, H = h.shape[0], w1a.shape[0]
         x = torch.cat([h, a], dim=1)
         W1, b1, W2, b2, W3, b3 = (_stacked(p, q) for p, q in ((w1a, w1b), (b1a, b1b), (w2a, w2b), (b2a, b2b), (w3a, w3b), (b3a, b3b)))
-        if W1.is_contiguous() and b1.is_contiguous():  # one GEMM for both first layers: (B, D) x (D, 2H)
-            # bias + ReLU in the GEMM's epilogue (one launch): torch._addmm_activation(bias, x, W^T) = relu(x W^T + bias)
-            a1 = torch._addmm_activation(b1.reshape(2 * H), x, W1.reshape(2 * H, -1).t()).view(B, 2, H).transpose(0, 1)
-        else:
-            a1 = torch.relu_(torch.baddbmm(b1.unsqueeze(1), x.unsqueeze(0).expand(2, B, -1), W1.transpose(1, 2)))
-        a2 = torch.relu_(torch.baddbmm(b2.unsqueeze(1), a1, W2.transpose(1, 2)))
-        q = torch.baddbmm(b3.unsqueeze(1), a2, W3.transpose(1, 2))  # (2, B, 1)
-        ctx.save_for_backward(x, a1, a2, W1, W2, W3)
+        if not (W1.is_contiguous() and b1.is_contiguous()):  # padding between the twins' tensors: stacked copies
+            W1, b1 = W1.contiguous(), b1.contiguous()
+        # bias + ReLU in the GEMM's epilogue (one launch): torch._addmm_activation(bias, x, W^T) = relu(x W^T + bias)
+        a1 = torch._addmm_activation(b1.reshape(2 * H), x, W1.reshape(2 * H, -1).t())  # (B, 2H) = [Q1 | Q2]
+        z2 = torch.bmm(a1.view(B, 2, H).transpose(0, 1), W2.transpose(1, 2))            # (2, B, H), no bias yet
+        q = torch.empty((2, B, 1), dtype=torch.float32, device=h.device)
+        _lib.call("augcl_mlp_out_forward", z2.data_ptr(), b2.data_ptr(), b2.stride(0), W3.data_ptr(), W3.stride(0),
+                  b3.data_ptr(), b3.stride(0), q.data_ptr(), 2, B, H, _lib.current_stream(h.device))
+        if gate_hook is not None:
+            gate_hook("twin", a1, z2)
+        ctx.save_for_backward(x, a1, z2, W1, W2, W3)  # z2 now holds a2 = relu(z2 + b2)
         ctx.n_h = h.shape[1]
         return q[0], q[1]
 
     @staticmethod
     def backward(ctx, g1, g2):
         x, a1, a2, W1, W2, W3 = ctx.saved_tensors
-        B = x.shape[0]
+        B, H = x.shape[0], a2.shape[2]
+        dev = x.device
         want_w = any(ctx.needs_input_grad[2:])
-        dq = torch.stack([g1, g2])                                       # (2, B, 1)
-        dz2 = torch.ops.aten.threshold_backward(torch.bmm(dq, W3), a2, 0)  # (2, B, H): ReLU gate of layer 2
-        dz1 = torch.ops.aten.threshold_backward(torch.bmm(dz2, W2), a1, 0)
-        dx = torch.bmm(dz1, W1).sum(0) if (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) else None
+        want_x = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        if g1 is None and g2 is None:
+            return (None,) * 14
+        g1 = torch.zeros((B, 1), dtype=torch.float32, device=dev) if g1 is None else g1.contiguous()
+        g2 = torch.zeros((B, 1), dtype=torch.float32, device=dev) if g2 is None else g2.contiguous()
+        dz2 = torch.empty_like(a2)
+        small = torch.empty(2 * H + 2 + 2 * H, dtype=torch.float32, device=dev) if want_w else None  # dW3 | db3 | db2
+        sp = (lambda off: small.data_ptr() + 4 * off) if want_w else (lambda off: None)
+        _lib.call("augcl_mlp_out_backward", g1.data_ptr(), g2.data_ptr(), a2.data_ptr(), W3.data_ptr(), W3.stride(0),
+                  dz2.data_ptr(), sp(0), sp(2 * H), sp(2 * H + 2), 2, B, H, _lib.current_stream(dev))
+        dz1 = torch.empty((B, 2 * H), dtype=torch.float32, device=dev)  # [Q1 | Q2] per row, like a1
+        torch.bmm(dz2, W2, out=dz1.view(B, 2, H).transpose(0, 1))
+        db1, _ = _mask_colsum(dz1, a1, want_w)
+        dx = dz1.mm(W1.reshape(2 * H, -1)) if want_x else None  # the sum over the two trunks happens inside the GEMM
         gw = [None] * 12
         if want_w:
-            dW3, db3 = torch.bmm(dq.transpose(1, 2), a2), dq.sum(1)
-            dW2, db2 = torch.bmm(dz2.transpose(1, 2), a1), dz2.sum(1)
-            dW1, db1 = torch.bmm(dz1.transpose(1, 2), x.unsqueeze(0).expand(2, B, -1)), dz1.sum(1)
+            dW1 = dz1.t().mm(x).view(2, H, -1)
+            dW2 = torch.bmm(dz2.transpose(1, 2), a1.view(B, 2, H).transpose(0, 1))
+            dW3, db3, db2 = small[:2 * H].view(2, 1, H), small[2 * H:2 * H + 2].view(2, 1), small[2 * H + 2:].view(2, H)
+            db1 = db1.view(2, H)
             for t in (0, 1):
                 gw[6 * t:6 * t + 6] = [dW1[t], db1[t], dW2[t], db2[t], dW3[t], db3[t]]
         dh = dx[:, :ctx.n_h] if dx is not None and ctx.needs_input_grad[0] else None
@@ -265,8 +315,52 @@ class _TwinQ(torch.autograd.Function):
         return (dh, da, *gw)
 
 
-def twin_q(h, a, q1, q2):
-    """(Q1(h, a), Q2(h, a)) for two modules.QFunction with 3-layer trunks (Linear, ReLU, Linear, ReLU, Linear)."""
+def twin_q(h, a, q1, q2, freeze=False):
+    """(Q1(h, a), Q2(h, a)) for two modules.QFunction with 3-layer trunks (Linear, ReLU, Linear, ReLU, Linear).
+    freeze: the trunks' weights take part as constants (the actor step, src/algorithms/sac.py:119-133: the reference
+    builds their gradients there and throws them away at the next critic zero_grad)."""
     t1, t2 = q1.trunk, q2.trunk
-    return _TwinQ.apply(h, a, t1[0].weight, t1[0].bias, t1[2].weight, t1[2].bias, t1[4].weight, t1[4].bias,
-                        t2[0].weight, t2[0].bias, t2[2].weight, t2[2].bias, t2[4].weight, t2[4].bias)
+    ps = (t1[0].weight, t1[0].bias, t1[2].weight, t1[2].bias, t1[4].weight, t1[4].bias,
+          t2[0].weight, t2[0].bias, t2[2].weight, t2[2].bias, t2[4].weight, t2[4].bias)
+    if freeze:
+        ps = tuple(p.detach() for p in ps)
+    return _TwinQ.apply(h, a, *ps)
+
+
+class _Mlp3(torch.autograd.Function):
+    """Linear-ReLU-Linear-ReLU-Linear (Actor.mlp, src/algorithms/modules.py:200-215) as one node: forward = three library
+    GEMMs, bias + ReLU in the epilogue of the first two; backward = the five GEMMs a 3-layer MLP needs (six with dx) and
+    two augcl_mask_colsum launches that gate dz AND deliver all three bias gradients.  3 + 8 launches instead of 5 + 13."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, w3, b3):
+        ctx.set_materialize_grads(False)
+        x = x.contiguous()
+        a1 = torch._addmm_activation(b1, x, w1.t())
+        a2 = torch._addmm_activation(b2, a1, w2.t())
+        out = torch.addmm(b3, a2, w3.t())
+        if gate_hook is not None:
+            gate_hook("mlp3", a1, a2)
+        ctx.save_for_backward(x, a1, a2, w1, w2, w3)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return (None,) * 7
+        x, a1, a2, w1, w2, w3 = ctx.saved_tensors
+        g = g.contiguous()
+        want_w = any(ctx.needs_input_grad[1:])
+        dz2 = g.mm(w3)
+        db2, db3 = _mask_colsum(dz2, a2, want_w, g if want_w else None)
+        dz1 = dz2.mm(w2)
+        db1, _ = _mask_colsum(dz1, a1, want_w)
+        dx = dz1.mm(w1) if ctx.needs_input_grad[0] else None
+        if not want_w:
+            return (dx,) + (None,) * 6
+        return dx, dz1.t().mm(x), db1, dz2.t().mm(a1), db2, g.t().mm(a2), db3
+
+
+def mlp3(x, seq):
+    """seq(x) for an nn.Sequential(Linear, ReLU, Linear, ReLU, Linear) on float32 device tensors."""
+    return _Mlp3.apply(x, seq[0].weight, seq[0].bias, seq[2].weight, seq[2].bias, seq[4].weight, seq[4].bias)

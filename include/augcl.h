@@ -164,11 +164,18 @@ int augcl_adam_f32(float *param, const float *grad, float *exp_avg, float *exp_a
                    double lr, double beta1, double beta2, double eps, int64_t step, double grad_scale,
                    augcl_stream_t stream);
 /* Same step with the step count kept ON THE DEVICE: step_state = 16 bytes {int64 step; float scratch[2]}, 8-byte
- * aligned, zero-initialised by the caller.  The call increments the count in stream order and derives the bias
- * corrections from it, so it can be captured in a hipGraph and replayed (no host scalar is baked in). */
+ * aligned, zero-initialised by the caller.  advance != 0: the call increments the count in stream order and derives the
+ * bias corrections from it (a 1-thread launch in front of the step); advance == 0: augcl_gather_f32(step_state = ...)
+ * has already done so for this step.  Either way no host scalar is baked in: capturable in a hipGraph. */
 int augcl_adam_f32_devstep(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n,
-                           double lr, double beta1, double beta2, double eps, void *step_state, double grad_scale,
-                           augcl_stream_t stream);
+                           double lr, double beta1, double beta2, double eps, void *step_state, int advance,
+                           double grad_scale, augcl_stream_t stream);
+/* Gradient gather in front of the flat Adam step (what loss.backward() + the optimiser's per-parameter loop do to
+ * p.grad in the reference, src/algorithms/sac.py:114-116): tensor i (numel[i] contiguous floats at src[i], 4-byte
+ * aligned) is copied to dst + dst_offset[i]; one launch per 96 tensors, the table passed by value (host arrays are read
+ * during the call only).  step_state != NULL: the launch also advances that optimiser's device-side step (see above). */
+int augcl_gather_f32(const void *const *src, const int64_t *dst_offset, const int64_t *numel, int n_tensors, float *dst,
+                     void *step_state, double lr, double beta1, double beta2, augcl_stream_t stream);
 
 /* ---- SAC heads: the element-wise tails of the policy / critic heads as single launches.
  * Squashed-Gaussian policy head = Actor.forward after its MLP (src/algorithms/modules.py:225-244) with
@@ -176,12 +183,13 @@ int augcl_adam_f32_devstep(float *param, const float *grad, float *exp_avg, floa
  *   log_std = min + 0.5 (max-min) (tanh(raw_ls) + 1); pi = mu + noise exp(log_std);
  *   log_pi = sum(-0.5 noise^2 - log_std) - 0.5 log(2 pi) A - sum log(relu(1 - tanh(pi)^2) + 1e-6);
  * outputs tanh(mu), tanh(pi), log_pi (B,1), log_std.  noise = NULL: compute_pi = False (mu_t, log_std only).
- * backward: gradients of the four outputs (NULL = none) -> g_raw (B,2A); recomputes from raw / noise. */
+ * backward: gradients of the four outputs (NULL = none) -> g_raw (B,2A); recomputes from raw / noise.  g_pi_ld = row
+ * stride of g_pi_t in floats (A when contiguous; it is usually a column slice of the critic's input gradient). */
 int augcl_gauss_head_forward(const float *raw, const float *noise, float *mu_t, float *pi_t, float *log_pi,
                              float *log_std, int B, int A, double log_std_min, double log_std_max,
                              augcl_stream_t stream);
 int augcl_gauss_head_backward(const float *raw, const float *noise, const float *g_mu_t, const float *g_pi_t,
-                              const float *g_log_pi, const float *g_log_std, float *g_raw, int B, int A,
+                              int g_pi_ld, const float *g_log_pi, const float *g_log_std, float *g_raw, int B, int A,
                               double log_std_min, double log_std_max, augcl_stream_t stream);
 /* SAC.calculate_target_Q (src/algorithms/sac.py:94-101):
  *   out = reward + (not_done * discount) * (min(tq1,tq2) - alpha * log_pi); alpha read from a device double. */
@@ -201,6 +209,22 @@ int augcl_actor_loss_backward(const float *q1, const float *q2, const double *lo
  * from state[3] (data parallel: average state[3] over ranks in between); out (may be NULL) = {alpha_loss, alpha}. */
 int augcl_alpha_step_f64(double *log_alpha, const float *log_pi, int B, double target_entropy, double lr, double beta1,
                          double beta2, double eps, double *state, float *out, int mode, augcl_stream_t stream);
+/* The 3-layer MLP trunks -- QFunction.trunk (src/algorithms/modules.py:247-261; Critic's Q1 / Q2, :264-276, run as T = 2
+ * trunks side by side) and Actor.mlp (:200-215) -- around their library GEMMs.  Twin strides are in floats (the twin's
+ * tensors sit at fixed distances inside the flat parameter buffer).
+ * forward: z (T,B,H) = a1 W2^T as the batched GEMM left it (no bias); in place a2 = relu(z + b2[t]);
+ *   q[t*B + b] = a2[t][b] . w3[t] + b3[t]  (fixed-order sum per row).
+ * backward: g0 / g1 (B) = dL/dq of trunk 0 / 1; dz2[t][b][c] = a2 > 0 ? g w3[t][c] : 0; optional (NULL = skip)
+ *   dw3 (T,H) = sum_b g a2, db3 (T) = sum_b g, db2 (T,H) = sum_b dz2, all fixed-order. */
+int augcl_mlp_out_forward(float *z, const float *b2, int64_t b2_twin_stride, const float *w3, int64_t w3_twin_stride,
+                          const float *b3, int64_t b3_twin_stride, float *q, int T, int B, int H, augcl_stream_t stream);
+int augcl_mlp_out_backward(const float *g0, const float *g1, const float *a2, const float *w3, int64_t w3_twin_stride,
+                           float *dz2, float *dw3, float *db3, float *db2, int T, int B, int H, augcl_stream_t stream);
+/* ReLU gate + bias gradient of a hidden Linear in one pass (torch's threshold_backward + sum(0)):
+ *   dz (B,N) <- a > 0 ? dz : 0 in place; db (N, may be NULL) = column sums of the gated dz; extra (B,E) with E > 0:
+ *   dextra (E) = its plain column sums (the output layer's bias gradient rides along). */
+int augcl_mask_colsum(float *dz, const float *a, float *db, const float *extra, float *dextra, int B, int N, int E,
+                      augcl_stream_t stream);
 /* Twin-Q loss (sac.py:108-110; svea.py:37-56 with S = 2 segments of one 2B batch against the same M targets):
  *   seg[s] = mse(q1[sM:(s+1)M], y) + mse(q2[...], y); out = {sum_s w[s] seg[s], seg[0..S)}; S <= 4; w on the host.
  * One workgroup, fixed-order tree sum (deterministic).  backward: dq = g_total * w[s] * 2 (q - y) / M. */
@@ -210,11 +234,13 @@ int augcl_q_loss_backward(const float *q1, const float *q2, const float *y, cons
                           const double *w, float *dq1, float *dq2, augcl_stream_t stream);
 
 /* RLProjection's tail (src/algorithms/modules.py:101-111): y = tanh(LayerNorm(x; eps) * gamma + beta) on (B,D) rows,
- * D <= 256, and its backward (dx, dgamma, dbeta; workspace = 2*B*D floats; fixed-order sums). */
+ * D <= 256, and its backward (dx, dgamma, dbeta; workspace = 2*B*D floats; fixed-order sums); gy_ld = row stride of
+ * gy in floats (D when contiguous). */
 int augcl_ln_tanh_forward(const float *x, const float *gamma, const float *beta, float *y, int B, int D, double eps,
                           augcl_stream_t stream);
-int augcl_ln_tanh_backward(const float *x, const float *gamma, const float *y, const float *gy, float *dx, float *dgamma,
-                           float *dbeta, float *dbias /* may be NULL: column sums of dx = the bias gradient of the Linear in front */,
+int augcl_ln_tanh_backward(const float *x, const float *gamma, const float *y, const float *gy, int gy_ld, float *dx,
+                           float *dgamma, float *dbeta,
+                           float *dbias /* may be NULL: column sums of dx = the bias gradient of the Linear in front */,
                            float *workspace /* 2*B*D floats */, int B, int D, double eps, augcl_stream_t stream);
 /* RLProjection forward as a whole (src/algorithms/modules.py:101-111): y = x W^T + bias on the f32 MFMA pipe (split-K, every
  * partial sum added in a fixed order: bitwise reproducible), z = tanh(LayerNorm(y) * gamma + beta).  x (M,K), w (N,K)
@@ -229,6 +255,10 @@ int augcl_proj_ln_tanh_forward(const float *x, const float *w, const float *bias
  * SAC.soft_update_critic_target (src/algorithms/sac.py:148-153):
  *   target[i] = tau*src[i] + (1-tau)*target[i]   (separate IEEE ops, bit-exact vs torch f32) */
 int augcl_ema_f32(float *target, const float *src, size_t n, double tau, augcl_stream_t stream);
+/* The two segments SAC.soft_update_critic_target updates (Q1 + Q2 with critic_tau, the encoder with encoder_tau) in one
+ * launch; each segment exactly as augcl_ema_f32 (n0 or n1 may be 0). */
+int augcl_ema2_f32(float *target0, const float *src0, size_t n0, double tau0, float *target1, const float *src1, size_t n1,
+                   double tau1, augcl_stream_t stream);
 
 /* ---- shared conv encoder: SharedCNN / HeadCNN of src/algorithms/modules.py:145-181, i.e.
  * NormalizeImg (x/255) -> Conv2d(C,32,3,stride=2) -> [ReLU -> Conv2d(32,32,3)]*, and its backward.

@@ -43,6 +43,15 @@ def test_bad_arguments_are_reported_not_crashed():
     assert lib.augcl_green_screen_resize_u8(None, None, None, 1, 84, 84, 0, 320, None) == -1
     assert lib.augcl_alpha_step_f64(None, None, 4, -6.0, 1e-4, 0.5, 0.999, 1e-8, None, None, 3, None) == -1
     assert lib.augcl_actor_loss_forward(None, None, None, None, None, 4, None) == -1
+    assert lib.augcl_mlp_out_forward(None, None, 0, None, 0, None, 0, None, 2, 0, 1024, None) == 0  # empty batch
+    assert lib.augcl_mlp_out_forward(None, None, 0, None, 0, None, 0, None, 2, 8, 1024, None) == -1
+    assert lib.augcl_mlp_out_backward(None, None, None, None, 0, None, None, None, None, 3, 8, 1024, None) == -1
+    assert b"T = 1 or 2" in lib.augcl_last_error()
+    assert lib.augcl_mask_colsum(None, None, None, None, None, 8, 16, 0, None) == -1
+    assert lib.augcl_ema2_f32(None, None, 0, 0.5, None, None, 0, 0.5, None) == 0
+    assert lib.augcl_ema2_f32(None, None, 4, 0.5, None, None, 0, 0.5, None) == -1
+    assert lib.augcl_adam_f32_devstep(None, None, None, None, 0, 1e-3, 0.9, 0.999, 1e-8, None, 1, 1.0, None) == -1  # no step state
+    assert lib.augcl_gather_f32(None, None, None, 3, None, None, 0.0, 0.0, 0.0, None) == -1 and b"null table" in lib.augcl_last_error()
 
 
 def test_ops_fail_loudly_without_gpu_tensor():

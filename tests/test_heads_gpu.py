@@ -158,6 +158,97 @@ def test_twin_q_matches_two_trunks(cuda, B, A, flat_layout):
     assert torch.equal(gh.double(), res[2][2])  # the same launches as the full backward's input-gradient chain
 
 
+def test_twin_q_frozen_weights_same_input_gradient(cuda):
+    """freeze=True (the actor step): same values and input gradients, no weight gradient is built."""
+    torch.manual_seed(5)
+    B, A = 96, 4
+    q1, q2 = m.QFunction(50, A, 256).to(cuda), m.QFunction(50, A, 256).to(cuda)
+    h0, a0 = torch.tanh(torch.randn(B, 50, device=cuda)), torch.rand(B, A, device=cuda) * 2 - 1
+    out = []
+    for freeze in (False, True):
+        h, a = h0.clone().requires_grad_(True), a0.clone().requires_grad_(True)
+        for p in list(q1.parameters()) + list(q2.parameters()):
+            p.grad = None
+        o1, o2 = head_ops.twin_q(h, a, q1, q2, freeze=freeze)
+        (o1.sum() - 2 * o2.sum()).backward()
+        out.append((o1.detach(), o2.detach(), h.grad, a.grad))
+        assert all((p.grad is None) == freeze for p in list(q1.parameters()) + list(q2.parameters()))
+    for x, y in zip(*out):
+        assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("B,D,Hd,E", [(256, 50, 1024, 12), (37, 50, 96, 2), (512, 100, 1024, 6)])
+def test_mlp3_matches_sequential(cuda, B, D, Hd, E):
+    """Actor.mlp (src/algorithms/modules.py:200-215) as one autograd node (head_ops.mlp3: GEMM-epilogue ReLUs forward,
+    augcl_mask_colsum backward) against the nn.Sequential it replaces, both judged against float64."""
+    torch.manual_seed(B + E)
+    seq = torch.nn.Sequential(torch.nn.Linear(D, Hd), torch.nn.ReLU(), torch.nn.Linear(Hd, Hd), torch.nn.ReLU(),
+                              torch.nn.Linear(Hd, E)).to(cuda)
+    for p in seq.parameters():
+        p.data.add_(0.05 * torch.randn_like(p))
+    x0 = torch.tanh(torch.randn(B, D, device=cuda))
+    go = torch.randn(B, E, device=cuda)
+    res = []
+    for mode in ("f64", "aten", "fused"):
+        net = seq.double() if mode == "f64" else seq.float()
+        dt = torch.float64 if mode == "f64" else torch.float32
+        for p in net.parameters():
+            p.grad = None
+        x = x0.to(dt).clone().requires_grad_(True)
+        out = head_ops.mlp3(x, net) if mode == "fused" else net(x)
+        (out * go.to(dt)).sum().backward()
+        res.append([t.detach().double().clone() for t in [out, x.grad] + [p.grad for p in net.parameters()]])
+    for i, (truth, aten, fused) in enumerate(zip(*res)):
+        scale = max(1e-3, float(truth.abs().max()))
+        e_aten, e_fused = float((aten - truth).abs().max()), float((fused - truth).abs().max())
+        assert e_fused <= max(3.0 * e_aten, 3e-6 * scale), (i, e_fused, e_aten)
+    # no weight gradients wanted: only dx comes back, identical
+    x = x0.clone().requires_grad_(True)
+    frozen = head_ops._Mlp3.apply(x, *[p.detach() for p in seq.float().parameters()])
+    (gx,) = torch.autograd.grad((frozen * go).sum(), [x])
+    assert torch.equal(gx.double(), res[2][1])
+
+
+def test_mask_colsum_and_mlp_out_kernels(cuda):
+    """The C-ABI pieces on their own: ReLU gate + column sums (ragged sizes, with and without the extra matrix), and
+    the twin output layer forward / backward against the ATen expressions."""
+    g = torch.Generator(device=cuda).manual_seed(9)
+    for B, N, E in ((1, 1, 0), (33, 70, 3), (512, 2048, 12), (100, 31, 40)):
+        dz = torch.randn(B, N, device=cuda, generator=g)
+        a = torch.relu(torch.randn(B, N, device=cuda, generator=g))
+        ex = torch.randn(B, E, device=cuda, generator=g) if E else None
+        want = torch.where(a > 0, dz, torch.zeros_like(dz))
+        got = dz.clone()
+        db, dex = head_ops._mask_colsum(got, a, True, ex)
+        assert torch.equal(got, want)
+        assert float((db.double() - want.double().sum(0)).abs().max()) <= 1e-5 * max(1.0, B ** 0.5)
+        if E:
+            assert float((dex.double() - ex.double().sum(0)).abs().max()) <= 1e-5 * max(1.0, B ** 0.5)
+        got2 = dz.clone()
+        assert head_ops._mask_colsum(got2, a, False) == (None, None) and torch.equal(got2, want)
+    from augcl_amd import _lib
+    T, B, H = 2, 77, 200
+    z = torch.randn(T, B, H, device=cuda, generator=g)
+    b2, w3, b3 = torch.randn(T, H, device=cuda, generator=g), torch.randn(T, H, device=cuda, generator=g), torch.randn(T, 1, device=cuda, generator=g)
+    a2_want = torch.relu(z + b2[:, None])
+    q_want = (a2_want.double() * w3.double()[:, None]).sum(-1) + b3.double()
+    q = torch.empty(T, B, device=cuda)
+    zz = z.clone()
+    st = _lib.current_stream(cuda)
+    _lib.call("augcl_mlp_out_forward", zz.data_ptr(), b2.data_ptr(), H, w3.data_ptr(), H, b3.data_ptr(), 1, q.data_ptr(), T, B, H, st)
+    assert torch.equal(zz, a2_want) and float((q.double() - q_want).abs().max()) <= 1e-5 * float(q_want.abs().max())
+    g0, g1 = torch.randn(B, device=cuda, generator=g), torch.randn(B, device=cuda, generator=g)
+    gg = torch.stack([g0, g1]).double()
+    dz2 = torch.empty_like(z)
+    dw3, db3, db2 = torch.empty(T, H, device=cuda), torch.empty(T, device=cuda), torch.empty(T, H, device=cuda)
+    _lib.call("augcl_mlp_out_backward", g0.data_ptr(), g1.data_ptr(), zz.data_ptr(), w3.data_ptr(), H, dz2.data_ptr(),
+              dw3.data_ptr(), db3.data_ptr(), db2.data_ptr(), T, B, H, st)
+    want = torch.where(zz > 0, (gg[:, :, None] * w3.double()[:, None]).float(), torch.zeros_like(z))
+    assert torch.equal(dz2, want)
+    for got_, want_ in ((dw3, (gg[:, :, None] * zz.double()).sum(1)), (db3, gg.sum(1)), (db2, want.double().sum(1))):
+        assert float((got_.double() - want_).abs().max()) <= 1e-5 * max(1.0, float(want_.abs().max()))
+
+
 def test_actor_loss_and_alpha_step_match_aten(cuda):
     """sac.py:119-146: the actor loss as one launch each way, and the temperature update (loss, gradient, Adam on the
     float64 scalar) as ONE launch, against the literal ATen chain + torch.optim.Adam over several steps."""

@@ -255,22 +255,6 @@ def group_of(name):
     return name.split(".")[0]  # Q1 / Q2 / mlp
 
 
-class GateRecorder:
-    """Forward hooks on the nn.ReLU modules of the product's MLP heads: the on/off decision of every call, in order."""
-
-    def __init__(self):
-        self.calls, self.handles = {}, []
-
-    def watch(self, tag, seq):
-        for i, mod in enumerate(m for m in seq if isinstance(m, torch.nn.ReLU)):
-            self.handles.append(mod.register_forward_hook(
-                lambda _m, _inp, out, key=(tag, i): self.calls.setdefault(key, []).append((out > 0).cpu())))
-
-    def close(self):
-        for h in self.handles:
-            h.remove()
-
-
 @pytest.mark.parametrize("algo,data_aug,A,B,hpo,init", CASES)
 def test_update_against_f64_referee(cuda, monkeypatch, algo, data_aug, A, B, hpo, init):
     """One full update() (critic, actor + alpha, target EMA) at the configs' batch sizes, on real-init / He-scaled nets.
@@ -364,26 +348,12 @@ def test_update_against_f64_referee(cuda, monkeypatch, algo, data_aug, A, B, hpo
     seen_feat = []
     watched = [agent.critic.encoder.shared_cnn] + ([agent.critic_weak.encoder.shared_cnn] if algo == "augcl" else [])
     hooks = [mod.register_forward_hook(lambda _m, _i, out: seen_feat.append(out.detach())) for mod in watched]
-    rec = GateRecorder()
-    rec.watch("mlp", agent.actor.mlp)
-    # the twin Q trunks run as one batched network (head_ops.twin_q) whose two ReLUs are a torch._addmm_activation epilogue and an in-place torch.relu_:
-    # layer 1 on a (B, 2H) tensor [Q1 | Q2], layer 2 on (2, B, H); record every call's gates in order
-    twin_relu, real_relu_ = [], torch.relu_
-
-    def relu_rec(t):
-        out = real_relu_(t)
-        twin_relu.append((out > 0).cpu())
-        return out
-
-    monkeypatch.setattr(torch, "relu_", relu_rec)
-    real_addmm_act = torch._addmm_activation  # layer 1: bias + ReLU in the GEMM epilogue (head_ops._TwinQ.forward)
-
-    def addmm_act_rec(*a, **k):
-        out = real_addmm_act(*a, **k)
-        twin_relu.append((out > 0).cpu())
-        return out
-
-    monkeypatch.setattr(torch, "_addmm_activation", addmm_act_rec)
+    # The MLP heads' ReLUs run inside GEMM epilogues and HIP kernels (head_ops._TwinQ / _Mlp3): head_ops.gate_hook hands
+    # over the post-ReLU activations of every fused forward, in call order.  twin: a1 (B, 2H) = [Q1 | Q2], a2 (2, B, H).
+    from augcl_amd import head_ops
+    twin_calls, mlp_calls = [], []
+    monkeypatch.setattr(head_ops, "gate_hook", lambda kind, a1, a2: (twin_calls if kind == "twin" else mlp_calls).append(
+        ((a1 > 0).cpu(), (a2 > 0).cpu())))
 
     calls = {"shift": 0}
 
@@ -414,7 +384,6 @@ def test_update_against_f64_referee(cuda, monkeypatch, algo, data_aug, A, B, hpo
     L = RecLogger()
     agent.update(Buf(), L, 0)
     torch.cuda.synchronize()
-    rec.close()
     for h in hooks:
         h.remove()
     assert not queue
@@ -428,7 +397,7 @@ def test_update_against_f64_referee(cuda, monkeypatch, algo, data_aug, A, B, hpo
     # forced), then the critic passes (AugCL: weak first), last the actor step's critic call.
     Hd = hp["hidden_dim"]
     twin = []
-    for l1, l2 in zip(twin_relu[0::2], twin_relu[1::2]):
+    for l1, l2 in twin_calls:
         rows = l1.shape[0]
         twin.append(([l1.view(rows, 2, Hd)[:, t] for t in (0, 1)], [l2[t] for t in (0, 1)]))  # per trunk: layer-1, layer-2 gates
 
@@ -439,7 +408,7 @@ def test_update_against_f64_referee(cuda, monkeypatch, algo, data_aug, A, B, hpo
 
     n_pass = len(critic_inputs)
     first = M if algo == "drq" else 1               # index of the first gradient-carrying twin_q call
-    forced = {"critic": [], "actor": {"mlp": [rec.calls[("mlp", i)][-1] for i in (0, 1)]}, "actor_q": q_gates(-1)}
+    forced = {"critic": [], "actor": {"mlp": list(mlp_calls[-1])}, "actor_q": q_gates(-1)}
     if algo == "augcl":
         forced["weak"] = [dict(cnn=weak_cnn[0][0], **q_gates(first))]
         first += 1

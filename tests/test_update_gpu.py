@@ -186,6 +186,56 @@ def test_adam_and_ema_kernels_match_torch(cuda):
     assert torch.equal(tg.cpu()[1:], (0.01 * p0 + (1 - 0.01) * t0)[1:]) and tg.cpu()[0] == t0[0]
 
 
+def test_adam_device_side_step_and_two_segment_ema(cuda):
+    """The graph-capturable Adam (step count on the device, bias corrections derived inside the ONE launch, the count
+    stored by the last workgroup to retire) walks exactly like the host-step variant; augcl_ema2_f32 = two augcl_ema_f32."""
+    from augcl_amd import flat
+    rs = np.random.RandomState(3)
+    n = 300000
+    p0 = torch.from_numpy(rs.standard_normal(n).astype(np.float32))
+    grads = [torch.from_numpy((rs.standard_normal(n) * 10.0 ** rs.uniform(-5, 1, n)).astype(np.float32)).to(cuda) for _ in range(6)]
+    opts = []
+    for dev_step in (False, True):
+        par = torch.nn.Parameter(p0.clone().to(cuda))
+        fopt = flat.FlatAdam(flat.FlatGroup([("p", par)]), 3e-4, (0.9, 0.999))
+        if dev_step:
+            fopt.make_capturable()
+        opts.append((par, fopt))
+    for i, g in enumerate(grads):
+        for par, fopt in opts:
+            fopt.zero_grad()
+            par.grad = g.clone()
+            fopt.step()
+        assert opts[1][1].step_count == i + 1
+    assert torch.equal(opts[0][0].detach(), opts[1][0].detach())
+    assert torch.equal(opts[0][1].exp_avg_sq, opts[1][1].exp_avg_sq)
+    # the gather launch on its own: several tensors, sources at odd offsets (views), big and tiny, one launch
+    shapes = [(7, 5), (33,), (1024, 56), (3,)]
+    pars = [torch.nn.Parameter(torch.zeros(sh, device=cuda)) for sh in shapes]
+    grp = flat.FlatGroup([(f"p{i}", p) for i, p in enumerate(pars)])
+    big = torch.randn(70000, device=cuda)
+    srcs = [big[o:o + int(np.prod(sh))].view(sh) for o, sh in zip((1, 40, 101, 4), shapes)]
+    assert grp.scatter_into_bucket(srcs) == [] and not grp.prepped
+    for name, src in zip(grp.names, srcs):
+        a, b = grp.slices[name]
+        assert torch.equal(grp.grad[a:b], src.reshape(-1)), name
+    assert grp.scatter_into_bucket([srcs[0], None, srcs[2].t().contiguous().t(), srcs[3]]) == ["p1"]  # a strided gradient
+    a, b = grp.slices["p2"]
+    assert torch.equal(grp.grad[a:b], srcs[2].reshape(-1)) and float(grp.grad[slice(*grp.slices["p1"])].abs().max()) == 0.0
+    # a state that starts at a later step (checkpoint resume)
+    opts[1][1].step_count = 41
+    assert opts[1][1].step_count == 41
+    t0 = torch.from_numpy(rs.standard_normal(n).astype(np.float32)).to(cuda)
+    src = p0.to(cuda)
+    one, two = t0.clone(), t0.clone()
+    flat.ema_(one, src, 5, 1000, 0.05)
+    flat.ema_(one, src, 1000, n - 3, 0.01)
+    flat.ema2_(two, src, (5, 1000, 0.05), (1000, n - 3, 0.01))
+    assert torch.equal(one, two) and not torch.equal(one, t0)
+    flat.ema2_(two, src, (0, 0, 0.5), (7, 7, 0.5))  # two empty segments: nothing happens
+    assert torch.equal(one, two)
+
+
 def test_flat_adam_skips_missing_gradients_like_torch(cuda):
     """torch.optim.Adam leaves a parameter without gradient untouched (no moment decay, no step, its own step count);
     FlatAdam steps the runs of tensors that do have one and keeps per-tensor counts from then on."""
