@@ -21,6 +21,7 @@ typedef uint32_t vu2 __attribute__((ext_vector_type(2)));
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ int acc_row_f(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
@@ -47,6 +48,7 @@ struct First9Args {
 constexpr int F9_U = 12;  // 16-byte chunks per loader lane per strip
 constexpr int F9_NP = 41; // k pairs (K = 81 padded to 82)
 constexpr int F9_AHEAD = 8;
+constexpr int F9B_NM = 6; // bf16 mode: MFMAs (K = 16 each) per 32-pixel tile
 
 template <int WI, bool OUT_BF16, bool RELU>
 __global__ __launch_bounds__(512, 2) void k_conv_first9(First9Args a)
@@ -171,6 +173,22 @@ __global__ __launch_bounds__(512, 2) void k_conv_first9(First9Args a)
     f32x16 bias16;
 #pragma unroll
     for (int r = 0; r < 16; ++r) bias16[r] = lbias[acc_row_f(r, h)];
+    // bf16 mode: the products run on v_mfma_f32_32x32x16_bf16 -- K = 81 padded to 96 = 6 MFMAs instead of 41.  A fragment
+    // of MFMA i: W[co = l31][k = 16 i + 8 h + j], j = 0..7, rounded to bf16 (RNE); k >= 81 carries a zero weight.
+    bf16x8 wfrag[F9B_NM];
+    if (OUT_BF16) {
+        const float *wst = ldsf + bufwords + l31 * 85;
+#pragma unroll
+        for (int i = 0; i < F9B_NM; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int ka = 16 * i + j, kb = ka + 8;
+                const int ia = ka < 81 ? ((ka / 3) % 9) * 9 + ((ka / 3) / 9) * 3 + ka % 3 : 0;
+                const int ib = kb < 81 ? ((kb / 3) % 9) * 9 + ((kb / 3) / 9) * 3 + kb % 3 : 0;
+                const float wa = ka < 81 ? wst[ia] : 0.0f, wb = kb < 81 ? wst[ib] : 0.0f;
+                wfrag[i][j] = (__bf16)(h ? wb : wa);
+            }
+    }
 
     auto compute = [&](int item, int bi) {
         const int b = item / a.S, s = item - b * a.S;
@@ -180,6 +198,85 @@ __global__ __launch_bounds__(512, 2) void k_conv_first9(First9Args a)
         const char *tile = reinterpret_cast<const char *>(ldsf + bi * bufwords);
         const int ntiles = (npix + 31) >> 5;
         if (cw >= ntiles) return; // wave-uniform
+        if constexpr (OUT_BF16) {
+            // B operand of MFMA i: this lane's pixel, taps k = 16 i + 8 h + j.  off(k) = (k/3) WI + k%3 floats past the pixel
+            // base; off(k + 8) - off(k) takes two values (k%3 == 0: 2 WI + 2, else 3 WI - 1), so two lane bases shifted by
+            // h times those make every read "base + compile-time immediate".  Pads (k > 80) re-use tap 80's value.
+            constexpr int D0 = (2 * WI + 2) * 4, D1 = (3 * WI - 1) * 4;
+            auto locb = [&](int tl, bool &valid_, int &yy_, int &xx_, int &ba_, int &bb_) {
+                int m_ = tl * 32 + l31;
+                valid_ = m_ < npix;
+                if (!valid_) m_ = npix - 1;
+                yy_ = (int)__umulhi((uint32_t)m_, a.magic_wo);
+                xx_ = m_ - yy_ * a.Wo;
+                const int base = (2 * yy_ * ROWF + 2 * xx_) * 4;
+                ba_ = base + h * D0;
+                bb_ = base + h * D1;
+            };
+            auto rdb = [&](int ba_, int bb_, int i, int j) {
+                const int k = 16 * i + j; // the h = 0 lanes' tap; h = 1 lanes read k + 8 through their shifted base
+                if (k + 8 > 80) { // i = 5: only k = 80 is real (h = 0, j = 0); every other slot meets a zero weight
+                    const int off80 = ((80 / 3) * WI + 80 % 3) * 4;
+                    return *reinterpret_cast<const float *>(tile + (ba_ - h * D0) + off80);
+                }
+                const int off = ((k / 3) * WI + k % 3) * 4;
+                return *reinterpret_cast<const float *>(tile + ((k % 3 == 0) ? ba_ : bb_) + off);
+            };
+            int yy, xx, ba, bb;
+            bool valid;
+            locb(cw, valid, yy, xx, ba, bb);
+            float raw[F9B_NM][8];
+#pragma unroll
+            for (int i = 0; i < F9B_NM - 1; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) raw[i][j] = rdb(ba, bb, i, j);
+            raw[F9B_NM - 1][0] = rdb(ba, bb, F9B_NM - 1, 0);
+            for (int tl = cw; tl < ntiles; tl += 4) {
+                int yy2, xx2, ba2, bb2;
+                bool valid2;
+                locb(tl + 4 < ntiles ? tl + 4 : tl, valid2, yy2, xx2, ba2, bb2);
+                f32x16 acc;
+#pragma unroll
+                for (int i = 0; i < F9B_NM; ++i) {
+                    bf16x8 bop;
+#pragma unroll
+                    for (int j = 0; j < 8; j += 2) {
+                        const float v0 = raw[i][i == F9B_NM - 1 ? 0 : j], v1 = raw[i][i == F9B_NM - 1 ? 0 : j + 1];
+                        const bf16x2 two = __builtin_convertvector(f32x2{v0, v1}, bf16x2);
+                        bop[j] = two[0];
+                        bop[j + 1] = two[1];
+                    }
+                    // the next tile's operands of this group are issued as soon as its registers are free
+                    if (i < F9B_NM - 1) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) raw[i][j] = rdb(ba2, bb2, i, j);
+                    } else {
+                        raw[i][0] = rdb(ba2, bb2, i, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfrag[i], bop, i == 0 ? bias16 : acc, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (valid) {
+                    vu2 *o = reinterpret_cast<vu2 *>(a.out) + ((size_t)(b * a.Ho + y0 + yy) * a.Wo + xx) * 8 + h;
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        vu2 pk;
+#pragma unroll
+                        for (int d = 0; d < 2; ++d) {
+                            const bf16x2 two = __builtin_convertvector(f32x2{acc[g4 * 4 + 2 * d], acc[g4 * 4 + 2 * d + 1]}, bf16x2);
+                            uint32_t bits = __builtin_bit_cast(uint32_t, two);
+                            if (RELU)
+                                bits = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, bits), s16x2{0, 0}));
+                            pk[d] = bits;
+                        }
+                        o[2 * g4] = pk;
+                    }
+                }
+                valid = valid2; yy = yy2; xx = xx2; ba = ba2; bb = bb2;
+            }
+            return;
+        }
         auto locate = [&](int tl, int &m_, bool &valid_, int &yy_, int &xx_, int &b1_, int &bw_) {
             m_ = tl * 32 + l31;
             valid_ = m_ < npix;
