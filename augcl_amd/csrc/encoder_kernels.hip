@@ -737,6 +737,202 @@ __global__ __launch_bounds__(256, (NT <= 3 ? 4 : NT <= 6 ? 2 : 1)) void k_wgrad_
     }
 }
 
+// k_wgrad_first_pipe: the same sums for the shapes the training loop uses (Wi a multiple of 4, a strip of at most 128
+// output pixels and 1024 16-byte chunks of x), with the staging restructured around ONE exposed memory latency per
+// workgroup instead of ~5 per strip: every thread fetches its share of the NEXT strip (x: <= 4 dwordx4; dZ: 16 dwords or
+// 2 dwordx4 of bf16) into registers before the MFMAs of the current strip, and writes them to LDS after.  (The loop
+// above copies channel pair after channel pair, each waiting for its own loads: 137 us at B = 512 with the MFMA pipe
+// busy 25 % of the time.)
+constexpr int WG1_XU = 4;   // x chunks (16 B) per thread per strip
+constexpr int WG1_ZP = 128; // dZ pixel slots per channel in the f32 fetch pattern (>= pixels per strip)
+
+// Workgroups per CU: 4 with bf16 dZ; 3 with f32 dZ, whose 16 prefetch registers more do not fit a 128-VGPR budget.
+template <int NT, bool BF16DZ>
+__global__ __launch_bounds__(256, (BF16DZ ? 4 : 3)) void k_wgrad_first_pipe(Wgrad1Args a, uint32_t magic_full, uint32_t magic_last,
+                                                                              uint32_t magic_wo)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // scalar: loop control on the SALU
+    const int l31 = lane & 31, h = lane >> 5;
+    const int st = a.stride;
+    const int rows_in_max = st * (a.RT - 1) + 3;
+    const int planeX = rows_in_max * a.Wi; // a multiple of 4: 16-byte LDS stores
+    const int planeZ = (a.RT * a.Wo) | 1;
+    float *ldsX = lds;
+    float *ldsZ = lds + a.C * planeX;
+    const int K = a.C * 9;
+    const int W4 = a.Wi >> 2;
+    // LDS offset of column n = l31 + 32 j: (c, ky, kx).  Columns n >= K are never stored: they read a valid address (0) and
+    // accumulate garbage of their own (an MFMA output column depends on its own B column only) -- no masking in the loop.
+    int noff[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = l31 + 32 * j;
+        const int nn = n < K ? n : 0;
+        const int c = nn / 9, t = nn - c * 9;
+        noff[j] = c * planeX + (t / 3) * a.Wi + (t % 3);
+    }
+    f32x16 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+    float dbacc = 0.0f;
+
+    typedef float vf4 __attribute__((ext_vector_type(4)));
+    typedef uint32_t vu4 __attribute__((ext_vector_type(4)));
+    struct Regs {
+        vf4 x[WG1_XU];
+        float z[BF16DZ ? 1 : 16];
+        vu4 zb[BF16DZ ? 2 : 1];
+    };
+    struct Geo {
+        int b, y0, rows, npix, run4, nchunk;
+        uint32_t magic;
+    };
+    auto geom = [&](int item) {
+        Geo g;
+        g.b = item / a.S;
+        const int s = item - g.b * a.S;
+        g.y0 = s * a.RT;
+        g.rows = min(a.RT, a.Ho - g.y0);
+        g.npix = g.rows * a.Wo;
+        g.run4 = (st * (g.rows - 1) + 3) * W4; // chunks per channel run
+        g.nchunk = a.C * g.run4;
+        g.magic = g.rows == a.RT ? magic_full : magic_last;
+        return g;
+    };
+    auto issue = [&](int item, Regs &R) {
+        const Geo g = geom(item);
+        const float *src = a.x + ((size_t)g.b * a.C * a.Hi + (size_t)st * g.y0) * a.Wi;
+#pragma unroll
+        for (int u = 0; u < WG1_XU; ++u) {
+            const int q = min(u * 256 + tid, g.nchunk - 1); // idempotent tail
+            const int c = (int)__umulhi((uint32_t)q, g.magic);
+            R.x[u] = *reinterpret_cast<const vf4 *>(src + (size_t)c * a.Hi * a.Wi + (q - c * g.run4) * 4);
+        }
+        if (BF16DZ) { // dZ bf16 NHWC: one 16-byte chunk = 8 channels of one pixel; chunk id = pixel * 4 + channel group
+            const vu4 *gz = reinterpret_cast<const vu4 *>(a.dz) + ((size_t)(g.b * a.Ho + g.y0) * a.Wo) * 4;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) R.zb[u] = gz[min(u * 256 + tid, g.npix * 4 - 1)];
+        } else { // dZ f32 NCHW: slot e = channel * 128 + pixel
+            const float *sz = a.dz + ((size_t)g.b * 32 * a.Ho + g.y0) * a.Wo;
+            const size_t csZ = (size_t)a.Ho * a.Wo;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int e = u * 256 + tid, c = e >> 7, p = min(e & (WG1_ZP - 1), g.npix - 1);
+                R.z[u] = sz[c * csZ + p];
+            }
+        }
+    };
+    auto commit = [&](int item, const Regs &R) {
+        const Geo g = geom(item);
+        const XfScale xf{a.scale};
+#pragma unroll
+        for (int u = 0; u < WG1_XU; ++u) {
+            const int q = min(u * 256 + tid, g.nchunk - 1);
+            const int c = (int)__umulhi((uint32_t)q, g.magic);
+            vf4 v = R.x[u];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = xf(v[e]);
+            *reinterpret_cast<vf4 *>(ldsX + c * planeX + (q - c * g.run4) * 4) = v;
+        }
+        if (BF16DZ) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int q = min(u * 256 + tid, g.npix * 4 - 1);
+                const int p = q >> 2, c0 = (q & 3) * 8;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    ldsZ[(c0 + 2 * e) * planeZ + p] = bf16lo(R.zb[u][e]);
+                    ldsZ[(c0 + 2 * e + 1) * planeZ + p] = bf16hi(R.zb[u][e]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int e = u * 256 + tid, c = e >> 7, p = e & (WG1_ZP - 1);
+                if (p < g.npix) ldsZ[c * planeZ + p] = R.z[u];
+            }
+        }
+    };
+
+    Regs R;
+    if ((int)blockIdx.x < a.n_items) issue(blockIdx.x, R);
+    for (int item = blockIdx.x; item < a.n_items; item += gridDim.x) {
+        __syncthreads(); // the previous strip's readers are done
+        commit(item, R);
+        __syncthreads();
+        if (item + (int)gridDim.x < a.n_items) issue(item + gridDim.x, R); // in flight under the MFMAs below
+        const Geo g = geom(item);
+        const int npair = (g.npix + 1) >> 1;
+        // operands of pixel pair pr: z = dZ[co = l31][p], x[j] = X tap n = l31 + 32 j of pixel p = 2 pr + h
+        auto ld = [&](int pr, float &z, float (&xv)[NT]) {
+            int p = 2 * pr + h;
+            const bool valid = p < g.npix;
+            if (!valid) p = g.npix - 1;
+            const int yy = (int)__umulhi((uint32_t)p, magic_wo), xx = p - yy * a.Wo;
+            z = ldsZ[l31 * planeZ + p];
+            if (!valid) z = 0.0f;
+            const float *px = ldsX + st * (yy * a.Wi + xx);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) xv[j] = px[noff[j]];
+        };
+        // two pairs in flight per wave: the LDS reads of the next pair are issued before the MFMAs of this one
+        float z0, z1, x0[NT], x1[NT];
+        if (wave < npair) ld(wave, z0, x0);
+        for (int pr = wave; pr < npair; pr += 8) {
+            if (pr + 4 < npair) ld(pr + 4, z1, x1);
+            __builtin_amdgcn_sched_barrier(0);
+            dbacc += z0;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(z0, x0[j], acc[j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (pr + 8 < npair) ld(pr + 8, z0, x0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (pr + 4 < npair) {
+                dbacc += z1;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(z1, x1[j], acc[j], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    __syncthreads();
+    const int slab_sz = 32 * K + 32;
+    float *slab = a.partial + (size_t)blockIdx.x * slab_sz;
+    for (int w = 1; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) lds[(j * 16 + r) * 64 + lane] = acc[j][r];
+            lds[NT * 16 * 64 + lane] = dbacc;
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][r] += lds[(j * 16 + r) * 64 + lane];
+            dbacc += lds[NT * 16 * 64 + lane];
+        }
+        __syncthreads();
+    }
+    if (wave == 0) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = l31 + 32 * j;
+            if (n < K)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) slab[(size_t)acc_row(r, h) * K + n] = acc[j][r];
+        }
+        const float other = __shfl_xor(dbacc, 32, 64);
+        if (h == 0) slab[32 * K + l31] = dbacc + other;
+    }
+}
+
 // the per-workgroup slabs are summed in a FIXED order by encoder_reduce.hip (reduce_slabs)
 constexpr int RG = 8; // rows of its level-1 scratch
 
@@ -1031,6 +1227,38 @@ static int wgrad_first_impl(const float *x, const float *dz, float *dw, float *d
     const int slab = 32 * K + 32;
     AUGCL_REQUIRE(workspace_bytes >= (size_t)(grid + RG) * slab * 4, "%s: workspace too small", name);
     hipStream_t s = as_stream(stream);
+    // pipelined staging (k_wgrad_first_pipe) for the shapes it covers; the generic kernel otherwise
+    const int run4_full = (stride * (a.RT - 1) + 3) * (Wi / 4);
+    const int rows_last = a.Ho - (a.S - 1) * a.RT;
+    const int run4_last = (stride * (rows_last - 1) + 3) * (Wi / 4);
+    const bool pipe = Wi % 4 == 0 && aligned16(x) && a.RT * a.Wo <= WG1_ZP && C * run4_full <= 256 * WG1_XU &&
+                      (!bf16dz || a.RT * a.Wo * 4 <= 512) && NT <= 3;
+    if (pipe) {
+        const int grid = grid_for(a.n_items, bf16dz ? 4 : 3); // = the kernel's launch bounds: every workgroup resident
+        const uint32_t mf = (uint32_t)(0x100000000ull / (unsigned)run4_full) + 1u;
+        const uint32_t ml = (uint32_t)(0x100000000ull / (unsigned)run4_last) + 1u;
+        const uint32_t mwo = (uint32_t)(0x100000000ull / (unsigned)a.Wo) + 1u;
+#define LAUNCH_WG1P(NTV)                                                                                  \
+    do {                                                                                                  \
+        if (bf16dz) {                                                                                     \
+            if (int rc = set_lds(k_wgrad_first_pipe<NTV, true>, lds, name)) return rc;                    \
+            hipLaunchKernelGGL((k_wgrad_first_pipe<NTV, true>), dim3(grid), dim3(256), lds, s, a, mf, ml, mwo);  \
+        } else {                                                                                          \
+            if (int rc = set_lds(k_wgrad_first_pipe<NTV, false>, lds, name)) return rc;                   \
+            hipLaunchKernelGGL((k_wgrad_first_pipe<NTV, false>), dim3(grid), dim3(256), lds, s, a, mf, ml, mwo); \
+        }                                                                                                 \
+    } while (0)
+        switch (NT) {
+        case 1: LAUNCH_WG1P(1); break;
+        case 2: LAUNCH_WG1P(2); break;
+        default: LAUNCH_WG1P(3); break;
+        }
+#undef LAUNCH_WG1P
+        float *part2p = workspace + (size_t)grid * slab;
+        if (int rc = augcl::check_launch(name)) return rc;
+        if (int rc = augcl::reduce_slabs(ReduceDesc{workspace, part2p, dw, db, grid, slab, 32 * K}, s, name)) return rc;
+        return augcl::check_launch(name);
+    }
 #define LAUNCH_WG1(NTV)                                                                      \
     do {                                                                                     \
         if (bf16dz) {                                                                        \
