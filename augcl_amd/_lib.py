@@ -94,6 +94,7 @@ _SIGS = {
     "augcl_mlp_out_forward": [_P, _P, _I64, _P, _I64, _P, _I64, _P, _I, _I, _I, _P],
     "augcl_mlp_out_backward": [_P, _P, _P, _P, _I64, _P, _P, _P, _P, _I, _I, _I, _P],
     "augcl_mask_colsum": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "augcl_proj_dx_f32": [_P, _P, _P, _I, _I, _I, _P],
     "augcl_enc_bf16_conv_first_forward": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
     "augcl_enc_bf16_conv32_forward": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "augcl_enc_bf16_conv32_backward_data": [_P, _P, _P, _P, _I, _I, _I, _P],

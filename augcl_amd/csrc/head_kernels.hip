@@ -572,6 +572,87 @@ __global__ __launch_bounds__(1024) void k_mask_colsum(float *__restrict__ dz, co
     }
 }
 
+// ---- RLProjection backward, input side: dx (M,K) = dy (M,N) w (N,K) with K = 14112, N = 100 -- a GEMM with a tiny inner
+// dimension whose 29-58 MB output is the cost.  hipBLASLt runs it at 0.7 TB/s (42 us at M = 512, a 64x64x16 macro tile);
+// here a wave keeps the weights of its 32 output columns, w[n][k0 .. k0+31], in registers (NP = N/2 MFMA B operands, n on
+// the MFMA's k index), the workgroup's four waves share each 32-row dy tile through LDS ([n][m], one conflict-free
+// ds_read_b32 per MFMA), and every accumulator row leaves as 128 contiguous bytes.
+template <int NP> // MFMA k-pairs: N <= 2 NP
+__global__ __launch_bounds__(256, 2) void k_proj_dx(const float *__restrict__ dy, const float *__restrict__ w,
+                                                    float *__restrict__ dx, int M, int N, int K, int mb_per_wg)
+{
+    __shared__ float at[2][2 * NP][33]; // two dy tiles, [n][m]
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int k0 = blockIdx.x * 128 + 32 * wv;
+    const bool wave_live = k0 < K; // the last column block may own fewer than four 32-column groups
+    const int kc = min(k0 + l31, K - 1);
+    // this lane's weights: w[n = 2 j + h][kc]
+    float wreg[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const int n = 2 * j + h;
+        wreg[j] = (wave_live && n < N) ? w[(size_t)n * K + kc] : 0.0f;
+    }
+    // dy tile fetch: 32 rows x N floats as 16-byte chunks, N/4 per row; thread -> chunks tid, tid + 256, ...
+    const int n4 = N >> 2, nchunk = 32 * n4;
+    constexpr int AU = (32 * 2 * NP / 4 + 255) / 256;
+    typedef float vf4 __attribute__((ext_vector_type(4)));
+    vf4 areg[AU];
+    const int mb0 = blockIdx.y * mb_per_wg, mb1 = min(mb0 + mb_per_wg, (M + 31) >> 5);
+    auto issue = [&](int mb) {
+#pragma unroll
+        for (int u = 0; u < AU; ++u) {
+            const int q = min(u * 256 + tid, nchunk - 1);
+            const int r = q / n4, c4 = q - r * n4;
+            areg[u] = *reinterpret_cast<const vf4 *>(dy + (size_t)min(mb * 32 + r, M - 1) * N + 4 * c4);
+        }
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < AU; ++u) {
+            const int q = min(u * 256 + tid, nchunk - 1);
+            const int r = q / n4, c4 = q - r * n4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) at[buf][4 * c4 + e][r] = areg[u][e];
+        }
+    };
+    if (2 * NP > N) { // rows n >= N of both tiles meet zero weights; keep them finite
+        for (int i = tid; i < 2 * (2 * NP - N) * 33; i += 256) {
+            const int b = i / ((2 * NP - N) * 33), rem = i - b * (2 * NP - N) * 33;
+            at[b][N + rem / 33][rem % 33] = 0.0f;
+        }
+    }
+    if (mb0 < mb1) issue(mb0);
+    int buf = 0;
+    for (int mb = mb0; mb < mb1; ++mb, buf ^= 1) {
+        commit(buf);
+        __syncthreads(); // tile `buf` complete.  Its previous readers (two iterations back) all passed the barrier in between.
+        if (mb + 1 < mb1) issue(mb + 1);
+        if (wave_live) {
+            f32x16h acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            // all NP A operands are requested before the first MFMA (they return in order; an MFMA of 64 cycles is shorter
+            // than one LDS round trip, so a one-deep prefetch left the pipe waiting half the time)
+            float av[NP];
+#pragma unroll
+            for (int j = 0; j < NP; ++j) av[j] = at[buf][2 * j + h][l31];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < NP; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], wreg[j], acc, 0, 0, 0);
+            // acc[r]: row m = mb*32 + (r&3) + 8 (r>>2) + 4 h, column k0 + l31
+            if (k0 + l31 < K) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (m < M) dx[(size_t)m * K + k0 + l31] = acc[r];
+                }
+            }
+        }
+    }
+}
+
 } // namespace augcl
 
 using namespace augcl;
@@ -774,6 +855,25 @@ int augcl_mask_colsum(float *dz, const float *a, float *db, const float *extra, 
     const int nb = (N + 31) / 32;
     hipLaunchKernelGGL(k_mask_colsum, dim3(nb + (E + 31) / 32), dim3(1024), 0, as_stream(stream), dz, a, db, extra, dextra, B,
                        N, E, nb);
+    return augcl::check_launch(name);
+}
+
+int augcl_proj_dx_f32(const float *dy, const float *w, float *dx, int M, int N, int K, augcl_stream_t stream)
+{
+    const char *name = "augcl_proj_dx_f32";
+    AUGCL_REQUIRE(M >= 1 && N >= 4 && N <= 128 && (N & 3) == 0 && K >= 1, "%s: shape not covered (N a multiple of 4, <= 128)", name);
+    AUGCL_REQUIRE(dy && w && dx, "%s: null tensor", name);
+    AUGCL_REQUIRE(aligned16(dy), "%s: dy must be 16-byte aligned", name);
+    const int mblocks = (M + 31) / 32;
+    // row tiles per workgroup (the weights' registers are loaded once per workgroup): ~444 workgroups at M = 256 and 512,
+    // all resident at two per CU
+    const int per = mblocks >= 16 ? 4 : mblocks >= 8 ? 2 : 1;
+    const dim3 grid((K + 127) / 128, (mblocks + per - 1) / per);
+    hipStream_t s = as_stream(stream);
+    if (N <= 100)
+        hipLaunchKernelGGL(k_proj_dx<50>, grid, dim3(256), 0, s, dy, w, dx, M, N, K, per);
+    else
+        hipLaunchKernelGGL(k_proj_dx<64>, grid, dim3(256), 0, s, dy, w, dx, M, N, K, per);
     return augcl::check_launch(name);
 }
 

@@ -97,7 +97,8 @@ class _LnTanh(torch.autograd.Function):
 class _ProjLnTanh(torch.autograd.Function):
     """RLProjection (src/algorithms/modules.py:101-111) as one node: forward = split-K f32-MFMA GEMM + (slab reduction,
     bias, LayerNorm, tanh) in two launches (augcl_proj_ln_tanh_forward); backward = the fused LN/tanh backward, whose
-    column-sum launch also yields the Linear's bias gradient, and two library GEMMs (dW, and dx when it is wanted)."""
+    column-sum launch also yields the Linear's bias gradient, a library GEMM for dW and, when dx is wanted,
+    augcl_proj_dx_f32 (the output-bound GEMM with the 100-wide inner dimension)."""
 
     @staticmethod
     def forward(ctx, x, w, b, gamma, beta, eps, slabs):
@@ -125,7 +126,14 @@ class _ProjLnTanh(torch.autograd.Function):
                   small[0].data_ptr(), small[1].data_ptr(), small[2].data_ptr(), ws.data_ptr(), M, N, ctx.eps,
                   _lib.current_stream(x.device))
         dw = dy.t().mm(x) if ctx.needs_input_grad[1] else None
-        dx = dy.mm(w) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if N % 4 == 0 and N <= 128 and w.is_contiguous():  # the skinny-inner-dimension GEMM as its own MFMA kernel
+                dx = torch.empty_like(x)
+                _lib.call("augcl_proj_dx_f32", dy.data_ptr(), w.data_ptr(), dx.data_ptr(), M, N, x.shape[1],
+                          _lib.current_stream(x.device))
+            else:
+                dx = dy.mm(w)
         return dx, dw, small[2], small[0], small[1], None, None
 
 

@@ -250,6 +250,9 @@ int augcl_proj_ln_tanh_workspace_slabs(int M, int K, int N);
 int augcl_proj_ln_tanh_forward(const float *x, const float *w, const float *bias, const float *gamma, const float *beta,
                                float *y, float *z, float *workspace, size_t workspace_bytes, int M, int K, int N, double eps,
                                augcl_stream_t stream);
+/* RLProjection backward, input side: dx (M,K) = dy (M,N) w (N,K), the gradient that enters the conv stack (what autograd's
+ * Linear backward computes for src/algorithms/modules.py:104); N a multiple of 4, <= 128; dy 16-byte aligned. */
+int augcl_proj_dx_f32(const float *dy, const float *w, float *dx, int M, int N, int K, augcl_stream_t stream);
 
 /* ---- target-network update: utils.soft_update_params (src/utils.py:76-78), called from
  * SAC.soft_update_critic_target (src/algorithms/sac.py:148-153):

@@ -48,6 +48,7 @@ def test_bad_arguments_are_reported_not_crashed():
     assert lib.augcl_mlp_out_backward(None, None, None, None, 0, None, None, None, None, 3, 8, 1024, None) == -1
     assert b"T = 1 or 2" in lib.augcl_last_error()
     assert lib.augcl_mask_colsum(None, None, None, None, None, 8, 16, 0, None) == -1
+    assert lib.augcl_proj_dx_f32(None, None, None, 8, 102, 14112, None) == -1 and b"not covered" in lib.augcl_last_error()
     assert lib.augcl_ema2_f32(None, None, 0, 0.5, None, None, 0, 0.5, None) == 0
     assert lib.augcl_ema2_f32(None, None, 4, 0.5, None, None, 0, 0.5, None) == -1
     assert lib.augcl_adam_f32_devstep(None, None, None, None, 0, 1e-3, 0.9, 0.999, 1e-8, None, 1, 1.0, None) == -1  # no step state

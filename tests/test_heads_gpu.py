@@ -331,3 +331,17 @@ def test_projection_fused_gemm_ln_tanh(cuda, M):
         assert e_fused <= max(3.0 * e_aten, 3e-6 * scale), (i, e_fused, e_aten, scale)
     with torch.no_grad():
         assert torch.equal(proj(x0), proj(x0))  # fixed-order split-K: the same bits every time
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 4, 1), (37, 52, 300), (256, 100, 14112), (100, 128, 1000), (65, 100, 129)])
+def test_proj_dx_kernel(cuda, M, N, K):
+    """augcl_proj_dx_f32: dx = dy w for ragged row / column counts (partial 32-row tiles, partial 128-column blocks,
+    inner dimensions below the register tile), against the float64 product."""
+    from augcl_amd import _lib
+    g = torch.Generator(device=cuda).manual_seed(M + K)
+    dy, w = torch.randn(M, N, device=cuda, generator=g), torch.randn(N, K, device=cuda, generator=g)
+    dx = torch.full((M, K), float("nan"), device=cuda)
+    _lib.call("augcl_proj_dx_f32", dy.data_ptr(), w.data_ptr(), dx.data_ptr(), M, N, K, _lib.current_stream(cuda))
+    want = dy.double() @ w.double()
+    assert float((dx.double() - want).abs().max()) <= 2e-6 * N ** 0.5 * max(1.0, float(want.abs().max()))
+
