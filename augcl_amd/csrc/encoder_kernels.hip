@@ -423,12 +423,19 @@ __device__ __forceinline__ float bf16hi(uint32_t d) { return __uint_as_float(d &
 
 // BF16IN: activations / dZ are bf16 NHWC (perf mode): wave w loads 16-byte chunk w (channels 8w..8w+7) of every
 // pixel of the runs -- fully coalesced -- and scatters the 8 values (widened to f32) into its 8 channel planes.
-template <int ABL = 0, bool BF16IN = false>
-__global__ __launch_bounds__(256, 1) void k_wgrad32(WgradArgs a)
+// SPLIT (f32 product path): 512 threads = the 4 accumulating waves + 4 LOADER waves that copy the next strip straight into
+// the other LDS buffer with dwordx4 loads while the MFMAs run -- without the 96 prefetch registers the accumulating waves
+// fit the 256-register budget of two waves per SIMD, and they no longer spend ~400 load / store instructions per strip
+// next to their MFMAs (ablation: staging cost 14 % of the launch).  One barrier per strip, as in k_conv32.
+template <int ABL = 0, bool BF16IN = false, bool SPLIT = false>
+__global__ __launch_bounds__(SPLIT ? 512 : 256, 1) void k_wgrad32(WgradArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // scalar: loop bounds stay on the SALU
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6); // scalar: loop bounds stay on the SALU
+    const bool loader = SPLIT && wave_all >= 4;
+    const int wave = SPLIT ? (loader ? 8 : wave_all) : wave_all; // accumulating-wave index 0..3 (loaders match none)
+    const int lw = wave_all & 3;                                   // loader index
     const int l31 = lane & 31, h = lane >> 5;
     const int planeA = ((a.RT + 2) * a.Wi) | 1;
     const int planeZ = (a.RT * a.Wo) | 1;
@@ -513,19 +520,48 @@ __global__ __launch_bounds__(256, 1) void k_wgrad32(WgradArgs a)
         }
     };
 
+    // SPLIT: loader wave lw copies channels 8 lw .. 8 lw + 7 of both tiles, channel pairs back to back
+    auto stage = [&](int item, int bi) {
+        const int b = item / a.S, s = item - b * a.S;
+        const int y0 = s * a.RT;
+        const int rows = min(a.RT, a.Ho - y0);
+        const int runA = (rows + 2) * a.Wi, runZ = rows * a.Wo;
+        const float *src = a.act + ((size_t)b * 32 * a.Hi + y0) * a.Wi;
+        const float *sz = a.dz + ((size_t)b * 32 * a.Ho + y0) * a.Wo;
+        const size_t csA = (size_t)a.Hi * a.Wi, csZ = (size_t)a.Ho * a.Wo;
+        float *ldsA = lds + bi * bufw, *ldsZ = ldsA + 32 * planeA;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = 8 * lw + 2 * k;
+            wave_copy_runs2<2, false>(src + c * csA, src + (c + 1) * csA, ldsA + c * planeA, ldsA + (c + 1) * planeA, runA, lane,
+                                      XfId());
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = 8 * lw + 2 * k;
+            wave_copy_runs2<1, false>(sz + c * csZ, sz + (c + 1) * csZ, ldsZ + c * planeZ, ldsZ + (c + 1) * planeZ, runZ, lane,
+                                      XfId());
+        }
+    };
+
     WgPrefetch pf;
     int it = 0;
     const int first = xcd_slot((int)blockIdx.x, (int)gridDim.x); // neighbouring strips on one XCD (halo rows hit in L2)
     if (first < a.n_items) {
-        issue(first, pf);
-        commit(first, 0, pf);
+        if (SPLIT) {
+            if (loader) stage(first, 0);
+        } else {
+            issue(first, pf);
+            commit(first, 0, pf);
+        }
     }
     __syncthreads();
     for (int item = first; item < a.n_items; item += gridDim.x, ++it) {
         const int next = item + gridDim.x;
-        if (next < a.n_items && ABL != 1) issue(next, pf);
+        if (!SPLIT && next < a.n_items && ABL != 1) issue(next, pf);
+        if (SPLIT && loader && next < a.n_items && ABL != 1) stage(next, (it + 1) & 1);
         __builtin_amdgcn_sched_barrier(0);
-        {
+        if (!loader) {
             const int s = item % a.S;
             const int y0 = s * a.RT;
             const int rows = min(a.RT, a.Ho - y0);
@@ -575,7 +611,7 @@ __global__ __launch_bounds__(256, 1) void k_wgrad32(WgradArgs a)
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (next < a.n_items && ABL != 1) commit(next, (it + 1) & 1, pf);
+        if (!SPLIT && next < a.n_items && ABL != 1) commit(next, (it + 1) & 1, pf);
         __syncthreads();
     }
     // ---- fixed-order reduction over the 4 waves through LDS, then one slab per workgroup
@@ -1168,9 +1204,9 @@ static int wgrad32_impl(const float *act_prev, const float *dz, float *dw, float
     if (bf16in) {
         if (int rc = set_lds(k_wgrad32<0, true>, lds, name)) return rc;
         hipLaunchKernelGGL((k_wgrad32<0, true>), dim3(grid), dim3(256), lds, s, a);
-    } else {
-        if (int rc = set_lds(k_wgrad32<0, false>, lds, name)) return rc;
-        hipLaunchKernelGGL((k_wgrad32<0, false>), dim3(grid), dim3(256), lds, s, a);
+    } else { // f32: 4 accumulating + 4 loader waves
+        if (int rc = set_lds(k_wgrad32<0, false, true>, lds, name)) return rc;
+        hipLaunchKernelGGL((k_wgrad32<0, false, true>), dim3(grid), dim3(512), lds, s, a);
     }
     if (int rc = augcl::check_launch(name)) return rc;
     return augcl::reduce_slabs(ReduceDesc{workspace, workspace + (size_t)grid * WG_SLAB, dw, db, grid, WG_SLAB, 32 * 288}, s, name);

@@ -32,6 +32,56 @@ __global__ __launch_bounds__(256, 1) void k_mfma_chain1(float *out, int iters, f
     for (int r = 0; r < 16; ++r) s += acc[r];
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
+// the same operand pattern feeding TWO independent accumulator chains (two tiles at once, shared weights)
+__global__ __launch_bounds__(512, 1) void k_mfma_chain2(float *out, int iters, float a0)
+{
+    __shared__ float sh[4096];
+    for (int i = threadIdx.x; i < 4096; i += blockDim.x) sh[i] = 1.0f + i * 1e-6f;
+    __syncthreads();
+    f32x16 acc0, acc1;
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    float a = a0 + threadIdx.x * 1e-3f;
+    const float *base = sh + (threadIdx.x & 63);
+    float xa[9], xb[9];
+    for (int t = 0; t < 9; ++t) xa[t] = base[t * 64];
+    for (int i = 0; i < iters; i += 2) {
+        for (int t = 0; t < 9; ++t) xb[t] = base[t * 64 + ((i + 1) & 3) * 700];
+        __builtin_amdgcn_sched_barrier(0);
+        for (int t = 0; t < 9; ++t) { if (t & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xa[t], acc1, 0, 0, 0); else acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xa[t], acc0, 0, 0, 0); }
+        for (int t = 0; t < 9; ++t) xa[t] = base[t * 64 + ((i + 2) & 3) * 700];
+        __builtin_amdgcn_sched_barrier(0);
+        for (int t = 0; t < 9; ++t) { if (t & 1) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xb[t], acc0, 0, 0, 0); else acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xb[t], acc1, 0, 0, 0); }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    float s = 0.f;
+    for (int r = 0; r < 16; ++r) s += acc0[r] + acc1[r];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+// one chain per wave, TWO waves per SIMD (512 threads per workgroup)
+__global__ __launch_bounds__(512, 1) void k_mfma_chain1x2(float *out, int iters, float a0)
+{
+    __shared__ float sh[4096];
+    for (int i = threadIdx.x; i < 4096; i += 512) sh[i] = 1.0f + i * 1e-6f;
+    __syncthreads();
+    f32x16 acc;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float a = a0 + threadIdx.x * 1e-3f;
+    const float *base = sh + (threadIdx.x & 63);
+    float xa[9], xb[9];
+    for (int t = 0; t < 9; ++t) xa[t] = base[t * 64];
+    for (int i = 0; i < iters; i += 2) {
+        for (int t = 0; t < 9; ++t) xb[t] = base[t * 64 + ((i + 1) & 3) * 700];
+        __builtin_amdgcn_sched_barrier(0);
+        for (int t = 0; t < 9; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xa[t], acc, 0, 0, 0);
+        for (int t = 0; t < 9; ++t) xa[t] = base[t * 64 + ((i + 2) & 3) * 700];
+        __builtin_amdgcn_sched_barrier(0);
+        for (int t = 0; t < 9; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xb[t], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    float s = 0.f;
+    for (int r = 0; r < 16; ++r) s += acc[r];
+    out[blockIdx.x * 512 + threadIdx.x] = s;
+}
 // register-only f32 MFMA loop: the practical MFMA ceiling (clock under load) on this chip
 __global__ __launch_bounds__(256, 1) void k_mfma_peak(float *out, int iters, float a0)
 {
@@ -93,6 +143,8 @@ int main(int argc, char **argv)
     vs.push_back({"wgrad 1/9 mfma", f_fwd, [&] { wg(k_wgrad32<2>); }});
     vs.push_back({"mfma f32 peak (regs only)", 2.0 * 32 * 32 * 2 * 16 * 4000.0 * 4 * 256, [&] { hipLaunchKernelGGL(k_mfma_peak, dim3(256), dim3(256), 0, 0, out, 4000, 0.5f); }});
     vs.push_back({"mfma 1 chain + LDS prefetch", 2.0 * 32 * 32 * 2 * 9 * 4000.0 * 4 * 256, [&] { hipLaunchKernelGGL(k_mfma_chain1, dim3(256), dim3(256), 0, 0, out, 4000, 0.5f); }});
+    vs.push_back({"mfma 2 chains + LDS (1 wave)", 2.0 * 32 * 32 * 2 * 9 * 4000.0 * 4 * 256, [&] { hipLaunchKernelGGL(k_mfma_chain2, dim3(256), dim3(256), 0, 0, out, 4000, 0.5f); }});
+    vs.push_back({"mfma 1 chain, 2 waves/SIMD", 2.0 * 32 * 32 * 2 * 9 * 4000.0 * 8 * 256, [&] { hipLaunchKernelGGL(k_mfma_chain1x2, dim3(256), dim3(512), 0, 0, out, 4000, 0.5f); }});
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     printf("B=%d H=%d\n%-26s %9s %9s\n", B, H, "variant", "med us", "TFLOP/s");
     std::vector<std::vector<double>> us(vs.size());
