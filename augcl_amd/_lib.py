@@ -80,6 +80,7 @@ _SIGS = {
     "augcl_ln_tanh_backward": [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _D, _P],
     "augcl_proj_ln_tanh_workspace_slabs": [_I, _I, _I],
     "augcl_proj_ln_tanh_forward": [_P, _P, _P, _P, _P, _P, _P, _P, _SZ, _I, _I, _I, _D, _P],
+    "augcl_proj_ln_tanh_cat_forward": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _SZ, _I, _I, _I, _D, _P],
     "augcl_td_target_f32": [_P, _P, _P, _P, _P, _P, _I, _D, _P, _I, _P],
     "augcl_actor_loss_forward": [_P, _P, _P, _P, _P, _I, _P],
     "augcl_actor_loss_backward": [_P, _P, _P, _P, _P, _P, _P, _I, _P],

@@ -146,8 +146,15 @@ class RLProjection(nn.Module):
         self.projection = nn.Sequential(nn.Linear(in_shape[0], out_dim), nn.LayerNorm(out_dim), nn.Tanh())
         self.apply(weight_init)
 
-    def forward(self, x):
+    def forward(self, x, tail=None):
+        """tail (not in the reference's signature): the actions the critic will concatenate to this projection's output;
+        returns (features, [features | tail]) when the fused launch can build that row as well, (features, None) if not."""
         lin, ln = self.projection[0], self.projection[1]
+        if tail is not None:
+            out = None
+            if head_ops._ok(x) and ln.weight.is_cuda and self.out_dim <= 128:
+                out = head_ops.proj_ln_tanh(x, lin, ln, tail=tail)
+            return out if out is not None else (self.forward(x), None)
         if head_ops._ok(x) and ln.weight.is_cuda and self.out_dim <= 256:
             out = head_ops.proj_ln_tanh(x, lin, ln)  # the whole projection: split-K MFMA GEMM + LN + tanh, 2 launches
             if out is not None:
@@ -169,15 +176,16 @@ class Encoder(nn.Module):
     def features(self, x):
         return self.head_cnn(self.shared_cnn(x))
 
-    def forward(self, x, detach=False, features=None):
+    def forward(self, x, detach=False, features=None, tail=None):
         """features: a precomputed head_cnn(shared_cnn(x)) may be passed to avoid recomputing the CNN
-        when two encoders share it and see the same input (actor + critic in update_actor_and_alpha)."""
+        when two encoders share it and see the same input (actor + critic in update_actor_and_alpha).
+        tail: see RLProjection.forward -- then the result is the pair (features, [features | tail] or None)."""
         x = self.features(x) if features is None else features
         if detach:
             x = x.detach()
         elif self.cuts is not None and x.requires_grad:
             self.cuts.append(x)  # the cut between conv stack and heads (flat.FlatAdam.backward_begin)
-        return self.projection(x)
+        return self.projection(x) if tail is None else self.projection(x, tail=tail)
 
 
 class Actor(nn.Module):
@@ -238,14 +246,22 @@ class Critic(nn.Module):
         self.Q2 = QFunction(self.encoder.out_dim, action_shape[0], hidden_dim)
 
     def _twin(self, h, action, freeze=False):
-        assert h.size(0) == action.size(0)
+        if action.size(0) != h.size(0):  # fewer action rows than observations: the rows repeat (SVEA's [obs; obs_aug])
+            assert h.size(0) % action.size(0) == 0
+            action = action.repeat(h.size(0) // action.size(0), 1)
         if head_ops._ok(h, action):  # both trunks as one batched network (head_ops.twin_q); nn.Sequential otherwise
             return head_ops.twin_q(h, action, self.Q1, self.Q2, freeze=freeze)
         return self.Q1(h, action), self.Q2(h, action)
 
     def forward(self, x, action, detach=False, features=None, freeze_q=False):
         """freeze_q (not in the reference's signature): the Q trunks' weights enter as constants -- the actor step only
-        needs the gradient with respect to the action."""
+        needs the gradient with respect to the action.  action may have B rows for a k*B-row x: the rows repeat."""
+        if head_ops._ok(action) and isinstance(self.encoder.projection, RLProjection):
+            # the projection's last launch also writes the Q trunks' input rows [features | action]: no concat launches
+            h, xcat = self.encoder(x, detach, features=features, tail=action)
+            if xcat is not None:
+                return head_ops.twin_q(xcat, None, self.Q1, self.Q2, freeze=freeze_q)
+            return self._twin(h, action, freeze_q)
         return self._twin(self.encoder(x, detach, features=features), action, freeze_q)
 
     def forward_Q(self, x_encoded, action):

@@ -26,7 +26,7 @@ class SVEA(RAD):
                 obs_aug = self.apply_aug(obs.clone() if self._aug_mutates() else obs)
             obs_both = torch.cat([obs, obs_aug], dim=0)
         self._cuts(self.critic)
-        q1, q2 = self.critic(obs_both, torch.cat([action, action], dim=0))
+        q1, q2 = self.critic(obs_both, action)  # B action rows for the 2B observations: the critic repeats them
         if head_ops._ok(q1, q2, target_Q):
             # one launch: per-half mse(Q1,y) + mse(Q2,y) and their weighted sum (and one launch backward)
             critic_loss, segs = head_ops.q_loss(q1, q2, target_Q, (self.svea_alpha, self.svea_beta))

@@ -428,8 +428,11 @@ __global__ __launch_bounds__(256) void k_proj_partial(ProjArgs a)
 __global__ __launch_bounds__(256) void k_proj_reduce_ln_tanh(const float *__restrict__ part, const float *__restrict__ bias,
                                                              const float *__restrict__ gamma, const float *__restrict__ beta,
                                                              float *__restrict__ y, float *__restrict__ z, int M, int N, int S,
-                                                             float eps)
+                                                             float eps, float *__restrict__ xcat,
+                                                             const float *__restrict__ tail, int A, int tail_rows)
 {
+    // xcat != null: the critic's input row [z | action] is written as well (row stride N + A <= 128): tail (tail_rows, A),
+    // row r takes tail row r % tail_rows -- SVEA's 2B-row pass repeats the B actions -- so no concat launch follows.
     __shared__ float red[2][2][2]; // [row in block][wave of the row][sum | sum of squares]
     const int half = threadIdx.x >> 7, j = threadIdx.x & 127, wv = (threadIdx.x >> 6) & 1;
     const int row = blockIdx.x * 2 + half;
@@ -461,7 +464,12 @@ __global__ __launch_bounds__(256) void k_proj_reduce_ln_tanh(const float *__rest
     if ((threadIdx.x & 63) == 0) red[half][wv][1] = q;
     __syncthreads();
     const float rstd = 1.0f / sqrtf((red[half][0][1] + red[half][1][1]) / (float)N + eps);
-    if (live) z[(size_t)row * N + j] = tanhf((d * rstd) * gamma[j] + beta[j]);
+    const float zv = live ? tanhf((d * rstd) * gamma[j] + beta[j]) : 0.0f;
+    if (live) z[(size_t)row * N + j] = zv;
+    if (xcat != nullptr && row < M) {
+        if (j < N) xcat[(size_t)row * (N + A) + j] = zv;
+        else if (j < N + A) xcat[(size_t)row * (N + A) + j] = tail[(size_t)(row % tail_rows) * A + (j - N)];
+    }
 }
 
 // ---- the 3-layer MLP trunks (QFunction src/algorithms/modules.py:247-261, Actor.mlp :200-215) around their library
@@ -803,23 +811,42 @@ int augcl_proj_ln_tanh_workspace_slabs(int M, int K, int N)
     return best;
 }
 
-int augcl_proj_ln_tanh_forward(const float *x, const float *w, const float *bias, const float *gamma, const float *beta,
-                               float *y, float *z, float *workspace, size_t workspace_bytes, int M, int K, int N, double eps,
-                               augcl_stream_t stream)
+static int proj_forward_impl(const float *x, const float *w, const float *bias, const float *gamma, const float *beta,
+                             float *y, float *z, float *xcat, const float *tail, int A, int tail_rows, float *workspace,
+                             size_t workspace_bytes, int M, int K, int N, double eps, augcl_stream_t stream, const char *name)
 {
-    const char *name = "augcl_proj_ln_tanh_forward";
     const int S = augcl_proj_ln_tanh_workspace_slabs(M, K, N);
     AUGCL_REQUIRE(S > 0, "%s: shape (M=%d, K=%d, N=%d) not covered (N <= 128, K/32 divisible by one of 63,49,32,21,16,9,8,7)", name, M, K, N);
     AUGCL_REQUIRE(x && w && bias && gamma && beta && y && z && workspace, "%s: null tensor", name);
     AUGCL_REQUIRE(aligned16(x) && aligned16(w), "%s: x and w must be 16-byte aligned", name);
     AUGCL_REQUIRE(workspace_bytes >= (size_t)S * M * N * sizeof(float), "%s: workspace too small (%zu < %zu)", name,
                   workspace_bytes, (size_t)S * M * N * sizeof(float));
+    AUGCL_REQUIRE(!xcat || (tail && A >= 1 && N + A <= 128 && tail_rows >= 1 && M % tail_rows == 0),
+                  "%s: concatenated output needs a tail with N + A <= 128 and M a multiple of its rows", name);
     ProjArgs a{x, w, workspace, M, K, N, S, K / 32 / S};
     hipStream_t s = as_stream(stream);
     hipLaunchKernelGGL(k_proj_partial, dim3((M + 31) / 32, S), dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_proj_reduce_ln_tanh, dim3((M + 1) / 2), dim3(256), 0, s, workspace, bias, gamma, beta, y, z, M, N, S,
-                       (float)eps);
+                       (float)eps, xcat, tail, A, tail_rows);
     return augcl::check_launch(name);
+}
+
+int augcl_proj_ln_tanh_forward(const float *x, const float *w, const float *bias, const float *gamma, const float *beta,
+                               float *y, float *z, float *workspace, size_t workspace_bytes, int M, int K, int N, double eps,
+                               augcl_stream_t stream)
+{
+    return proj_forward_impl(x, w, bias, gamma, beta, y, z, nullptr, nullptr, 0, 1, workspace, workspace_bytes, M, K, N, eps,
+                             stream, "augcl_proj_ln_tanh_forward");
+}
+
+int augcl_proj_ln_tanh_cat_forward(const float *x, const float *w, const float *bias, const float *gamma, const float *beta,
+                                   float *y, float *z, float *xcat, const float *tail, int A, int tail_rows, float *workspace,
+                                   size_t workspace_bytes, int M, int K, int N, double eps, augcl_stream_t stream)
+{
+    const char *name = "augcl_proj_ln_tanh_cat_forward";
+    AUGCL_REQUIRE(xcat, "%s: null output", name);
+    return proj_forward_impl(x, w, bias, gamma, beta, y, z, xcat, tail, A, tail_rows, workspace, workspace_bytes, M, K, N, eps,
+                             stream, name);
 }
 
 int augcl_mlp_out_forward(float *z, const float *b2, int64_t b2_twin_stride, const float *w3, int64_t w3_twin_stride,

@@ -101,23 +101,44 @@ class _ProjLnTanh(torch.autograd.Function):
     augcl_proj_dx_f32 (the output-bound GEMM with the 100-wide inner dimension)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, gamma, beta, eps, slabs):
+    def forward(ctx, x, w, b, gamma, beta, eps, slabs, tail):
+        ctx.set_materialize_grads(False)
         x = x.contiguous()
         M, K = x.shape
         N = w.shape[0]
         yz = torch.empty((2, M, N), dtype=torch.float32, device=x.device)
         ws = torch.empty(slabs * M * N, dtype=torch.float32, device=x.device)
-        _lib.call("augcl_proj_ln_tanh_forward", x.data_ptr(), w.data_ptr(), b.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                  yz[0].data_ptr(), yz[1].data_ptr(), ws.data_ptr(), ws.numel() * 4, M, K, N, float(eps),
-                  _lib.current_stream(x.device))
+        st = _lib.current_stream(x.device)
+        ctx.eps, ctx.tail_rows = float(eps), 0
+        if tail is None:
+            _lib.call("augcl_proj_ln_tanh_forward", x.data_ptr(), w.data_ptr(), b.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                      yz[0].data_ptr(), yz[1].data_ptr(), ws.data_ptr(), ws.numel() * 4, M, K, N, float(eps), st)
+            ctx.save_for_backward(x, w, gamma, yz)
+            return yz[1]
+        # the critic's input rows [z | action] leave the same launch (no torch.cat after it); tail rows repeat over M
+        tail = tail.contiguous()
+        A = tail.shape[1]
+        xcat = torch.empty((M, N + A), dtype=torch.float32, device=x.device)
+        _lib.call("augcl_proj_ln_tanh_cat_forward", x.data_ptr(), w.data_ptr(), b.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                  yz[0].data_ptr(), yz[1].data_ptr(), xcat.data_ptr(), tail.data_ptr(), A, tail.shape[0], ws.data_ptr(),
+                  ws.numel() * 4, M, K, N, float(eps), st)
         ctx.save_for_backward(x, w, gamma, yz)
-        ctx.eps = float(eps)
-        return yz[1]
+        ctx.tail_rows = tail.shape[0]
+        return yz[1], xcat
 
     @staticmethod
-    def backward(ctx, gz):
+    def backward(ctx, gz, gcat=None):
         x, w, gamma, yz = ctx.saved_tensors
         M, N = yz.shape[1], yz.shape[2]
+        d_tail = None
+        if gcat is not None:  # gradient of [z | tail]: its first N columns are z's, the rest the tail's (summed over repeats)
+            if ctx.needs_input_grad[7]:
+                d_tail = gcat[:, N:]
+                if ctx.tail_rows != M:
+                    d_tail = d_tail.reshape(M // ctx.tail_rows, ctx.tail_rows, -1).sum(0)
+            gz = gcat[:, :N] if gz is None else gz + gcat[:, :N]
+        if gz is None:
+            return None, None, None, None, None, None, None, d_tail
         gz, ld = _rows(gz, N)  # usually the feature columns of the critic's input gradient: read in place
         dy = torch.empty((M, N), dtype=torch.float32, device=x.device)
         small = torch.empty((3, N), dtype=torch.float32, device=x.device)  # dgamma, dbeta, dbias
@@ -134,12 +155,13 @@ class _ProjLnTanh(torch.autograd.Function):
                           _lib.current_stream(x.device))
             else:
                 dx = dy.mm(w)
-        return dx, dw, small[2], small[0], small[1], None, None
+        return dx, dw, small[2], small[0], small[1], None, None, d_tail
 
 
-def proj_ln_tanh(x, lin, ln):
+def proj_ln_tanh(x, lin, ln, tail=None):
     """tanh(LayerNorm(Linear(x))) for an nn.Linear / nn.LayerNorm pair, or None when the fused kernels do not cover the
-    shape (the caller then runs the Linear through the GEMM library and `ln_tanh`)."""
+    shape (the caller then runs the Linear through the GEMM library and `ln_tanh`).  tail (R, A) with x's row count a
+    multiple of R: returns (z, [z | tail rows repeated]) -- the critic's input, built by the same launch."""
     if lin.bias is None or x.dim() != 2 or not x.is_contiguous() and x.stride(-1) != 1:
         return None
     M, K = x.shape
@@ -149,7 +171,10 @@ def proj_ln_tanh(x, lin, ln):
     slabs = _lib.load().augcl_proj_ln_tanh_workspace_slabs(int(M), int(K), int(N))
     if slabs <= 0:
         return None
-    return _ProjLnTanh.apply(x, lin.weight, lin.bias, ln.weight, ln.bias, ln.eps, slabs)
+    if tail is not None and not (_ok(tail) and tail.dim() == 2 and N + tail.shape[1] <= 128 and tail.shape[0] >= 1
+                                 and M % tail.shape[0] == 0):
+        return None
+    return _ProjLnTanh.apply(x, lin.weight, lin.bias, ln.weight, ln.bias, ln.eps, slabs, tail)
 
 
 def ln_tanh(x, gamma, beta, eps=1e-5):
@@ -274,7 +299,7 @@ class _TwinQ(torch.autograd.Function):
     def forward(ctx, h, a, w1a, b1a, w2a, b2a, w3a, b3a, w1b, b1b, w2b, b2b, w3b, b3b):
         ctx.set_materialize_grads(False)
         B, H = h.shape[0], w1a.shape[0]
-        x = torch.cat([h, a], dim=1)
+        x = h if a is None else torch.cat([h, a], dim=1)  # a = None: h already is [features | action]
         W1, b1, W2, b2, W3, b3 = (_stacked(p, q) for p, q in ((w1a, w1b), (b1a, b1b), (w2a, w2b), (b2a, b2b), (w3a, w3b), (b3a, b3b)))
         if not (W1.is_contiguous() and b1.is_contiguous()):  # padding between the twins' tensors: stacked copies
             W1, b1 = W1.contiguous(), b1.contiguous()
@@ -287,7 +312,7 @@ class _TwinQ(torch.autograd.Function):
         if gate_hook is not None:
             gate_hook("twin", a1, z2)
         ctx.save_for_backward(x, a1, z2, W1, W2, W3)  # z2 now holds a2 = relu(z2 + b2)
-        ctx.n_h = h.shape[1]
+        ctx.n_h = h.shape[1] if a is not None else -1
         return q[0], q[1]
 
     @staticmethod
@@ -318,6 +343,8 @@ class _TwinQ(torch.autograd.Function):
             db1 = db1.view(2, H)
             for t in (0, 1):
                 gw[6 * t:6 * t + 6] = [dW1[t], db1[t], dW2[t], db2[t], dW3[t], db3[t]]
+        if ctx.n_h < 0:  # pre-concatenated input: one gradient for the whole row
+            return (dx, None, *gw)
         dh = dx[:, :ctx.n_h] if dx is not None and ctx.needs_input_grad[0] else None
         da = dx[:, ctx.n_h:] if dx is not None and ctx.needs_input_grad[1] else None
         return (dh, da, *gw)
@@ -325,6 +352,7 @@ class _TwinQ(torch.autograd.Function):
 
 def twin_q(h, a, q1, q2, freeze=False):
     """(Q1(h, a), Q2(h, a)) for two modules.QFunction with 3-layer trunks (Linear, ReLU, Linear, ReLU, Linear).
+    a = None: h already holds the concatenated rows [features | action] (proj_ln_tanh(..., tail=action)).
     freeze: the trunks' weights take part as constants (the actor step, src/algorithms/sac.py:119-133: the reference
     builds their gradients there and throws them away at the next critic zero_grad)."""
     t1, t2 = q1.trunk, q2.trunk

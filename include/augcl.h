@@ -250,6 +250,12 @@ int augcl_proj_ln_tanh_workspace_slabs(int M, int K, int N);
 int augcl_proj_ln_tanh_forward(const float *x, const float *w, const float *bias, const float *gamma, const float *beta,
                                float *y, float *z, float *workspace, size_t workspace_bytes, int M, int K, int N, double eps,
                                augcl_stream_t stream);
+/* The same with the critic's input row built on the way out: xcat (M, N + A) = [z | tail row (m % tail_rows)], what
+ * QFunction.forward's torch.cat([obs, action], dim=1) produces (src/algorithms/modules.py:258-261; SVEA's 2B-row critic
+ * pass repeats the B actions, svea.py:44-45).  N + A <= 128, M a multiple of tail_rows. */
+int augcl_proj_ln_tanh_cat_forward(const float *x, const float *w, const float *bias, const float *gamma, const float *beta,
+                                   float *y, float *z, float *xcat, const float *tail, int A, int tail_rows, float *workspace,
+                                   size_t workspace_bytes, int M, int K, int N, double eps, augcl_stream_t stream);
 /* RLProjection backward, input side: dx (M,K) = dy (M,N) w (N,K), the gradient that enters the conv stack (what autograd's
  * Linear backward computes for src/algorithms/modules.py:104); N a multiple of 4, <= 128; dy 16-byte aligned. */
 int augcl_proj_dx_f32(const float *dy, const float *w, float *dx, int M, int N, int K, augcl_stream_t stream);

@@ -39,6 +39,7 @@ def test_bad_arguments_are_reported_not_crashed():
     assert lib.augcl_proj_ln_tanh_workspace_slabs(8, 14112, 300) == 0 and lib.augcl_proj_ln_tanh_workspace_slabs(8, 1000, 100) == 0
     assert lib.augcl_proj_ln_tanh_forward(None, None, None, None, None, None, None, None, 0, 8, 1000, 100, 1e-5, None) == -1
     assert b"not covered" in lib.augcl_last_error()
+    assert lib.augcl_proj_ln_tanh_cat_forward(None, None, None, None, None, None, None, None, None, 6, 4, None, 0, 8, 14112, 100, 1e-5, None) == -1
     assert lib.augcl_interpolate_bg_u8(None, None, 0, 240, 320, 84, 84, None) == 0 and lib.augcl_interpolate_bg_u8(None, None, 1, 240, 320, 84, 84, None) == -1
     assert lib.augcl_green_screen_resize_u8(None, None, None, 1, 84, 84, 0, 320, None) == -1
     assert lib.augcl_alpha_step_f64(None, None, 4, -6.0, 1e-4, 0.5, 0.999, 1e-8, None, None, 3, None) == -1

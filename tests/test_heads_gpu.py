@@ -345,3 +345,60 @@ def test_proj_dx_kernel(cuda, M, N, K):
     want = dy.double() @ w.double()
     assert float((dx.double() - want).abs().max()) <= 2e-6 * N ** 0.5 * max(1.0, float(want.abs().max()))
 
+
+@pytest.mark.parametrize("M,R,A", [(256, 256, 6), (512, 256, 6), (66, 33, 21), (3, 1, 1)])
+def test_projection_builds_the_critic_input_row(cuda, M, R, A):
+    """proj_ln_tanh(..., tail=action): the launch that finishes the projection also writes [features | action] (action rows
+    repeating over the batch, SVEA's 2B-row critic pass) -- equal, values and every gradient, to projection + repeat +
+    torch.cat; and the critic takes that path by itself."""
+    torch.manual_seed(M + A)
+    K, N = 14112, 100
+    proj = m.RLProjection((K,), N).to(cuda)
+    lin, ln = proj.projection[0], proj.projection[1]
+    g = torch.Generator(device=cuda).manual_seed(3)
+    x0 = torch.relu(torch.randn(M, K, device=cuda, generator=g)) * 0.2
+    t0 = torch.rand(R, A, device=cuda, generator=g) * 2 - 1
+    go = torch.randn(M, N + A, device=cuda, generator=g)
+    res = []
+    for fused in (False, True):
+        for p_ in proj.parameters():
+            p_.grad = None
+        x, t = x0.clone().requires_grad_(True), t0.clone().requires_grad_(True)
+        if fused:
+            z, xcat = head_ops.proj_ln_tanh(x, lin, ln, tail=t)
+        else:
+            z = head_ops.proj_ln_tanh(x, lin, ln)
+            xcat = torch.cat([z, t.repeat(M // R, 1)], dim=1)
+        (xcat * go).sum().backward()
+        res.append([xcat.detach(), z.detach(), x.grad, t.grad] + [p_.grad.clone() for p_ in proj.parameters()])
+    for i, (a, b) in enumerate(zip(*res)):
+        assert torch.equal(a, b) if i != 3 else float((a - b).abs().max()) <= 1e-6 * max(1.0, float(a.abs().max())), i
+
+
+def test_critic_uses_the_concatenating_projection(cuda):
+    """Critic.forward: fused [features | action] rows (actions repeating for a 2B batch) == encoder, repeat, concat, trunks."""
+    torch.manual_seed(11)
+    B, A = 64, 6
+
+    class Feat(torch.nn.Module):
+        def forward(self, x):
+            return x
+
+    enc = m.Encoder(Feat(), Feat(), m.RLProjection((14112,), 100)).to(cuda)
+    critic = m.Critic(enc, (A,), 256).to(cuda)
+    x0 = torch.relu(torch.randn(2 * B, 14112, device=cuda)) * 0.2
+    a0 = torch.rand(B, A, device=cuda) * 2 - 1
+    out = []
+    for fused in (True, False):
+        for p_ in critic.parameters():
+            p_.grad = None
+        a = a0.clone().requires_grad_(True)
+        if fused:
+            q1, q2 = critic(x0, a)
+        else:
+            q1, q2 = critic._twin(critic.encoder(x0), a)
+        (q1.sum() + 0.5 * q2.sum()).backward()
+        out.append([q1.detach(), q2.detach(), a.grad] + [p_.grad.clone() for p_ in critic.parameters()])
+    for i, (u, v) in enumerate(zip(*out)):
+        assert float((u - v).abs().max()) <= 2e-6 * max(1e-3, float(v.abs().max())), i
+

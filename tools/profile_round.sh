@@ -1,0 +1,37 @@
+#!/bin/bash
+# The rocprofv3 passes behind profiles/ -- run ON the GPU box from the repo root:  bash tools/profile_round.sh r2
+# then, back in the container:  python tools/summarize_profiles.py r2   (copies / condenses gpurun_out/r2_* into profiles/).
+# One counter group per pass (MI355X_MICROARCH.md); --pmc is never combined with the hip / sys traces; every raw
+# trace directory is condensed on the box (tools/prof_summary.py, tools/pmc_summary.py) and deleted.
+set -e
+R=${1:-r2}
+ROOT=$(pwd)
+cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
+O=gpurun_out
+BENCH="python bench.py --steps 2000 --warmup 200 --no-sac --no-cpu-baseline --min-timed-s 0"
+
+# 1. per-kernel durations of the augmentation / replay bench (headline kernel k_conv<...> and the extras)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${R}_bench -- $BENCH > $O/${R}_bench.out 2>&1
+python tools/prof_summary.py $O/${R}_bench 1 "bench.py --steps 2000 --warmup 200 --no-sac (B=256 augmentation / replay kernels)"
+echo "[profile_round] bench stats done"
+
+# 2. HBM traffic of the same kernels: FETCH_SIZE and WRITE_SIZE in separate passes
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${R}_fetch -- $BENCH > /dev/null 2>&1
+python tools/pmc_summary.py $O/${R}_fetch
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/${R}_write -- $BENCH > /dev/null 2>&1
+python tools/pmc_summary.py $O/${R}_write
+echo "[profile_round] traffic done"
+
+# 3. SVEA update(): per-kernel durations (hipGraph replay) and MFMA-busy counters, f32 parity path and bf16 mode
+for P in f32 bf16; do
+    rocprofv3 --kernel-trace --stats --output-format csv -d $O/${R}_update_$P -- python tools/prof_update.py 40 $P graph > $O/${R}_update_$P.log 2>&1
+    python tools/prof_summary.py $O/${R}_update_$P 48 "SVEA update() B=256, $P, hipGraph replay (tools/prof_update.py 40 $P graph: 8 warm-up + 40 timed)"
+    rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/${R}_mfma_$P -- python tools/prof_update.py 12 $P > /dev/null 2>&1
+    python tools/pmc_summary.py $O/${R}_mfma_$P
+    echo "[profile_round] update $P done"
+done
+
+# 4. the launch sequence of one graph-replayed update (launch count, per-kernel durations in order)
+rocprofv3 --kernel-trace --output-format csv -d $O/${R}_seq_f32 -- python tools/prof_update.py 6 f32 graph > /dev/null 2>&1
+python tools/prof_sequence.py $O/${R}_seq_f32 280
+echo "[profile_round] all done"

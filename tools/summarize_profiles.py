@@ -105,3 +105,18 @@ for prec in ("f32", "bf16"):
 if "f32" in busy or "bf16" in busy:
     json.dump(busy, open(os.path.join(out, f"{tag}_mfma_busy.json"), "w"), indent=1)
     print("mfma_busy:", busy.get("f32"), busy.get("bf16"))
+
+# ---- the launch sequence of graph-replayed updates: launches per update() with and without the actor step
+if os.path.exists(G("seq_f32_sequence.txt")):
+    rows = [l.rstrip("\n") for l in open(G("seq_f32_sequence.txt"))]
+    body = [l for l in rows if not l.startswith("#")]
+    marks = [i for i, l in enumerate(body) if "k_conv<84" in l or "k_replay_shift_conv" in l]  # the eager front end starts an update
+    counts = [b - a for a, b in zip(marks[:-1], marks[1:])]
+    with open(os.path.join(out, f"{tag}_update_launch_sequence.txt"), "w") as o:
+        o.write("# kernel launches of consecutive SVEA update() calls, f32, hipGraph replay (tools/prof_sequence.py); an update starts at\n"
+                "# the front end's k_conv<...> launch; the actor / temperature step runs every second update\n"
+                f"# launches per update in this window: {counts}  (average over an actor + a critic-only update: "
+                f"{sum(counts[-2:]) / 2 if len(counts) >= 2 else 'n/a'})\n")
+        o.write("\n".join(rows) + "\n")
+    print("launches per update:", counts)
+
