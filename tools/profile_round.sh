@@ -33,5 +33,5 @@ done
 
 # 4. the launch sequence of one graph-replayed update (launch count, per-kernel durations in order)
 rocprofv3 --kernel-trace --output-format csv -d $O/${R}_seq_f32 -- python tools/prof_update.py 6 f32 graph > /dev/null 2>&1
-python tools/prof_sequence.py $O/${R}_seq_f32 280
+python tools/prof_sequence.py $O/${R}_seq_f32 420
 echo "[profile_round] all done"
