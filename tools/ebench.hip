@@ -82,6 +82,37 @@ __global__ __launch_bounds__(512, 1) void k_mfma_chain1x2(float *out, int iters,
     for (int r = 0; r < 16; ++r) s += acc[r];
     out[blockIdx.x * 512 + threadIdx.x] = s;
 }
+// 16x16x4 f32 MFMAs, one ds_read_b32 per MFMA, 4 independent accumulator tiles per wave; NW waves per workgroup
+typedef float f32x4m __attribute__((ext_vector_type(4)));
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 1) void k_mfma_16x4(float *out, int iters, float a0)
+{
+    __shared__ float sh[8192];
+    for (int i = threadIdx.x; i < 8192; i += NW * 64) sh[i] = 1.0f + i * 1e-6f;
+    __syncthreads();
+    f32x4m acc[4];
+    for (int t = 0; t < 4; ++t) for (int r = 0; r < 4; ++r) acc[t][r] = 0.f;
+    float w[9];
+    for (int t = 0; t < 9; ++t) w[t] = a0 + threadIdx.x * 1e-3f + t;
+    const int lane = threadIdx.x & 63;
+    const float *base = sh + (lane & 15) + (lane >> 4) * 1040 + (threadIdx.x >> 6) * 16; // 4 k-groups 1040 floats apart (== 16 mod 64 banks)
+    float xa[4][9], xb[4][9];
+    for (int p = 0; p < 4; ++p) for (int t = 0; t < 9; ++t) xa[p][t] = base[p * 64 + (t / 3) * 88 + t % 3];
+    for (int i = 0; i < iters; i += 2) {
+        const float *b1 = base + ((i + 1) & 3) * 300;
+        for (int p = 0; p < 4; ++p) for (int t = 0; t < 9; ++t) xb[p][t] = b1[p * 64 + (t / 3) * 88 + t % 3];
+        __builtin_amdgcn_sched_barrier(0);
+        for (int t = 0; t < 9; ++t) for (int p = 0; p < 4; ++p) acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t], xa[p][t], acc[p], 0, 0, 0);
+        const float *b2 = base + ((i + 2) & 3) * 300;
+        for (int p = 0; p < 4; ++p) for (int t = 0; t < 9; ++t) xa[p][t] = b2[p * 64 + (t / 3) * 88 + t % 3];
+        __builtin_amdgcn_sched_barrier(0);
+        for (int t = 0; t < 9; ++t) for (int p = 0; p < 4; ++p) acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t], xb[p][t], acc[p], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    float s = 0.f;
+    for (int t = 0; t < 4; ++t) for (int r = 0; r < 4; ++r) s += acc[t][r];
+    out[blockIdx.x * NW * 64 + threadIdx.x] = s;
+}
 // register-only f32 MFMA loop: the practical MFMA ceiling (clock under load) on this chip
 __global__ __launch_bounds__(256, 1) void k_mfma_peak(float *out, int iters, float a0)
 {
@@ -145,7 +176,21 @@ int main(int argc, char **argv)
     vs.push_back({"mfma 1 chain + LDS prefetch", 2.0 * 32 * 32 * 2 * 9 * 4000.0 * 4 * 256, [&] { hipLaunchKernelGGL(k_mfma_chain1, dim3(256), dim3(256), 0, 0, out, 4000, 0.5f); }});
     vs.push_back({"mfma 2 chains + LDS (1 wave)", 2.0 * 32 * 32 * 2 * 9 * 4000.0 * 4 * 256, [&] { hipLaunchKernelGGL(k_mfma_chain2, dim3(256), dim3(256), 0, 0, out, 4000, 0.5f); }});
     vs.push_back({"mfma 1 chain, 2 waves/SIMD", 2.0 * 32 * 32 * 2 * 9 * 4000.0 * 8 * 256, [&] { hipLaunchKernelGGL(k_mfma_chain1x2, dim3(256), dim3(512), 0, 0, out, 4000, 0.5f); }});
+    vs.push_back({"mfma 16x16x4 + LDS, 4 waves", 2.0 * 16 * 16 * 4 * 36 * 1000.0 * 4 * 256, [&] { hipLaunchKernelGGL(k_mfma_16x4<4>, dim3(256), dim3(256), 0, 0, out, 1000, 0.5f); }});
+    vs.push_back({"mfma 16x16x4 + LDS, 8 waves", 2.0 * 16 * 16 * 4 * 36 * 1000.0 * 8 * 256, [&] { hipLaunchKernelGGL(k_mfma_16x4<8>, dim3(256), dim3(512), 0, 0, out, 1000, 0.5f); }});
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    if (argc > 3) { // sustained run of ONE variant for argv[4] seconds (clock / power sampling from outside)
+        const size_t v = (size_t)atoi(argv[3]) % vs.size();
+        const double secs = argc > 4 ? atof(argv[4]) : 3.0;
+        printf("sustained: %s\n", vs[v].name.c_str()); fflush(stdout);
+        double total_us = 0; long n = 0;
+        while (total_us < secs * 1e6) {
+            CK(hipEventRecord(e0, 0)); for (int i = 0; i < 50; ++i) vs[v].run(); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); total_us += ms * 1000.0; n += 50;
+        }
+        printf("%s: %.1f us per launch, %.1f TFLOP/s over %.1f s\n", vs[v].name.c_str(), total_us / n, vs[v].flop / (total_us / n) / 1e6, total_us / 1e6);
+        return 0;
+    }
     printf("B=%d H=%d\n%-26s %9s %9s\n", B, H, "variant", "med us", "TFLOP/s");
     std::vector<std::vector<double>> us(vs.size());
     for (int r = 0; r < 5; ++r) for (size_t v = 0; v < vs.size(); ++v) {
