@@ -173,6 +173,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_first9(First9Args a)
     f32x16 bias16;
 #pragma unroll
     for (int r = 0; r < 16; ++r) bias16[r] = lbias[acc_row_f(r, h)];
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, -1, 0x00020000);
     // bf16 mode: the products run on v_mfma_f32_32x32x16_bf16 -- K = 81 padded to 96 = 6 MFMAs instead of 41.  A fragment
     // of MFMA i: W[co = l31][k = 16 i + 8 h + j], j = 0..7, rounded to bf16 (RNE); k >= 81 carries a zero weight.
     bf16x8 wfrag[F9B_NM];
@@ -328,14 +329,15 @@ __global__ __launch_bounds__(512, 2) void k_conv_first9(First9Args a)
                         }
                         o[2 * g4] = pk;
                     }
-                } else {
-                    float *o = reinterpret_cast<float *>(a.out) + ((size_t)(b * 32) * a.Ho + y) * a.Wo + xx;
+                } else { // buffer stores: lane byte offset + a wave-uniform row offset in an SGPR (no vector address chain)
                     const int chw = a.Ho * a.Wo;
+                    const unsigned boff = (unsigned)(((b * 32 + 4 * h) * a.Ho + y) * a.Wo + xx) * 4u; // host: B*32*Ho*Wo < 2^30
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         float v = acc[r];
-                        if (RELU) v = v > 0.0f ? v : 0.0f;
-                        o[acc_row_f(r, h) * chw] = v;
+                        if (RELU) v = __int_as_float(max(__float_as_int(v), 0)); // one v_max_i32: negative floats are negative ints
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_out, boff,
+                                                              (unsigned)(((r & 3) + 8 * (r >> 2)) * chw) * 4u, 0);
                     }
                 }
             }
@@ -375,6 +377,7 @@ int conv_first9_try(const float *in, const float *w, const float *bias, void *ou
 {
     if (C != 9 || Wi != 84 || stride != 2 || Hi < 3) return 1;
     if (w2 != nullptr && (B & 1)) return 1;
+    if ((size_t)B * 32 * ((Hi - 3) / 2 + 1) * ((Wi - 3) / 2 + 1) >= ((size_t)1 << 30)) return 1; // 32-bit byte offsets in the epilogue
     if ((reinterpret_cast<uintptr_t>(in) & 15u) != 0 || ((size_t)Hi * Wi) % 4 != 0) return 1;
     First9Args a{};
     a.in = in; a.w = w; a.bias = bias; a.out = out;

@@ -175,6 +175,11 @@ __global__ __launch_bounds__(512, 2) void k_conv32(ConvArgs a)
     f32x16 bias16; // accumulator seed: C operand of a tile's first MFMA
 #pragma unroll
     for (int r = 0; r < 16; ++r) bias16[r] = lbias[acc_row(r, h)];
+    const int relu_floor = __builtin_amdgcn_readfirstlane(a.relu ? 0 : (int)0x80000000); // opaque: stays ONE v_max_i32
+    // raw buffer resources (base, stride 0, no bound, gfx9 dword-3 flags): offsets < 2^32 by the host's size check
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_mask =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(MODE == 1 && a.mask ? a.mask : a.in), 0, -1, 0x00020000);
 
     // stage item `it` into buffer `bi` (loader waves only): wave cw copies channels 8cw .. 8cw+7, four
     // channel pairs back to back => 24 dwordx4 per lane in flight, one exposed latency per item
@@ -201,6 +206,18 @@ __global__ __launch_bounds__(512, 2) void k_conv32(ConvArgs a)
     const int first = a.dual ? grp * nhalf + (int)(blockIdx.x >> 1) : xcd_slot((int)blockIdx.x, (int)gridDim.x);
     const int NG = a.dual ? (int)(gridDim.x >> 1) : (int)gridDim.x;
     const int n_end = a.dual ? (grp + 1) * nhalf : a.n_items;
+    // ABL == 4 (tools/ebench only): compute wave 0 of workgroup 0 logs (event id, shader clock) pairs through the pointer
+    // smuggled in a.bias2: 0 tile start, 1 MFMA chain drained, 2 stores issued, 4 before / 5 after the strip's barrier
+    unsigned long long *dbg = nullptr;
+    int ndbg = 0;
+    if (ABL == 4 && blockIdx.x == 0 && wave == 0) dbg = reinterpret_cast<unsigned long long *>(const_cast<float *>(a.bias2));
+    auto stamp = [&](int id) {
+        if (ABL == 4 && dbg != nullptr && ndbg < 2000) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            if (lane == 0) dbg[ndbg] = (t << 4) | (unsigned)id;
+            ++ndbg;
+        }
+    };
     if (loader && first < n_end && ABL != 1) stage(first, 0);
     __syncthreads();
     for (int item = first; item < n_end; item += NG, ++it) {
@@ -217,6 +234,7 @@ __global__ __launch_bounds__(512, 2) void k_conv32(ConvArgs a)
             // ---- M-tiles of 32 consecutive strip pixels, round-robin over the 4 compute waves
             const int ntiles = (npix + 31) >> 5;
             for (int tile = cw; tile < ntiles; tile += 4) {
+                if (ABL == 4) stamp(0);
                 int m = tile * 32 + l31;
                 const bool valid = m < npix;
                 if (!valid) m = npix - 1; // read a real pixel, discard the result
@@ -231,12 +249,23 @@ __global__ __launch_bounds__(512, 2) void k_conv32(ConvArgs a)
                 }
                 // backward-data: the ReLU gate of the layer below is (a_prev > 0) at this lane's 16 outputs -- the same
                 // addresses it will store to.  Issued NOW, consumed after the 144 MFMAs: the latency is free.
-                const int chw = a.Ho * a.Wo; // 32-bit offsets: the host checks B*32*Ho*Wo < 2^31
+                const int chw = a.Ho * a.Wo; // 32-bit offsets: the host checks B*32*Ho*Wo < 2^30
                 const int o0 = (b * 32 * a.Ho + (y0 + yy)) * a.Wo + xx + 4 * h * chw;
+                // one 32-bit lane offset for all 16 rows; the per-row part (rows of co: a multiple of chw) is wave-uniform and
+                // goes into the scalar base of each access (global_load / global_store with an SGPR base: no 64-bit vector
+                // address arithmetic per access -- the epilogue took ~1040 of a tile's ~11300 cycles with it)
+                const unsigned boff = (unsigned)o0 * 4u; // bytes: the host checks B*32*Ho*Wo < 2^30
+                // The accumulating waves reach global memory through BUFFER instructions: address = resource base + this
+                // lane's 32-bit byte offset + a wave-uniform row offset in an SGPR (`buffer_load / buffer_store_dword v, voff,
+                // s[rsrc], soff offen`), i.e. no vector address arithmetic per access.  hipcc's flat-pointer code carried a
+                // 64-bit vector address from row to row and selected the ReLU per element -- 6 vector instructions per
+                // row, ~1040 of a tile's ~11300 cycles (tools/ebench, per-tile s_memtime stamps).
                 float gv[16];
                 if (MODE == 1 && a.mask != nullptr) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) gv[r] = a.mask[o0 + ((r & 3) + 8 * (r >> 2)) * chw];
+                    for (int r = 0; r < 16; ++r)
+                        gv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                              rs_mask, boff, (unsigned)(((r & 3) + 8 * (r >> 2)) * chw) * 4u, 0));
                 }
                 f32x16 acc;
                 // explicit software pipeline: the 9 taps of channel cil+1 are in flight while the 9 MFMAs of
@@ -271,22 +300,25 @@ __global__ __launch_bounds__(512, 2) void k_conv32(ConvArgs a)
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                if (ABL == 4) stamp(acc[0] == 12345.678f ? 3 : 1); // after the MFMA chain has drained (reads acc)
                 if (valid && (ABL != 3 || acc[0] == 12345.678f)) {
+                    // rows in accumulator order: co = 0,1,2,3, 8,9,10,11, ... (+4 h in the lane offset).  Forward ReLU on
+                    // the bit pattern is one v_max_i32 (negative floats are negative integers; floor INT_MIN = no ReLU).
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int o = o0 + ((r & 3) + 8 * (r >> 2)) * chw;
                         float v = acc[r];
-                        if (MODE == 0) {
-                            if (a.relu) v = v > 0.0f ? v : 0.0f;
-                        } else if (a.mask != nullptr) {
-                            v = gv[r] > 0.0f ? v : 0.0f;
-                        }
-                        a.out[o] = v;
+                        if (MODE == 0) v = __int_as_float(max(__float_as_int(v), relu_floor));
+                        else if (a.mask != nullptr) v = gv[r] > 0.0f ? v : 0.0f;
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_out, boff,
+                                                              (unsigned)(((r & 3) + 8 * (r >> 2)) * chw) * 4u, 0);
                     }
                 }
+                if (ABL == 4) stamp(2);
             }
         }
+        if (ABL == 4 && !loader) stamp(4);
         __syncthreads(); // next tile landed AND current tile's readers are done
+        if (ABL == 4 && !loader) stamp(5);
     }
 }
 
@@ -1034,7 +1066,7 @@ static int conv32_forward_impl(const float *in, const float *w, const float *bia
     AUGCL_REQUIRE(in && w && out, "%s: null tensor", name);
     AUGCL_REQUIRE(aligned16(w) && aligned16(w2), "%s: weights must be 16-byte aligned", name);
     AUGCL_REQUIRE(w2 == nullptr || (B & 1) == 0, "%s: a two-weight-set batch must be even", name);
-    AUGCL_REQUIRE((size_t)B * 32 * Hi * Wi < ((size_t)1 << 31), "%s: tensor too large for 32-bit offsets", name);
+    AUGCL_REQUIRE((size_t)B * 32 * Hi * Wi < ((size_t)1 << 30), "%s: tensor too large for 32-bit byte offsets (2^30 elements)", name);
     ConvArgs a{};
     a.w2 = w2; a.bias2 = bias2; a.dual = w2 != nullptr;
     a.in = in; a.w = w; a.bias = bias; a.mask = nullptr; a.out = out;
@@ -1081,7 +1113,7 @@ int augcl_enc_conv32_backward_data(const float *dz, const float *w, const float 
     AUGCL_REQUIRE(B >= 0 && Ho >= 1 && Wo >= 1, "%s: bad shape", name);
     if (B == 0) return AUGCL_OK;
     AUGCL_REQUIRE(dz && w && dact, "%s: null tensor", name);
-    AUGCL_REQUIRE((size_t)B * 32 * (Ho + 2) * (Wo + 2) < ((size_t)1 << 31), "%s: tensor too large for 32-bit offsets", name);
+    AUGCL_REQUIRE((size_t)B * 32 * (Ho + 2) * (Wo + 2) < ((size_t)1 << 30), "%s: tensor too large for 32-bit byte offsets (2^30 elements)", name);
     ConvArgs a{};
     a.in = dz; a.w = w; a.bias = nullptr; a.mask = act_prev; a.out = dact;
     a.B = B; a.Hi = Ho; a.Wi = Wo; a.Ho = Ho + 2; a.Wo = Wo + 2; a.relu = 0;

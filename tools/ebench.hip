@@ -179,6 +179,32 @@ int main(int argc, char **argv)
     vs.push_back({"mfma 16x16x4 + LDS, 4 waves", 2.0 * 16 * 16 * 4 * 36 * 1000.0 * 4 * 256, [&] { hipLaunchKernelGGL(k_mfma_16x4<4>, dim3(256), dim3(256), 0, 0, out, 1000, 0.5f); }});
     vs.push_back({"mfma 16x16x4 + LDS, 8 waves", 2.0 * 16 * 16 * 4 * 36 * 1000.0 * 8 * 256, [&] { hipLaunchKernelGGL(k_mfma_16x4<8>, dim3(256), dim3(512), 0, 0, out, 1000, 0.5f); }});
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    if (argc > 3 && atoi(argv[3]) < 0) { // per-tile shader-clock stamps of workgroup 0's first compute wave (k_conv32<MODE, 4>)
+        unsigned long long *dbg; CK(hipMalloc(&dbg, 2000 * 8)); CK(hipMemset(dbg, 0, 2000 * 8));
+        const int mode = -atoi(argv[3]) - 1; // -1: forward, -2: backward-data
+        auto go = [&](auto kern, int MODEV) {
+            ConvArgs a{}; a.in = in; a.w = w; a.bias = MODEV ? nullptr : bias; a.mask = MODEV ? mask : nullptr; a.out = out; a.B = B; a.Hi = H; a.Wi = H; a.relu = 1;
+            a.bias2 = reinterpret_cast<const float *>(dbg); a.dual = 0;
+            size_t lds;
+            if (MODEV == 0) { a.Ho = H - 2; a.Wo = H - 2; a.RT = pick_rt(a.Ho, 32 * H, 2, kBufLds, &a.S); const size_t bw = (size_t)32 * (((a.RT + 2) * H + 3) & ~3); lds = (std::max(2 * bw, bw + 32 * 292) + 32) * 4; }
+            else { a.Ho = H + 2; a.Wo = H + 2; const int G = (2 * H + 4 + 3) & ~3; a.RT = pick_rt(a.Ho, 32 * H, 2, kBufLds - 8 * G - 64, &a.S); const size_t bw = (size_t)32 * (((a.RT + 2) * H + 3) & ~3) + 2 * G; lds = (std::max(2 * bw, bw + 32 * 292) + 32) * 4; }
+            a.n_items = B * a.S;
+            set_lds(kern, lds, "x");
+            for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(kern, dim3(grid_for(a.n_items, 1)), dim3(512), lds, 0, a);
+            CK(hipDeviceSynchronize());
+            printf("RT=%d S=%d npix=%d items/WG=%.1f\n", a.RT, a.S, a.RT * a.Wo, (double)a.n_items / grid_for(a.n_items, 1));
+        };
+        if (mode == 0) go(k_conv32<0, 4>, 0); else go(k_conv32<1, 4>, 1);
+        std::vector<unsigned long long> hd(2000); CK(hipMemcpy(hd.data(), dbg, 2000 * 8, hipMemcpyDeviceToHost));
+        unsigned long long prev = 0;
+        for (int i = 0; i < 2000 && hd[i]; ++i) {
+            const unsigned long long t = hd[i] >> 4; const int id = (int)(hd[i] & 15);
+            printf("%d:%llu ", id, prev ? t - prev : 0ull); prev = t;
+            if (id == 5) printf("\n");
+        }
+        printf("\n");
+        return 0;
+    }
     if (argc > 3) { // sustained run of ONE variant for argv[4] seconds (clock / power sampling from outside)
         const size_t v = (size_t)atoi(argv[3]) % vs.size();
         const double secs = argc > 4 ? atof(argv[4]) : 3.0;
