@@ -576,6 +576,18 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, 1) void k_wgrad32(WgradArgs a)
         }
     };
 
+    // ABL == 4 (tools/ebench only): accumulating wave 0 of workgroup 0 logs (event, shader clock) behind the slabs:
+    // 0 strip start, 4 before / 5 after the strip's barrier, 6 loop done, 7 slab written
+    unsigned long long *dbg = nullptr;
+    int ndbg = 0;
+    if (ABL == 4 && blockIdx.x == 0 && wave == 0) dbg = reinterpret_cast<unsigned long long *>(a.partial + (size_t)gridDim.x * WG_SLAB + 8 * WG_SLAB);
+    auto stamp = [&](int id) {
+        if (ABL == 4 && dbg != nullptr && ndbg < 500) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            if (lane == 0) dbg[ndbg] = (t << 4) | (unsigned)id;
+            ++ndbg;
+        }
+    };
     WgPrefetch pf;
     int it = 0;
     const int first = xcd_slot((int)blockIdx.x, (int)gridDim.x); // neighbouring strips on one XCD (halo rows hit in L2)
@@ -594,6 +606,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, 1) void k_wgrad32(WgradArgs a)
         if (SPLIT && loader && next < a.n_items && ABL != 1) stage(next, (it + 1) & 1);
         __builtin_amdgcn_sched_barrier(0);
         if (!loader) {
+            if (ABL == 4) stamp(0);
             const int s = item % a.S;
             const int y0 = s * a.RT;
             const int rows = min(a.RT, a.Ho - y0);
@@ -602,50 +615,108 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, 1) void k_wgrad32(WgradArgs a)
             const int npair = (npix + 1) >> 1;
             // operands of pixel pair pr: z = dZ[co=l31][p], xv[t] = A[ci=l31][p + tap t]  (p = 2 pr + h).
             // Each wave walks p, p+8, p+16, ...: (yy,xx) advance incrementally (no division in the loop).
-            int pn = 2 * wave + h, yn = pn / a.Wo, xn = pn - yn * a.Wo; // NEXT pair to be loaded
+            // NEXT pair to be loaded: pixel pn = (row, xn), its dZ / A addresses walk along (no multiply in the loop)
+            int pn = 2 * wave + h, xn;
+            const float *pzn, *pan;
+            {
+                const int yn = pn / a.Wo;
+                xn = pn - yn * a.Wo;
+                pzn = ldsZ + l31 * planeZ + pn;
+                pan = ldsA + l31 * planeA + yn * a.Wi + xn;
+            }
             const int ylast = (npix - 1) / a.Wo, xlast = (npix - 1) - ylast * a.Wo;
-            auto ldnext = [&](float &z, float (&xv)[9], bool &valid) {
-                valid = pn < npix; // the odd tail pixel: read real data, zero dZ at USE time (no wait on the load here)
-                const int p = valid ? pn : npix - 1;
-                const int yy = valid ? yn : ylast, xx = valid ? xn : xlast;
-                z = ldsZ[l31 * planeZ + p];
-                const float *pa = ldsA + l31 * planeA + yy * a.Wi + xx;
-#pragma unroll
-                for (int t = 0; t < 9; ++t) xv[t] = pa[(t / 3) * a.Wi + (t % 3)];
-                pn += 8;
-                xn += 8;
-                if (xn >= a.Wo) { // Wo >= 8 is guaranteed by the launcher => at most one wrap
-                    xn -= a.Wo;
-                    ++yn;
-                }
+            const float *pzlast = ldsZ + l31 * planeZ + (npix - 1), *palast = ldsA + l31 * planeA + ylast * a.Wi + xlast;
+            // a pair's operands: per tap row one single + one PAIR of consecutive floats (what ds_read2_b32 delivers: as
+            // a 2-vector the pair keeps adjacent registers; as scalars hipcc shuffled one pair through v_mov after a wait)
+            typedef float f32x2w __attribute__((ext_vector_type(2)));
+            struct Ops {
+                float z, s[3];
+                f32x2w d[3];
             };
-            float z0, z1, x0[9], x1[9];
+            struct Nx { // where the next pair's operands live
+                const float *pz, *pa;
+            };
+            auto addr = [&](Nx &n, bool &valid) {
+                valid = pn < npix; // the odd tail pixel: read real data, zero dZ at USE time (no wait on the load here)
+                n.pz = valid ? pzn : pzlast;
+                n.pa = valid ? pan : palast;
+                pn += 8;
+                pzn += 8;
+                xn += 8;
+                const bool wrap = xn >= a.Wo; // Wo >= 8 is guaranteed by the launcher => at most one wrap
+                pan += wrap ? 8 + (a.Wi - a.Wo) : 8;
+                xn -= wrap ? a.Wo : 0;
+            };
+            auto rd1 = [&](const Nx &n, Ops &o) { // 4 LDS instructions
+                o.z = *n.pz;
+                o.s[0] = n.pa[0];
+                o.d[0] = f32x2w{n.pa[1], n.pa[2]};
+                o.s[1] = n.pa[a.Wi];
+            };
+            auto rd2 = [&](const Nx &n, Ops &o) { // 4 LDS instructions
+                o.d[1] = f32x2w{n.pa[a.Wi + 1], n.pa[a.Wi + 2]};
+                o.s[2] = n.pa[2 * a.Wi];
+                o.d[2] = f32x2w{n.pa[2 * a.Wi + 1], n.pa[2 * a.Wi + 2]};
+            };
+            auto mf = [&](const Ops &o, float z, int t) {
+                const float xv = t % 3 == 0 ? o.s[t / 3] : o.d[t / 3][t % 3 - 1];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(z, xv, acc[t], 0, 0, 0);
+            };
+#define AUGCL_SB() __builtin_amdgcn_sched_barrier(0)
+            // One pixel pair = 9 MFMAs; the NEXT pair's fetch (addresses, 4 + 4 LDS reads) is issued in three pieces after
+            // the 1st, 2nd and 3rd MFMA: the single wave that feeds this SIMD's MFMA pipe issues in order, and a ~30-
+            // instruction fetch block between two 9-MFMA groups left the pipe idle for ~150 of a pair's ~790 cycles
+            // (tools/ebench stamps; 576 are MFMA).  `fetch` is wave-uniform.  The s_waitcnt drains the in-order LDS counter
+            // where everything outstanding is >= 6 MFMAs old, so that hipcc adds no waits of its own inside the groups.
+            auto pairstep = [&](const Ops &cur, bool vcur, Ops &nxt, bool &vnxt, bool fetch) {
+                __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0)
+                const float z = vcur ? cur.z : 0.0f;
+                dbacc += z;
+                Nx n;
+                mf(cur, z, 0);
+                AUGCL_SB();
+                if (fetch) addr(n, vnxt);
+                AUGCL_SB();
+                if (ABL != 2) mf(cur, z, 1);
+                AUGCL_SB();
+                if (fetch) rd1(n, nxt);
+                AUGCL_SB();
+                if (ABL != 2) mf(cur, z, 2);
+                AUGCL_SB();
+                if (fetch) rd2(n, nxt);
+                AUGCL_SB();
+                if (ABL != 2) {
+#pragma unroll
+                    for (int t = 3; t < 9; ++t) mf(cur, z, t);
+                }
+                AUGCL_SB();
+            };
+            Ops o0, o1;
             bool v0 = true, v1 = true;
             int pr = wave;
-            if (pr < npair) ldnext(z0, x0, v0);
-            for (; pr < npair; pr += 8) { // two pairs per trip: the next pair's 10 LDS reads fly under 9 MFMAs
-                if (pr + 4 < npair) ldnext(z1, x1, v1);
-                __builtin_amdgcn_sched_barrier(0);
-                z0 = v0 ? z0 : 0.0f;
-                dbacc += z0;
-#pragma unroll
-                for (int t = 0; t < (ABL == 2 ? 1 : 9); ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(z0, x0[t], acc[t], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (pr + 8 < npair) ldnext(z0, x0, v0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (pr + 4 < npair) {
-                    z1 = v1 ? z1 : 0.0f;
-                    dbacc += z1;
-#pragma unroll
-                    for (int t = 0; t < (ABL == 2 ? 1 : 9); ++t)
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(z1, x1[t], acc[t], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
+            if (pr < npair) {
+                Nx n;
+                addr(n, v0);
+                rd1(n, o0);
+                rd2(n, o0);
             }
+            for (; pr + 8 < npair; pr += 8) { // steady state: two pairs per trip, both with a successor
+                pairstep(o0, v0, o1, v1, true);
+                pairstep(o1, v1, o0, v0, true);
+            }
+            if (pr < npair) { // one or two pairs left
+                const bool two = pr + 4 < npair;
+                pairstep(o0, v0, o1, v1, two);
+                if (two) pairstep(o1, v1, o0, v0, false);
+            }
+#undef AUGCL_SB
         }
         if (!SPLIT && next < a.n_items && ABL != 1) commit(next, (it + 1) & 1, pf);
+        if (ABL == 4 && !loader) stamp(4);
         __syncthreads();
+        if (ABL == 4 && !loader) stamp(5);
     }
+    if (ABL == 4 && !loader) stamp(6);
     // ---- fixed-order reduction over the 4 waves through LDS, then one slab per workgroup
     // lane (ci = l31, h) holds dW[co = acc_row(r,h)][ci][t] in acc[t][r]
     float *slab = a.partial + (size_t)blockIdx.x * WG_SLAB;
@@ -676,6 +747,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, 1) void k_wgrad32(WgradArgs a)
         const float other = __shfl_xor(dbacc, 32, 64);
         if (h == 0) slab[32 * 288 + l31] = dbacc + other;
     }
+    if (ABL == 4) stamp(7);
 }
 
 // first layer: dW1[co][c][t] = sum dZ[co][p] * X[c][st*y+ky][st*x+kx]/scale ; n = c*9+t over NT n-tiles of 32

@@ -113,6 +113,24 @@ __global__ __launch_bounds__(NW * 64, 1) void k_mfma_16x4(float *out, int iters,
     for (int t = 0; t < 4; ++t) for (int r = 0; r < 4; ++r) s += acc[t][r];
     out[blockIdx.x * NW * 64 + threadIdx.x] = s;
 }
+// 9 accumulator tiles (k_wgrad32's shape): RUN consecutive MFMAs on the same accumulator before moving to the next one
+template <int RUN>
+__global__ __launch_bounds__(256, 1) void k_mfma_9acc(float *out, int iters, float a0)
+{
+    f32x16 acc[9];
+    for (int t = 0; t < 9; ++t) for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float a[4], b[4];
+    for (int u = 0; u < 4; ++u) { a[u] = a0 + threadIdx.x * 1e-3f + u; b[u] = 1.0f + threadIdx.x * 1e-4f + u; }
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int u = 0; u < RUN; ++u) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[(u + t) & 3], acc[t], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int t = 0; t < 9; ++t) for (int r = 0; r < 16; ++r) s += acc[t][r];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
 // register-only f32 MFMA loop: the practical MFMA ceiling (clock under load) on this chip
 __global__ __launch_bounds__(256, 1) void k_mfma_peak(float *out, int iters, float a0)
 {
@@ -148,7 +166,7 @@ int main(int argc, char **argv)
     float *in, *out, *w, *bias, *mask, *ws, *dw, *db;
     CK(hipMalloc(&in, nout * 4)); CK(hipMalloc(&out, nout * 4)); CK(hipMalloc(&mask, nout * 4));
     CK(hipMalloc(&w, 9216 * 4)); CK(hipMalloc(&bias, 128)); CK(hipMalloc(&dw, 9216 * 4)); CK(hipMalloc(&db, 128));
-    const size_t wsb = augcl_enc_wgrad_workspace_bytes(32); CK(hipMalloc(&ws, wsb));
+    const size_t wsb = augcl_enc_wgrad_workspace_bytes(32); CK(hipMalloc(&ws, wsb + 8192)); // + room for the ABL = 4 stamps
     std::vector<float> h(nout); for (size_t i = 0; i < nout; ++i) h[i] = (float)((i * 2654435761u >> 9) & 1023) / 512.f - 0.7f;
     CK(hipMemcpy(in, h.data(), nout * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(mask, h.data(), nout * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(w, h.data(), 9216 * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(bias, h.data(), 128, hipMemcpyHostToDevice));
@@ -178,7 +196,33 @@ int main(int argc, char **argv)
     vs.push_back({"mfma 1 chain, 2 waves/SIMD", 2.0 * 32 * 32 * 2 * 9 * 4000.0 * 8 * 256, [&] { hipLaunchKernelGGL(k_mfma_chain1x2, dim3(256), dim3(512), 0, 0, out, 4000, 0.5f); }});
     vs.push_back({"mfma 16x16x4 + LDS, 4 waves", 2.0 * 16 * 16 * 4 * 36 * 1000.0 * 4 * 256, [&] { hipLaunchKernelGGL(k_mfma_16x4<4>, dim3(256), dim3(256), 0, 0, out, 1000, 0.5f); }});
     vs.push_back({"mfma 16x16x4 + LDS, 8 waves", 2.0 * 16 * 16 * 4 * 36 * 1000.0 * 8 * 256, [&] { hipLaunchKernelGGL(k_mfma_16x4<8>, dim3(256), dim3(512), 0, 0, out, 1000, 0.5f); }});
+    vs.push_back({"mfma 9 accs round-robin", 2.0 * 32 * 32 * 2 * 9 * 4000.0 * 4 * 256, [&] { hipLaunchKernelGGL(k_mfma_9acc<1>, dim3(256), dim3(256), 0, 0, out, 4000, 0.5f); }});
+    vs.push_back({"mfma 9 accs, runs of 2", 2.0 * 32 * 32 * 2 * 18 * 2000.0 * 4 * 256, [&] { hipLaunchKernelGGL(k_mfma_9acc<2>, dim3(256), dim3(256), 0, 0, out, 2000, 0.5f); }});
+    vs.push_back({"mfma 9 accs, runs of 4", 2.0 * 32 * 32 * 2 * 36 * 1000.0 * 4 * 256, [&] { hipLaunchKernelGGL(k_mfma_9acc<4>, dim3(256), dim3(256), 0, 0, out, 1000, 0.5f); }});
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    if (argc > 3 && atoi(argv[3]) == -3) { // per-strip shader-clock stamps of k_wgrad32<4, false, true>, workgroup 0 / wave 0
+        WgradArgs a{}; a.act = in; a.dz = out; a.partial = ws; a.B = B; a.Hi = H; a.Wi = H; a.Ho = H - 2; a.Wo = H - 2;
+        int rt = (kBufLds / 4 - 64 * H - 64) / (32 * H + 32 * a.Wo); rt = std::min(rt, std::min(512 / H - 2, 256 / a.Wo)); if (rt > a.Ho) rt = a.Ho;
+        a.S = (a.Ho + rt - 1) / rt; a.RT = (a.Ho + a.S - 1) / a.S; a.n_items = B * a.S;
+        const int planeA = ((a.RT + 2) * H) | 1, planeZ = (a.RT * a.Wo) | 1; size_t lds = 2 * (size_t)(32 * planeA + 32 * planeZ) * 4;
+        const int grid = grid_for(a.n_items, 1);
+        set_lds(k_wgrad32<4, false, true>, lds, "x");
+        unsigned long long *dbg = reinterpret_cast<unsigned long long *>(ws + (size_t)grid * WG_SLAB + 8 * WG_SLAB);
+        if ((size_t)(grid + 8) * WG_SLAB * 4 + 500 * 8 > wsb + 8192) { printf("workspace too small for stamps\n"); return 1; }
+        CK(hipMemset(dbg, 0, 500 * 8));
+        for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL((k_wgrad32<4, false, true>), dim3(grid), dim3(512), lds, 0, a);
+        CK(hipDeviceSynchronize());
+        printf("RT=%d S=%d npix=%d pairs/wave=%.1f items/WG=%.1f\n", a.RT, a.S, a.RT * a.Wo, a.RT * a.Wo / 8.0, (double)a.n_items / grid);
+        std::vector<unsigned long long> hd(500); CK(hipMemcpy(hd.data(), dbg, 500 * 8, hipMemcpyDeviceToHost));
+        unsigned long long prev = 0;
+        for (int i = 0; i < 500 && hd[i]; ++i) {
+            const unsigned long long t = hd[i] >> 4; const int id = (int)(hd[i] & 15);
+            printf("%d:%llu ", id, prev ? t - prev : 0ull); prev = t;
+            if (id == 5) printf("\n");
+        }
+        printf("\n");
+        return 0;
+    }
     if (argc > 3 && atoi(argv[3]) < 0) { // per-tile shader-clock stamps of workgroup 0's first compute wave (k_conv32<MODE, 4>)
         unsigned long long *dbg; CK(hipMalloc(&dbg, 2000 * 8)); CK(hipMemset(dbg, 0, 2000 * 8));
         const int mode = -atoi(argv[3]) - 1; // -1: forward, -2: backward-data
