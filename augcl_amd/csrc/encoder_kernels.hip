@@ -55,6 +55,7 @@ struct ConvArgs {
     // even workgroups serve the first half, odd ones the second, so a workgroup still holds ONE weight set
     const float *w2, *bias2;
     int dual;
+    uint32_t magic_wi; // floor(2^32 / Wi) + 1 (MODE 1: row of a run element)
 };
 
 // ---- global -> LDS staging of contiguous runs ------------------------------------------------------
@@ -118,10 +119,10 @@ __device__ __forceinline__ int round4(int v) { return (v + 3) & ~3; }
 // LDS image while the compute waves run the current one.  One workgroup per CU, one barrier per item.
 // (Two independent 256-thread workgroups per CU ran in lockstep -- same program, same start -- so their
 // staging and MFMA phases never overlapped: ablation showed t = t_mfma + t_rest, not max.)
-// LDS image per buffer: [guard G][32 planes of `plane` words][guard G]; a plane mirrors the channel's
-// memory rows (row stride Wi).  MODE 1 (backward-data) keeps NO padding in LDS: taps that fall outside dZ
-// are zeroed with a per-lane select in front of the MFMA, the guards only keep those discarded reads
-// inside the allocation.
+// LDS image per buffer: 32 planes of `plane` words.  Forward: a plane mirrors the channel's memory rows (row stride Wi).
+// Backward-data: rows are 2 words further apart and those 2 words are zero (right pad of one row = left pad of the next),
+// dZ rows outside the image are zero rows: the full correlation reads its padding from the tile, nothing is masked in
+// front of the MFMAs (per-lane selects there cost 92.6 instead of 70.5 cycles per MFMA -- see the loop below).
 template <int MODE, int ABL = 0> // ABL: developer ablation switch (tools/ebench), 0 = product
 __global__ __launch_bounds__(512, 2) void k_conv32(ConvArgs a)
 {
@@ -133,9 +134,11 @@ __global__ __launch_bounds__(512, 2) void k_conv32(ConvArgs a)
     const int cw = wave & 3; // index inside the role
     const int l31 = lane & 31, h = lane >> 5;
     const int Wi = a.Wi;
-    const int plane = round4((a.RT + 2) * Wi);
-    const int G = MODE ? round4(2 * Wi + 4) : 0;
-    const int bufw = 2 * G + 32 * plane; // words per buffer
+    // LDS row pitch.  MODE 1 keeps 2 zero words between consecutive dZ rows (the right pad of one row = the left pad of the
+    // next) and zero rows outside the image: every tap of every output pixel reads a real word or a zero, nothing is masked.
+    const int pitch = MODE ? Wi + 2 : Wi;
+    const int plane = round4((a.RT + 2) * pitch + (MODE ? 2 : 0));
+    const int bufw = 32 * plane; // words per buffer
     constexpr int WROW = 292;            // weight staging row pitch (16-byte aligned rows, conflict-free reads)
     float *lbias = lds_raw + max(2 * bufw, bufw + 32 * WROW);
 
@@ -183,7 +186,7 @@ __global__ __launch_bounds__(512, 2) void k_conv32(ConvArgs a)
 
     // stage item `it` into buffer `bi` (loader waves only): wave cw copies channels 8cw .. 8cw+7, four
     // channel pairs back to back => 24 dwordx4 per lane in flight, one exposed latency per item
-    auto stage = [&](int item, int bi) {
+    auto stage = [&](int item, int bi, bool first_use) {
         const int b = item / a.S, s = item - b * a.S;
         const int y0 = s * a.RT;
         const int rows = min(a.RT, a.Ho - y0);
@@ -192,13 +195,57 @@ __global__ __launch_bounds__(512, 2) void k_conv32(ConvArgs a)
         const int run = (r1 - r0) * Wi;
         const float *src = a.in + ((size_t)b * 32 * a.Hi + r0) * Wi;
         const size_t cs = (size_t)a.Hi * Wi;
-        float *dst = lds_raw + bi * bufw + G;
+        float *dst = lds_raw + bi * bufw;
+        if (MODE == 0) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int ci = 8 * cw + 2 * k;
-            wave_copy_runs2<3>(src + ci * cs, src + (ci + 1) * cs, dst + ci * plane, dst + (ci + 1) * plane, run, lane,
-                               XfId());
+            for (int k = 0; k < 4; ++k) {
+                const int ci = 8 * cw + 2 * k;
+                wave_copy_runs2<3>(src + ci * cs, src + (ci + 1) * cs, dst + ci * plane, dst + (ci + 1) * plane, run, lane,
+                                   XfId());
+            }
+            return;
         }
+        // MODE 1: tile row j = dZ row (y0 - 2 + j) at words [j * pitch + 2, j * pitch + 2 + Wi) of its channel plane
+        const int top = r0 - (y0 - P), nrow = r1 - r0, tile_rows = rows + 2; // rows above / inside / (below) the image
+        float *d8 = dst + 8 * cw * plane;
+        if (first_use) { // the 2 pad words in front of every row and behind the last: written once per buffer
+            for (int i = lane; i < 8 * (a.RT + 3) * 2; i += 64) {
+                const int c = i / ((a.RT + 3) * 2), r = i - c * (a.RT + 3) * 2;
+                d8[c * plane + (r >> 1) * pitch + (r & 1)] = 0.0f;
+            }
+        }
+        const int bot = tile_rows - top - nrow;
+        if (top + bot > 0) { // first / last strip of an image: dZ rows outside it are zero
+            for (int i = lane; i < 8 * (top + bot) * Wi; i += 64) {
+                const int c = i / ((top + bot) * Wi), rem = i - c * (top + bot) * Wi;
+                const int jr = rem / Wi, x = rem - jr * Wi;
+                const int j = jr < top ? jr : top + nrow + (jr - top);
+                d8[c * plane + j * pitch + 2 + x] = 0.0f;
+            }
+        }
+        // row by row, lanes along x: 4 channels x 8 rows = 32 dwords per lane in flight, then 32 conflict-free ds_write_b32 at
+        // row base + immediate -- no per-element address arithmetic (a chunked copy of the contiguous run needs a division
+        // per element to find its row, and made the loaders the slower half of the pipeline)
+        for (int x0 = 0; x0 < Wi; x0 += 64) {
+            const int x = min(x0 + lane, Wi - 1); // lanes past the row end repeat its last word
+#pragma unroll
+            for (int hc = 0; hc < 2; ++hc) {
+                const float *s4 = src + (size_t)(8 * cw + 4 * hc) * cs + x;
+                float *d4 = d8 + 4 * hc * plane + top * pitch + 2 + x;
+                for (int rb = 0; rb < nrow; rb += 8) {
+                    float v[4][8];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) v[c][r] = s4[c * cs + (size_t)min(rb + r, nrow - 1) * Wi];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) d4[c * plane + min(rb + r, nrow - 1) * pitch] = v[c][r];
+                }
+            }
+        }
+        (void)run;
     };
 
     int it = 0;
@@ -218,19 +265,18 @@ __global__ __launch_bounds__(512, 2) void k_conv32(ConvArgs a)
             ++ndbg;
         }
     };
-    if (loader && first < n_end && ABL != 1) stage(first, 0);
+    if (loader && first < n_end && ABL != 1) stage(first, 0, true);
     __syncthreads();
     for (int item = first; item < n_end; item += NG, ++it) {
         const int next = item + NG;
         if (loader) {
-            if (next < n_end && ABL != 1) stage(next, (it + 1) & 1);
+            if (next < n_end && ABL != 1) stage(next, (it + 1) & 1, it == 0);
         } else {
             const int b = item / a.S, s = item - b * a.S;
             const int y0 = s * a.RT;
             const int rows = min(a.RT, a.Ho - y0); // output rows of this strip
             const int npix = rows * a.Wo;
-            const int r0 = MODE ? max(0, y0 - P) : y0;
-            const float *lds = lds_raw + (it & 1) * bufw + G;
+            const float *lds = lds_raw + (it & 1) * bufw;
             // ---- M-tiles of 32 consecutive strip pixels, round-robin over the 4 compute waves
             const int ntiles = (npix + 31) >> 5;
             for (int tile = cw; tile < ntiles; tile += 4) {
@@ -239,14 +285,9 @@ __global__ __launch_bounds__(512, 2) void k_conv32(ConvArgs a)
                 const bool valid = m < npix;
                 if (!valid) m = npix - 1; // read a real pixel, discard the result
                 const int yy = m / a.Wo, xx = m - yy * a.Wo;
-                // top-left tap of this pixel inside the staged rows (may lie in the guard for MODE 1)
-                const float *base = lds + ((y0 + yy - P - r0) * Wi + (xx - P)) + h * 16 * plane;
-                bool rowok[3], colok[3];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    rowok[k] = MODE == 0 || ((unsigned)(y0 + yy + k - P) < (unsigned)a.Hi);
-                    colok[k] = MODE == 0 || ((unsigned)(xx + k - P) < (unsigned)Wi);
-                }
+                // top-left tap of this pixel in the tile: forward -- tile row yy, column xx; backward-data -- dZ row
+                // y0 + yy - 2 = tile row yy, padded column xx (the tile's own zero pads stand in for everything outside dZ)
+                const float *base = lds + yy * pitch + xx + h * 16 * plane;
                 // backward-data: the ReLU gate of the layer below is (a_prev > 0) at this lane's 16 outputs -- the same
                 // addresses it will store to.  Issued NOW, consumed after the 144 MFMAs: the latency is free.
                 const int chw = a.Ho * a.Wo; // 32-bit offsets: the host checks B*32*Ho*Wo < 2^30
@@ -273,35 +314,25 @@ __global__ __launch_bounds__(512, 2) void k_conv32(ConvArgs a)
                 float xa[9], xb[9];
                 constexpr int NC = (ABL == 2 ? 2 : 16);
 #pragma unroll
-                for (int t = 0; t < 9; ++t) xa[t] = base[(t / 3) * Wi + (t % 3)];
+                for (int t = 0; t < 9; ++t) xa[t] = base[(t / 3) * pitch + (t % 3)];
 #pragma unroll
                 for (int cil = 0; cil < NC; cil += 2) {
                     const float *p1 = base + (cil + 1) * plane;
 #pragma unroll
-                    for (int t = 0; t < 9; ++t) xb[t] = p1[(t / 3) * Wi + (t % 3)];
+                    for (int t = 0; t < 9; ++t) xb[t] = p1[(t / 3) * pitch + (t % 3)];
                     __builtin_amdgcn_sched_barrier(0); // keep the 9 reads AHEAD of the MFMA group (hipcc sinks them)
-                    // backward-data: out-of-image taps are zeroed IN PLACE for the whole group before its MFMAs.  (Selected
-                    // one by one into a temporary between the MFMAs, the select's write waited for the in-flight MFMA that
-                    // still named that temporary as its operand: 92.6 instead of 70.5 cycles per MFMA, tools/ebench stamps.)
-                    if (MODE == 1) {
-#pragma unroll
-                        for (int t = 0; t < 9; ++t) xa[t] = (rowok[t / 3] && colok[t % 3]) ? xa[t] : 0.0f;
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
+                    // (backward-data used to select out-of-image taps to zero per MFMA into one temporary: the select's write
+                    // waited for the in-flight MFMA that still named that temporary as its operand -- 92.6 instead of 70.5
+                    // cycles per MFMA, tools/ebench stamps; with the zero-padded tile there is nothing to select)
 #pragma unroll
                     for (int t = 0; t < 9; ++t)
                         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[cil * 9 + t], xa[t], (cil == 0 && t == 0) ? bias16 : acc, 0, 0, 0);
                     if (cil + 2 < NC) {
                         const float *p2 = base + (cil + 2) * plane;
 #pragma unroll
-                        for (int t = 0; t < 9; ++t) xa[t] = p2[(t / 3) * Wi + (t % 3)];
+                        for (int t = 0; t < 9; ++t) xa[t] = p2[(t / 3) * pitch + (t % 3)];
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    if (MODE == 1) {
-#pragma unroll
-                        for (int t = 0; t < 9; ++t) xb[t] = (rowok[t / 3] && colok[t % 3]) ? xb[t] : 0.0f;
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
 #pragma unroll
                     for (int t = 0; t < 9; ++t)
                         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[(cil + 1) * 9 + t], xb[t], acc, 0, 0, 0);
@@ -1196,14 +1227,15 @@ int augcl_enc_conv32_backward_data(const float *dz, const float *w, const float 
     ConvArgs a{};
     a.in = dz; a.w = w; a.bias = nullptr; a.mask = act_prev; a.out = dact;
     a.B = B; a.Hi = Ho; a.Wi = Wo; a.Ho = Ho + 2; a.Wo = Wo + 2; a.relu = 0;
-    const int G = (2 * Wo + 4 + 3) & ~3;
     AUGCL_REQUIRE(aligned16(w), "%s: weights must be 16-byte aligned", name);
     // (strip heights: the even split of pick_rt measured better over the 10 layer sizes than minimising the number of
     // 4-wave tile rounds per image -- fewer, larger strips starve the loader/compute pipeline)
-    a.RT = pick_rt(a.Ho, 32 * Wo, 2, kBufLds - 8 * G - 64, &a.S, augcl::extra_strips(1, Wo));
+    // the dZ tile is kept zero-padded in LDS: row pitch Wo + 2, + 2 words behind the last row
+    a.RT = pick_rt(a.Ho, 32 * (Wo + 2), 2, kBufLds - 32 * 8, &a.S, augcl::extra_strips(1, Wo));
     AUGCL_REQUIRE(a.RT > 0, "%s: image row too wide for LDS (W=%d)", name, Wo);
     a.n_items = B * a.S;
-    const size_t bufw = (size_t)32 * (((a.RT + 2) * Wo + 3) & ~3) + 2 * G;
+    a.magic_wi = (uint32_t)(0x100000000ull / (unsigned)Wo) + 1u;
+    const size_t bufw = (size_t)32 * (((a.RT + 2) * (Wo + 2) + 2 + 3) & ~3);
     const size_t lds = (std::max(2 * bufw, bufw + 32 * 292) + 32) * 4;
     if (int rc = set_lds(k_conv32<1>, lds, name)) return rc;
     hipLaunchKernelGGL(k_conv32<1>, dim3(grid_for(a.n_items, 1)), dim3(512), lds, as_stream(stream), a);

@@ -23,7 +23,7 @@ st = torch.cuda.current_stream().cuda_stream
 w = torch.randn(32, 32, 3, 3, device=dev) * 0.05
 bias = torch.zeros(32, device=dev)
 p = lambda t: ctypes.c_void_p(t.data_ptr())
-kinds = ['f32 fwd', 'f32 bwd', 'bf16 fwd', 'bf16 bwd']
+kinds = ["f32 fwd", "f32 bwd"]
 print("B=%d   columns: extra strips 0..4 (us), best" % B)
 for H in range(41, 21, -2):
     x = torch.rand(B, 32, H, H, device=dev) - 0.3
