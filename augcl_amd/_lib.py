@@ -159,8 +159,20 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
+_raw_stream = None
+
+
 def current_stream(device=None):
+    """Raw handle (hipStream_t as an integer) of torch's current stream on `device`: what every entry point takes.
+    torch._C._cuda_getCurrentRawStream when it exists (no Stream object per call: this sits on the launch path of every
+    kernel, and the bf16 mode is host-bound when it runs without hipGraphs)."""
+    global _raw_stream
     import torch
+    if _raw_stream is None:
+        _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", False)
+    if _raw_stream:
+        idx = device.index if (device is not None and hasattr(device, "index") and device.index is not None) else torch.cuda.current_device()
+        return _raw_stream(idx)
     return torch.cuda.current_stream(device).cuda_stream
 
 

@@ -91,34 +91,39 @@ class FlatGroup:
         names = g.names if names is None else names
         if all(t is None for t in grads):
             return list(names)  # nothing to copy; the caller skips these tensors (no zero-fill launches either)
+        base = g.grad.data_ptr()
+        on_gpu = g.grad.is_cuda
         for n, t in zip(names, grads):
             a, b = g.slices[n]
             if t is None:
                 missing.append(n)
                 g.grad[a:b].zero_()  # keeps the data-parallel all-reduce of the whole bucket well defined
                 continue
-            if t.data_ptr() == g.grad[a:b].data_ptr():
+            p = t.data_ptr()
+            if p == base + 4 * a:
                 continue  # already in the bucket
-            dsts.append((a, b))
-            srcs.append(t)
+            if on_gpu and (not t.is_cuda or t.dtype != torch.float32):
+                on_gpu = False
+            elif not t.is_contiguous():
+                t = t.contiguous()
+                p = t.data_ptr()
+            dsts.append((a, b, p))
+            srcs.append(t)  # (also keeps a .contiguous() copy alive until the launch is queued)
         if not srcs:
             return missing
-        if g.grad.is_cuda and all(t.is_cuda and t.dtype == torch.float32 for t in srcs):
-            srcs = [t if t.is_contiguous() else t.contiguous() for t in srcs]
+        if on_gpu:
             k = len(srcs)
-            ptrs = (ctypes.c_void_p * k)(*[t.data_ptr() for t in srcs])
-            offs = (ctypes.c_int64 * k)(*[a for a, _ in dsts])
-            lens = (ctypes.c_int64 * k)(*[b - a for a, b in dsts])
-            assert all(t.numel() == b - a for t, (a, b) in zip(srcs, dsts))
+            ptrs = (ctypes.c_void_p * k)(*[p for _, _, p in dsts])
+            offs = (ctypes.c_int64 * k)(*[a for a, _, _ in dsts])
+            lens = (ctypes.c_int64 * k)(*[b - a for a, b, _ in dsts])
             prep = step_prep if (step_prep is not None and not missing) else None
-            _lib.call("augcl_gather_f32", ctypes.cast(ptrs, ctypes.c_void_p), ctypes.cast(offs, ctypes.c_void_p),
-                      ctypes.cast(lens, ctypes.c_void_p), k, g.grad.data_ptr(), None if prep is None else prep[0],
-                      0.0 if prep is None else prep[1], 0.0 if prep is None else prep[2], 0.0 if prep is None else prep[3],
-                      _lib.current_stream(g.grad.device))
+            _lib.call("augcl_gather_f32", ctypes.addressof(ptrs), ctypes.addressof(offs), ctypes.addressof(lens), k, base,
+                      None if prep is None else prep[0], 0.0 if prep is None else prep[1], 0.0 if prep is None else prep[2],
+                      0.0 if prep is None else prep[3], _lib.current_stream(g.grad.device))
             if prep is not None:
                 g.prepped = True
         else:
-            torch._foreach_copy_([g.grad[a:b].view(t.shape) for (a, b), t in zip(dsts, srcs)], srcs)
+            torch._foreach_copy_([g.grad[a:b].view(t.shape) for (a, b, _), t in zip(dsts, srcs)], srcs)
         return missing
 
     def segment(self, prefix):

@@ -286,6 +286,32 @@ def _mask_colsum(dz, a, want_db, extra=None):
     return (sums[:N] if want_db else None), (sums[N:] if E else None)
 
 
+_twin_cache = {}
+
+
+def _twin_views(*ps):
+    """The six stacked (2, ...) tensors of a twin's 12 parameters.  When all of them are VIEWS of one flat buffer (the
+    agents' layout) they are built once per parameter storage and reused: building them is ~30 us of host time per call, and
+    the bf16 mode without hipGraphs is host-bound.  (Copies -- parameters that are not neighbours in one storage -- are
+    rebuilt every call: they go stale with the next optimiser step.)"""
+    key = tuple(p.data_ptr() for p in ps)
+    hit = _twin_cache.get(key)
+    if hit is not None:
+        return hit
+    a, b = ps[:6], ps[6:]
+    out = [_stacked(p, q) for p, q in zip(a, b)]
+    views = all(t.data_ptr() == p.data_ptr() for t, p in zip(out, a))
+    if not (out[0].is_contiguous() and out[1].is_contiguous()):  # padding between the twins' tensors: stacked copies
+        out[0], out[1] = out[0].contiguous(), out[1].contiguous()
+        views = False
+    out = tuple(out)
+    if views:
+        if len(_twin_cache) >= 16:
+            _twin_cache.clear()
+        _twin_cache[key] = out
+    return out
+
+
 class _TwinQ(torch.autograd.Function):
     """Q1(h, a), Q2(h, a) of src/algorithms/modules.py:247-276 -- two identical 3-layer MLPs over the same input -- as ONE
     batched network.  Forward, 4 launches: concat, ONE GEMM for both first layers with bias + ReLU in its epilogue
@@ -300,9 +326,7 @@ class _TwinQ(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         B, H = h.shape[0], w1a.shape[0]
         x = h if a is None else torch.cat([h, a], dim=1)  # a = None: h already is [features | action]
-        W1, b1, W2, b2, W3, b3 = (_stacked(p, q) for p, q in ((w1a, w1b), (b1a, b1b), (w2a, w2b), (b2a, b2b), (w3a, w3b), (b3a, b3b)))
-        if not (W1.is_contiguous() and b1.is_contiguous()):  # padding between the twins' tensors: stacked copies
-            W1, b1 = W1.contiguous(), b1.contiguous()
+        W1, b1, W2, b2, W3, b3 = _twin_views(w1a, b1a, w2a, b2a, w3a, b3a, w1b, b1b, w2b, b2b, w3b, b3b)
         # bias + ReLU in the GEMM's epilogue (one launch): torch._addmm_activation(bias, x, W^T) = relu(x W^T + bias)
         a1 = torch._addmm_activation(b1.reshape(2 * H), x, W1.reshape(2 * H, -1).t())  # (B, 2H) = [Q1 | Q2]
         z2 = torch.bmm(a1.view(B, 2, H).transpose(0, 1), W2.transpose(1, 2))            # (2, B, H), no bias yet
