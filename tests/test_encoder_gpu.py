@@ -172,3 +172,45 @@ def test_dual_stack_forward_equals_two_passes(cuda, B, precision):
     with torch.no_grad():
         assert encoder_ops.conv_stack_dual(torch.rand(2, 3, 40, 40, device=cuda), [w[:, :3].contiguous() if i == 0 else w for i, w in enumerate(wa)], ba,
                                            [w[:, :3].contiguous() if i == 0 else w for i, w in enumerate(wb)], bb) is None
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 12, 70), (3, 70, 12), (1, 10, 100), (2, 33, 35), (5, 11, 11), (1, 3, 9)])
+def test_conv32_layer_entry_points_on_odd_shapes(cuda, B, H, W):
+    """The three 32 -> 32 layer kernels through the C ABI on shapes the square training stack never produces: wide rows
+    (more than one 64-lane chunk per row in the backward-data loader), tall thin images, single-strip images, the smallest
+    legal size -- against float64 ATen convolutions.  H x W is the layer's INPUT size."""
+    import ctypes
+    import torch.nn.functional as F
+    from augcl_amd import _lib
+    L = _lib.load()
+    g = torch.Generator(device=cuda).manual_seed(B * 1000 + H * 10 + W)
+    x = torch.relu(torch.randn(B, 32, H, W, device=cuda, generator=g))
+    w = torch.randn(32, 32, 3, 3, device=cuda, generator=g) * 0.06
+    bias = torch.randn(32, device=cuda, generator=g) * 0.1
+    dz = torch.randn(B, 32, H - 2, W - 2, device=cuda, generator=g)
+    st = _lib.current_stream(cuda)
+    p = lambda t: t.data_ptr()  # noqa: E731
+    # forward (+ ReLU)
+    y = torch.full((B, 32, H - 2, W - 2), float("nan"), device=cuda)
+    _lib.call("augcl_enc_conv32_forward", p(x), p(w), p(bias), p(y), B, H, W, 1, st)
+    want = torch.relu(F.conv2d(x.double(), w.double(), bias.double()))
+    assert float((y.double() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    # backward-data, gated by the layer input's ReLU
+    dx = torch.full((B, 32, H, W), float("nan"), device=cuda)
+    _lib.call("augcl_enc_conv32_backward_data", p(dz), p(w), p(x), p(dx), B, H - 2, W - 2, st)
+    want = F.conv_transpose2d(dz.double(), w.double()) * (x > 0)
+    assert float((dx.double() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    # ... and without a gate
+    _lib.call("augcl_enc_conv32_backward_data", p(dz), p(w), None, p(dx), B, H - 2, W - 2, st)
+    assert float((dx.double() - F.conv_transpose2d(dz.double(), w.double())).abs().max()) <= 2e-5 * float(want.abs().max() + 1)
+    # backward-weights
+    if W - 2 >= 8:  # the kernel's documented width range (10 <= W <= 170)
+        ws = torch.empty(L.augcl_enc_wgrad_workspace_bytes(32) // 4, device=cuda)
+        dw, db = torch.full((32, 32, 3, 3), float("nan"), device=cuda), torch.full((32,), float("nan"), device=cuda)
+        _lib.call("augcl_enc_conv32_backward_weights", p(x), p(dz), p(dw), p(db), p(ws), ws.numel() * 4, B, H, W, st)
+        xd = x.double().requires_grad_(False)
+        wd = w.double().clone().requires_grad_(True)
+        F.conv2d(xd, wd).backward(dz.double())
+        assert float((dw.double() - wd.grad).abs().max()) <= 3e-5 * float(wd.grad.abs().max())
+        assert float((db.double() - dz.double().sum((0, 2, 3))).abs().max()) <= 3e-5 * float(dz.double().sum((0, 2, 3)).abs().max() + 1)
+
