@@ -508,8 +508,28 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, 1) void k_wgrad32(WgradArgs a)
     const int lw = wave_all & 3;                                   // loader index
     const int l31 = lane & 31, h = lane >> 5;
     const int planeA = ((a.RT + 2) * a.Wi) | 1;
-    const int planeZ = (a.RT * a.Wo) | 1;
+    const int planeZ = (a.RT * a.Wo + 1) | 1; // word RT*Wo of every dZ plane is never written by data: it stays ZERO
     const int bufw = 32 * planeA + 32 * planeZ;
+    // Pair table behind the two tile buffers: for pixel pair pr and lane half hh, the byte offsets of pixel p = 2 pr + hh in a
+    // dZ plane and of its top-left tap in an A plane -- for a full strip and for the image's last (shorter) strip.  A pixel
+    // past the strip points at the zero word / at tap 0, so the MFMA loop needs no bounds logic and no select: every vector
+    // instruction a wave issues between its MFMAs costs MFMA time (tools/ebench k_wg_pair: the ~12-instruction address walk
+    // alone took the loop from 576 to 650 cycles per pair; the LDS reads themselves are free).
+    const int ntab = 2 * (((a.RT * a.Wo + 1) >> 1) + 8); // entries per table (8 pairs of padding: the loop reads ahead)
+    int2 *tab = reinterpret_cast<int2 *>(lds + 2 * bufw);
+    {
+        const int rows_last = a.Ho - (a.S - 1) * a.RT;
+        for (int i = tid; i < 2 * ntab; i += (SPLIT ? 512 : 256)) {
+            const int set = i >= ntab, e = i - set * ntab;
+            const int npix_s = (set ? rows_last : a.RT) * a.Wo;
+            const int p = e; // = 2 pr + hh
+            const bool valid = p < npix_s;
+            const int pc = valid ? p : 0;
+            const int yy = pc / a.Wo, xx = pc - yy * a.Wo;
+            tab[i] = make_int2((valid ? p : a.RT * a.Wo) * 4, (yy * a.Wi + xx) * 4);
+        }
+        if (tid < 64) lds[(tid >> 5) * bufw + 32 * planeA + (tid & 31) * planeZ + a.RT * a.Wo] = 0.0f; // the zero words
+    }
 
     f32x16 acc[9];
 #pragma unroll
@@ -651,102 +671,76 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, 1) void k_wgrad32(WgradArgs a)
             const int npix = rows * a.Wo;
             const float *ldsA = lds + (it & 1) * bufw, *ldsZ = ldsA + 32 * planeA;
             const int npair = (npix + 1) >> 1;
-            // operands of pixel pair pr: z = dZ[co=l31][p], xv[t] = A[ci=l31][p + tap t]  (p = 2 pr + h).
-            // Each wave walks p, p+8, p+16, ...: (yy,xx) advance incrementally (no division in the loop).
-            // NEXT pair to be loaded: pixel pn = (row, xn), its dZ / A addresses walk along (no multiply in the loop)
-            int pn = 2 * wave + h, xn;
-            const float *pzn, *pan;
-            {
-                const int yn = pn / a.Wo;
-                xn = pn - yn * a.Wo;
-                pzn = ldsZ + l31 * planeZ + pn;
-                pan = ldsA + l31 * planeA + yn * a.Wi + xn;
-            }
-            const int ylast = (npix - 1) / a.Wo, xlast = (npix - 1) - ylast * a.Wo;
-            const float *pzlast = ldsZ + l31 * planeZ + (npix - 1), *palast = ldsA + l31 * planeA + ylast * a.Wi + xlast;
-            // a pair's operands: per tap row one single + one PAIR of consecutive floats (what ds_read2_b32 delivers: as
-            // a 2-vector the pair keeps adjacent registers; as scalars hipcc shuffled one pair through v_mov after a wait)
+            // operands of pixel pair pr: z = dZ[co=l31][p], taps A[ci=l31][p + tap]  (p = 2 pr + h); this wave takes pairs
+            // wave, wave + 4, ...  Per tap row one single + one PAIR of consecutive floats (what ds_read2_b32 delivers: as a
+            // 2-vector the pair keeps adjacent registers; as scalars hipcc shuffled one pair through v_mov after a wait).
             typedef float f32x2w __attribute__((ext_vector_type(2)));
             struct Ops {
                 float z, s[3];
                 f32x2w d[3];
             };
-            struct Nx { // where the next pair's operands live
-                const float *pz, *pa;
+            const char *zc = reinterpret_cast<const char *>(ldsZ + l31 * planeZ);  // this lane's dZ plane
+            const char *ac = reinterpret_cast<const char *>(ldsA + l31 * planeA);  // this lane's A plane
+            const int2 *tp = tab + (rows == a.RT ? 0 : ntab) + 2 * wave + h;      // table entry of this lane's current pair
+            auto rd1 = [&](const float *pa, const float *pz, Ops &o) { // 4 LDS instructions
+                o.z = *pz;
+                o.s[0] = pa[0];
+                o.d[0] = f32x2w{pa[1], pa[2]};
+                o.s[1] = pa[a.Wi];
             };
-            auto addr = [&](Nx &n, bool &valid) {
-                valid = pn < npix; // the odd tail pixel: read real data, zero dZ at USE time (no wait on the load here)
-                n.pz = valid ? pzn : pzlast;
-                n.pa = valid ? pan : palast;
-                pn += 8;
-                pzn += 8;
-                xn += 8;
-                const bool wrap = xn >= a.Wo; // Wo >= 8 is guaranteed by the launcher => at most one wrap
-                pan += wrap ? 8 + (a.Wi - a.Wo) : 8;
-                xn -= wrap ? a.Wo : 0;
+            auto rd2 = [&](const float *pa, Ops &o) { // 4 LDS instructions
+                o.d[1] = f32x2w{pa[a.Wi + 1], pa[a.Wi + 2]};
+                o.s[2] = pa[2 * a.Wi];
+                o.d[2] = f32x2w{pa[2 * a.Wi + 1], pa[2 * a.Wi + 2]};
             };
-            auto rd1 = [&](const Nx &n, Ops &o) { // 4 LDS instructions
-                o.z = *n.pz;
-                o.s[0] = n.pa[0];
-                o.d[0] = f32x2w{n.pa[1], n.pa[2]};
-                o.s[1] = n.pa[a.Wi];
-            };
-            auto rd2 = [&](const Nx &n, Ops &o) { // 4 LDS instructions
-                o.d[1] = f32x2w{n.pa[a.Wi + 1], n.pa[a.Wi + 2]};
-                o.s[2] = n.pa[2 * a.Wi];
-                o.d[2] = f32x2w{n.pa[2 * a.Wi + 1], n.pa[2 * a.Wi + 2]};
-            };
-            auto mf = [&](const Ops &o, float z, int t) {
+            auto mf = [&](const Ops &o, int t) {
                 const float xv = t % 3 == 0 ? o.s[t / 3] : o.d[t / 3][t % 3 - 1];
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(z, xv, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.z, xv, acc[t], 0, 0, 0);
             };
 #define AUGCL_SB() __builtin_amdgcn_sched_barrier(0)
-            // One pixel pair = 9 MFMAs; the NEXT pair's fetch (addresses, 4 + 4 LDS reads) is issued in three pieces after
-            // the 1st, 2nd and 3rd MFMA: the single wave that feeds this SIMD's MFMA pipe issues in order, and a ~30-
-            // instruction fetch block between two 9-MFMA groups left the pipe idle for ~150 of a pair's ~790 cycles
-            // (tools/ebench stamps; 576 are MFMA).  `fetch` is wave-uniform.  The s_waitcnt drains the in-order LDS counter
-            // where everything outstanding is >= 6 MFMAs old, so that hipcc adds no waits of its own inside the groups.
-            auto pairstep = [&](const Ops &cur, bool vcur, Ops &nxt, bool &vnxt, bool fetch) {
+            // One pixel pair = 9 MFMAs; the NEXT pair's fetch (2 address adds + the table read for the pair after it, then
+            // 4 + 4 operand reads) is issued in three pieces after the 1st, 2nd and 3rd MFMA.  The s_waitcnt drains the
+            // in-order LDS counter where everything outstanding is >= 6 MFMAs old, so that hipcc adds no waits of its own
+            // inside the groups (it cannot tell how old loop-carried reads are and waited for the ones just issued).
+            int2 tn; // table entry of the NEXT pair
+            auto pairstep = [&](const Ops &cur, Ops &nxt) {
                 __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0)
-                const float z = vcur ? cur.z : 0.0f;
-                dbacc += z;
-                Nx n;
-                mf(cur, z, 0);
+                dbacc += cur.z;
+                mf(cur, 0);
                 AUGCL_SB();
-                if (fetch) addr(n, vnxt);
+                const float *pz = reinterpret_cast<const float *>(zc + tn.x), *pa = reinterpret_cast<const float *>(ac + tn.y);
+                tp += 8;
+                tn = *tp;
                 AUGCL_SB();
-                if (ABL != 2) mf(cur, z, 1);
+                if (ABL != 2) mf(cur, 1);
                 AUGCL_SB();
-                if (fetch) rd1(n, nxt);
+                rd1(pa, pz, nxt);
                 AUGCL_SB();
-                if (ABL != 2) mf(cur, z, 2);
+                if (ABL != 2) mf(cur, 2);
                 AUGCL_SB();
-                if (fetch) rd2(n, nxt);
+                rd2(pa, nxt);
                 AUGCL_SB();
                 if (ABL != 2) {
 #pragma unroll
-                    for (int t = 3; t < 9; ++t) mf(cur, z, t);
+                    for (int t = 3; t < 9; ++t) mf(cur, t);
                 }
                 AUGCL_SB();
             };
             Ops o0, o1;
-            bool v0 = true, v1 = true;
-            int pr = wave;
-            if (pr < npair) {
-                Nx n;
-                addr(n, v0);
-                rd1(n, o0);
-                rd2(n, o0);
+            {
+                const int2 t0 = *tp;
+                tp += 8;
+                tn = *tp;
+                rd1(reinterpret_cast<const float *>(ac + t0.y), reinterpret_cast<const float *>(zc + t0.x), o0);
+                rd2(reinterpret_cast<const float *>(ac + t0.y), o0);
             }
-            for (; pr + 8 < npair; pr += 8) { // steady state: two pairs per trip, both with a successor
-                pairstep(o0, v0, o1, v1, true);
-                pairstep(o1, v1, o0, v0, true);
+            const int nw = (npair - wave + 3) >> 2; // pairs of this wave (reads past them land on the table's padding)
+            int i = 0;
+            for (; i + 1 < nw; i += 2) {
+                pairstep(o0, o1);
+                pairstep(o1, o0);
             }
-            if (pr < npair) { // one or two pairs left
-                const bool two = pr + 4 < npair;
-                pairstep(o0, v0, o1, v1, two);
-                if (two) pairstep(o1, v1, o0, v0, false);
-            }
+            if (i < nw) pairstep(o0, o1);
 #undef AUGCL_SB
         }
         if (!SPLIT && next < a.n_items && ABL != 1) commit(next, (it + 1) & 1, pf);
@@ -1328,7 +1322,7 @@ static int wgrad32_impl(const float *act_prev, const float *dz, float *dw, float
     a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ho = Hi - 2; a.Wo = Wi - 2;
     // LDS words per output row: A rows (32*Wi) + Z rows (32*Wo); +2 halo rows of A; + slack for the odd strides
     const int budget = kBufLds; // per buffer of the double-buffered {A, dZ} tile pair (one workgroup per CU)
-    int rt = (budget / 4 - 64 * Wi - 64) / (32 * Wi + 32 * a.Wo);
+    int rt = (budget / 4 - 64 * Wi - 64 - 32 - 600) / (32 * Wi + 32 * a.Wo); // - zero words - half the pair tables
     // register prefetch geometry: an A run (rt+2 rows) fits 8, a dZ run (rt rows) 4 dwords per lane
     rt = std::min(rt, std::min(512 / Wi - 2, 256 / a.Wo));
     AUGCL_REQUIRE(rt >= 1 && a.Wo >= 8, "%s: unsupported width %d (need 10 <= W <= 170)", name, Wi);
@@ -1336,8 +1330,9 @@ static int wgrad32_impl(const float *act_prev, const float *dz, float *dw, float
     a.S = (a.Ho + rt - 1) / rt;
     a.RT = (a.Ho + a.S - 1) / a.S;
     a.n_items = B * a.S;
-    const int planeA = ((a.RT + 2) * Wi) | 1, planeZ = (a.RT * a.Wo) | 1;
-    size_t lds = 2 * (size_t)(32 * planeA + 32 * planeZ) * 4;
+    const int planeA = ((a.RT + 2) * Wi) | 1, planeZ = (a.RT * a.Wo + 1) | 1;
+    const int ntab = 2 * (((a.RT * a.Wo + 1) >> 1) + 8); // pair table: two sets of ntab (dZ offset, A offset) entries
+    size_t lds = 2 * (size_t)(32 * planeA + 32 * planeZ) * 4 + (size_t)2 * ntab * 8;
     const size_t red = (size_t)(145 * 64) * 4; // wave-reduction scratch reuses the tiles
     if (lds < red) lds = red;
     const int grid = grid_for(a.n_items, 1);

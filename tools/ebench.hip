@@ -131,6 +131,61 @@ __global__ __launch_bounds__(256, 1) void k_mfma_9acc(float *out, int iters, flo
     for (int t = 0; t < 9; ++t) for (int r = 0; r < 16; ++r) s += acc[t][r];
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
+// k_wgrad32's pair loop in isolation: 9 accumulators, per pixel pair 9 MFMAs + (V >= 1) 8 LDS reads issued after the
+// 2nd / 3rd MFMA + (V >= 2) a dozen address instructions after the 1st + (V >= 3) the select / bias-sum in front
+template <int V>
+__global__ __launch_bounds__(256, 1) void k_wg_pair(float *out, int pairs, float a0)
+{
+    __shared__ float sh[64 * 129 + 256];
+    for (int i = threadIdx.x; i < 64 * 129 + 256; i += 256) sh[i] = 1.0f + i * 1e-6f;
+    __syncthreads();
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f32x16 acc[9];
+    for (int t = 0; t < 9; ++t) for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
+    const float *pa = sh + l31 * 129 + h, *pz = sh + 64 * 129 + l31 + h;
+    struct Ops { float z, s[3]; f2 d[3]; };
+    Ops o0, o1;
+    auto rd1 = [&](const float *a, const float *z, Ops &o) { o.z = *z; o.s[0] = a[0]; o.d[0] = f2{a[1], a[2]}; o.s[1] = a[37]; };
+    auto rd2 = [&](const float *a, Ops &o) { o.d[1] = f2{a[38], a[39]}; o.s[2] = a[74]; o.d[2] = f2{a[75], a[76]}; };
+    rd1(pa, pz, o0); rd2(pa, o0); o1 = o0;
+    int xn = h, pn = 2 * (threadIdx.x >> 6) + h;
+    float dbacc = 0.f;
+    auto mf = [&](const Ops &o, float z, int t) { const float xv = t % 3 == 0 ? o.s[t / 3] : o.d[t / 3][t % 3 - 1]; acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(z, xv, acc[t], 0, 0, 0); };
+    auto step = [&](const Ops &cur, Ops &nxt) {
+        if (V >= 1) __builtin_amdgcn_s_waitcnt(0xC07F);
+        float z = cur.z;
+        if (V >= 3) { z = pn < pairs * 8 ? z : 0.0f; dbacc += z; }
+        const float *na = pa, *nz = pz;
+        mf(cur, z, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (V >= 2) { // the product's address walk
+            const bool valid = pn < pairs * 8;
+            nz = valid ? pz : sh + 64 * 129;
+            na = valid ? pa : sh;
+            pn += 8; xn += 8;
+            const bool wrap = xn >= 35;
+            pa += wrap ? 2 : 0; pa -= wrap ? 2 : 0; // keeps the walk's instructions, stays inside the array
+            xn -= wrap ? 35 : 0;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mf(cur, z, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (V >= 1) rd1(na, nz, nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        mf(cur, z, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (V >= 1) rd2(na, nxt);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 3; t < 9; ++t) mf(cur, z, t);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int i = 0; i < pairs; i += 2) { step(o0, o1); step(o1, o0); }
+    float s = dbacc;
+    for (int t = 0; t < 9; ++t) for (int r = 0; r < 16; ++r) s += acc[t][r];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
 // register-only f32 MFMA loop: the practical MFMA ceiling (clock under load) on this chip
 __global__ __launch_bounds__(256, 1) void k_mfma_peak(float *out, int iters, float a0)
 {
@@ -182,9 +237,9 @@ int main(int argc, char **argv)
     vs.push_back({"wgrad product", f_fwd, [&] { augcl_enc_conv32_backward_weights(in, out, dw, db, ws, wsb, B, H, H, 0); }});
     auto wg = [&](auto kern) {
         WgradArgs a{}; a.act = in; a.dz = out; a.partial = ws; a.B = B; a.Hi = H; a.Wi = H; a.Ho = H - 2; a.Wo = H - 2;
-        int rt = (kBufLds / 4 - 64 * H - 64) / (32 * H + 32 * a.Wo); rt = std::min(rt, std::min(512 / H - 2, 256 / a.Wo)); if (rt > a.Ho) rt = a.Ho;
+        int rt = (kBufLds / 4 - 64 * H - 64 - 32 - 600) / (32 * H + 32 * a.Wo); rt = std::min(rt, std::min(512 / H - 2, 256 / a.Wo)); if (rt > a.Ho) rt = a.Ho;
         a.S = (a.Ho + rt - 1) / rt; a.RT = (a.Ho + a.S - 1) / a.S; a.n_items = B * a.S;
-        const int planeA = ((a.RT + 2) * H) | 1, planeZ = (a.RT * a.Wo) | 1; size_t lds = 2 * (size_t)(32 * planeA + 32 * planeZ) * 4;
+        const int planeA = ((a.RT + 2) * H) | 1, planeZ = (a.RT * a.Wo + 1) | 1; size_t lds = 2 * (size_t)(32 * planeA + 32 * planeZ) * 4 + (size_t)2 * 2 * (((a.RT * a.Wo + 1) >> 1) + 8) * 8;
         set_lds(kern, lds, "x"); hipLaunchKernelGGL(kern, dim3(grid_for(a.n_items, 1)), dim3(256), lds, 0, a);
     };
     vs.push_back({"wgrad kernel only", f_fwd, [&] { wg(k_wgrad32<0>); }});
@@ -199,12 +254,16 @@ int main(int argc, char **argv)
     vs.push_back({"mfma 9 accs round-robin", 2.0 * 32 * 32 * 2 * 9 * 4000.0 * 4 * 256, [&] { hipLaunchKernelGGL(k_mfma_9acc<1>, dim3(256), dim3(256), 0, 0, out, 4000, 0.5f); }});
     vs.push_back({"mfma 9 accs, runs of 2", 2.0 * 32 * 32 * 2 * 18 * 2000.0 * 4 * 256, [&] { hipLaunchKernelGGL(k_mfma_9acc<2>, dim3(256), dim3(256), 0, 0, out, 2000, 0.5f); }});
     vs.push_back({"mfma 9 accs, runs of 4", 2.0 * 32 * 32 * 2 * 36 * 1000.0 * 4 * 256, [&] { hipLaunchKernelGGL(k_mfma_9acc<4>, dim3(256), dim3(256), 0, 0, out, 1000, 0.5f); }});
+    vs.push_back({"wgrad pair loop: MFMA only", 2.0 * 32 * 32 * 2 * 9 * 4000.0 * 4 * 256, [&] { hipLaunchKernelGGL(k_wg_pair<0>, dim3(256), dim3(256), 0, 0, out, 4000, 0.5f); }});
+    vs.push_back({"wgrad pair loop: + LDS reads", 2.0 * 32 * 32 * 2 * 9 * 4000.0 * 4 * 256, [&] { hipLaunchKernelGGL(k_wg_pair<1>, dim3(256), dim3(256), 0, 0, out, 4000, 0.5f); }});
+    vs.push_back({"wgrad pair loop: + addresses", 2.0 * 32 * 32 * 2 * 9 * 4000.0 * 4 * 256, [&] { hipLaunchKernelGGL(k_wg_pair<2>, dim3(256), dim3(256), 0, 0, out, 4000, 0.5f); }});
+    vs.push_back({"wgrad pair loop: + select/sum", 2.0 * 32 * 32 * 2 * 9 * 4000.0 * 4 * 256, [&] { hipLaunchKernelGGL(k_wg_pair<3>, dim3(256), dim3(256), 0, 0, out, 4000, 0.5f); }});
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     if (argc > 3 && atoi(argv[3]) == -3) { // per-strip shader-clock stamps of k_wgrad32<4, false, true>, workgroup 0 / wave 0
         WgradArgs a{}; a.act = in; a.dz = out; a.partial = ws; a.B = B; a.Hi = H; a.Wi = H; a.Ho = H - 2; a.Wo = H - 2;
-        int rt = (kBufLds / 4 - 64 * H - 64) / (32 * H + 32 * a.Wo); rt = std::min(rt, std::min(512 / H - 2, 256 / a.Wo)); if (rt > a.Ho) rt = a.Ho;
+        int rt = (kBufLds / 4 - 64 * H - 64 - 32 - 600) / (32 * H + 32 * a.Wo); rt = std::min(rt, std::min(512 / H - 2, 256 / a.Wo)); if (rt > a.Ho) rt = a.Ho;
         a.S = (a.Ho + rt - 1) / rt; a.RT = (a.Ho + a.S - 1) / a.S; a.n_items = B * a.S;
-        const int planeA = ((a.RT + 2) * H) | 1, planeZ = (a.RT * a.Wo) | 1; size_t lds = 2 * (size_t)(32 * planeA + 32 * planeZ) * 4;
+        const int planeA = ((a.RT + 2) * H) | 1, planeZ = (a.RT * a.Wo + 1) | 1; size_t lds = 2 * (size_t)(32 * planeA + 32 * planeZ) * 4 + (size_t)2 * 2 * (((a.RT * a.Wo + 1) >> 1) + 8) * 8;
         const int grid = grid_for(a.n_items, 1);
         set_lds(k_wgrad32<4, false, true>, lds, "x");
         unsigned long long *dbg = reinterpret_cast<unsigned long long *>(ws + (size_t)grid * WG_SLAB + 8 * WG_SLAB);
