@@ -930,9 +930,25 @@ __global__ __launch_bounds__(256, (BF16DZ ? 4 : 3)) void k_wgrad_first_pipe(Wgra
     const int st = a.stride;
     const int rows_in_max = st * (a.RT - 1) + 3;
     const int planeX = rows_in_max * a.Wi; // a multiple of 4: 16-byte LDS stores
-    const int planeZ = (a.RT * a.Wo) | 1;
+    const int planeZ = (a.RT * a.Wo + 1) | 1; // word RT*Wo of every dZ plane is never written by data: it stays ZERO
     float *ldsX = lds;
     float *ldsZ = lds + a.C * planeX;
+    // pair table (as in k_wgrad32): byte offsets of pixel p = 2 pr + hh in a dZ plane and of its top-left tap in an X plane,
+    // for a full strip and for the last strip of an image; pixels past the strip point at the zero word / tap 0
+    const int ntab = 2 * (((a.RT * a.Wo + 1) >> 1) + 8);
+    int2 *tab = reinterpret_cast<int2 *>(lds + ((a.C * planeX + 32 * planeZ + 1) & ~1));
+    {
+        const int rows_last = a.Ho - (a.S - 1) * a.RT;
+        for (int i = tid; i < 2 * ntab; i += 256) {
+            const int set = i >= ntab, e = i - set * ntab;
+            const int npix_s = (set ? rows_last : a.RT) * a.Wo;
+            const bool valid = e < npix_s;
+            const int pc = valid ? e : 0;
+            const int yy = pc / a.Wo, xx = pc - yy * a.Wo;
+            tab[i] = make_int2((valid ? e : a.RT * a.Wo) * 4, st * (yy * a.Wi + xx) * 4);
+        }
+        if (tid < 32) ldsZ[tid * planeZ + a.RT * a.Wo] = 0.0f;
+    }
     const int K = a.C * 9;
     const int W4 = a.Wi >> 2;
     // LDS offset of column n = l31 + 32 j: (c, ky, kx).  Columns n >= K are never stored: they read a valid address (0) and
@@ -1039,29 +1055,31 @@ __global__ __launch_bounds__(256, (BF16DZ ? 4 : 3)) void k_wgrad_first_pipe(Wgra
         if (item + (int)gridDim.x < a.n_items) issue(item + gridDim.x, R); // in flight under the MFMAs below
         const Geo g = geom(item);
         const int npair = (g.npix + 1) >> 1;
-        // operands of pixel pair pr: z = dZ[co = l31][p], x[j] = X tap n = l31 + 32 j of pixel p = 2 pr + h
-        auto ld = [&](int pr, float &z, float (&xv)[NT]) {
-            int p = 2 * pr + h;
-            const bool valid = p < g.npix;
-            if (!valid) p = g.npix - 1;
-            const int yy = (int)__umulhi((uint32_t)p, magic_wo), xx = p - yy * a.Wo;
-            z = ldsZ[l31 * planeZ + p];
-            if (!valid) z = 0.0f;
-            const float *px = ldsX + st * (yy * a.Wi + xx);
+        // operands of pixel pair pr: z = dZ[co = l31][p], x[j] = X tap n = l31 + 32 j of pixel p = 2 pr + h.  Addresses come
+        // from the pair table (2 adds + NT adds per pair instead of a division, a multiply and selects: every vector
+        // instruction between a wave's MFMAs costs MFMA time); two pairs in flight per wave.
+        const char *zc = reinterpret_cast<const char *>(ldsZ + l31 * planeZ);
+        const char *xc[NT];
 #pragma unroll
-            for (int j = 0; j < NT; ++j) xv[j] = px[noff[j]];
+        for (int j = 0; j < NT; ++j) xc[j] = reinterpret_cast<const char *>(ldsX + noff[j]);
+        const int2 *tp = tab + (g.rows == a.RT ? 0 : ntab) + 2 * wave + h;
+        auto ld = [&](float &z, float (&xv)[NT]) {
+            const int2 t = *tp;
+            tp += 8;
+            z = *reinterpret_cast<const float *>(zc + t.x);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) xv[j] = *reinterpret_cast<const float *>(xc[j] + t.y);
         };
-        // two pairs in flight per wave: the LDS reads of the next pair are issued before the MFMAs of this one
         float z0, z1, x0[NT], x1[NT];
-        if (wave < npair) ld(wave, z0, x0);
+        ld(z0, x0); // (pairs past the strip read the zero word: harmless)
         for (int pr = wave; pr < npair; pr += 8) {
-            if (pr + 4 < npair) ld(pr + 4, z1, x1);
+            ld(z1, x1);
             __builtin_amdgcn_sched_barrier(0);
             dbacc += z0;
 #pragma unroll
             for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(z0, x0[j], acc[j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (pr + 8 < npair) ld(pr + 8, z0, x0);
+            ld(z0, x0);
             __builtin_amdgcn_sched_barrier(0);
             if (pr + 4 < npair) {
                 dbacc += z1;
@@ -1405,9 +1423,13 @@ static int wgrad_first_impl(const float *x, const float *dz, float *dw, float *d
     const int run4_full = (stride * (a.RT - 1) + 3) * (Wi / 4);
     const int rows_last = a.Ho - (a.S - 1) * a.RT;
     const int run4_last = (stride * (rows_last - 1) + 3) * (Wi / 4);
+    // its LDS: X planes, dZ planes with a spare zero word each, the pair tables
+    const int planeZp = (a.RT * a.Wo + 1) | 1, ntab = 2 * (((a.RT * a.Wo + 1) >> 1) + 8);
+    const size_t lds_pipe = std::max((size_t)(((C * planeX + 32 * planeZp + 1) & ~1) + 2 * ntab * 2) * 4, red);
     const bool pipe = Wi % 4 == 0 && aligned16(x) && a.RT * a.Wo <= WG1_ZP && C * run4_full <= 256 * WG1_XU &&
-                      (!bf16dz || a.RT * a.Wo * 4 <= 512) && NT <= 3;
+                      (!bf16dz || a.RT * a.Wo * 4 <= 512) && NT <= 3 && lds_pipe <= (size_t)kWg1Lds * kWg1PerCu / per_cu;
     if (pipe) {
+        const size_t lds = lds_pipe;
         const int grid = grid_for(a.n_items, bf16dz ? 4 : 3); // = the kernel's launch bounds: every workgroup resident
         const uint32_t mf = (uint32_t)(0x100000000ull / (unsigned)run4_full) + 1u;
         const uint32_t ml = (uint32_t)(0x100000000ull / (unsigned)run4_last) + 1u;
