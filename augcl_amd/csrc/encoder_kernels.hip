@@ -27,6 +27,9 @@ namespace augcl {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// words per channel plane of k_conv32's LDS tiles: 2 buffers x 32 planes x 624 words = 156 KB of the CU's 160 KB
+constexpr int kConvPlane = 624;
+
 __device__ __forceinline__ float div255e(float x)
 {
     const float r = 1.0f / 255.0f;
@@ -137,8 +140,11 @@ __global__ __launch_bounds__(512, 2) void k_conv32(ConvArgs a)
     // LDS row pitch.  MODE 1 keeps 2 zero words between consecutive dZ rows (the right pad of one row = the left pad of the
     // next) and zero rows outside the image: every tap of every output pixel reads a real word or a zero, nothing is masked.
     const int pitch = MODE ? Wi + 2 : Wi;
-    const int plane = round4((a.RT + 2) * pitch + (MODE ? 2 : 0));
-    const int bufw = 32 * plane; // words per buffer
+    // The channel-plane stride is a COMPILE-TIME constant (the largest plane the LDS budget admits; the host sizes RT so that
+    // a strip's rows fit): channel offsets then fold into the 16-bit immediate of every ds_read and the MFMA chain carries
+    // no address arithmetic for them -- a vector instruction between a wave's MFMAs costs MFMA time.
+    constexpr int plane = kConvPlane;
+    constexpr int bufw = 32 * plane; // words per buffer
     constexpr int WROW = 292;            // weight staging row pitch (16-byte aligned rows, conflict-free reads)
     float *lbias = lds_raw + max(2 * bufw, bufw + 32 * WROW);
 
@@ -225,7 +231,8 @@ __global__ __launch_bounds__(512, 2) void k_conv32(ConvArgs a)
         }
         // row by row, lanes along x: 4 channels x 8 rows = 32 dwords per lane in flight, then 32 conflict-free ds_write_b32 at
         // row base + immediate -- no per-element address arithmetic (a chunked copy of the contiguous run needs a division
-        // per element to find its row, and made the loaders the slower half of the pipeline)
+        // per element to find its row, and made the loaders the slower half of the pipeline; walking the (channel, row)
+        // pairs as one list without the duplicate rows of a ragged last batch measured 20 % slower: scalar bookkeeping)
         for (int x0 = 0; x0 < Wi; x0 += 64) {
             const int x = min(x0 + lane, Wi - 1); // lanes past the row end repeat its last word
 #pragma unroll
@@ -311,15 +318,19 @@ __global__ __launch_bounds__(512, 2) void k_conv32(ConvArgs a)
                 f32x16 acc;
                 // explicit software pipeline: the 9 taps of channel cil+1 are in flight while the 9 MFMAs of
                 // channel cil issue (one wave per SIMD must never wait on a just-issued ds_read)
+                // single ds_read_b32 per tap, kept apart by the volatile access: merged into ds_read2_b32, whose offsets
+                // reach only 1 KB, a pair needs its own base register -- one vector add per pair inside the MFMA chain --
+                // while a lone ds_read_b32 takes the whole (channel plane + tap) offset as its 16-bit immediate
+#define LDSV(p) (*(const volatile __attribute__((address_space(3))) float *)(p))
                 float xa[9], xb[9];
+                const float *const rb[3] = {base, base + pitch, base + 2 * pitch}; // the three tap rows of this lane's pixel
                 constexpr int NC = (ABL == 2 ? 2 : 16);
 #pragma unroll
-                for (int t = 0; t < 9; ++t) xa[t] = base[(t / 3) * pitch + (t % 3)];
+                for (int t = 0; t < 9; ++t) xa[t] = LDSV(rb[t / 3] + (t % 3));
 #pragma unroll
                 for (int cil = 0; cil < NC; cil += 2) {
-                    const float *p1 = base + (cil + 1) * plane;
 #pragma unroll
-                    for (int t = 0; t < 9; ++t) xb[t] = p1[(t / 3) * pitch + (t % 3)];
+                    for (int t = 0; t < 9; ++t) xb[t] = LDSV(rb[t / 3] + (cil + 1) * plane + (t % 3));
                     __builtin_amdgcn_sched_barrier(0); // keep the 9 reads AHEAD of the MFMA group (hipcc sinks them)
                     // (backward-data used to select out-of-image taps to zero per MFMA into one temporary: the select's write
                     // waited for the in-flight MFMA that still named that temporary as its operand -- 92.6 instead of 70.5
@@ -328,9 +339,8 @@ __global__ __launch_bounds__(512, 2) void k_conv32(ConvArgs a)
                     for (int t = 0; t < 9; ++t)
                         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[cil * 9 + t], xa[t], (cil == 0 && t == 0) ? bias16 : acc, 0, 0, 0);
                     if (cil + 2 < NC) {
-                        const float *p2 = base + (cil + 2) * plane;
 #pragma unroll
-                        for (int t = 0; t < 9; ++t) xa[t] = p2[(t / 3) * pitch + (t % 3)];
+                        for (int t = 0; t < 9; ++t) xa[t] = LDSV(rb[t / 3] + (cil + 2) * plane + (t % 3));
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -338,6 +348,7 @@ __global__ __launch_bounds__(512, 2) void k_conv32(ConvArgs a)
                         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[(cil + 1) * 9 + t], xb[t], acc, 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+#undef LDSV
                 if (ABL == 4) stamp(acc[0] == 12345.678f ? 3 : 1); // after the MFMA chain has drained (reads acc)
                 if (valid && (ABL != 3 || acc[0] == 12345.678f)) {
                     // rows in accumulator order: co = 0,1,2,3, 8,9,10,11, ... (+4 h in the lane offset).  Forward ReLU on
@@ -1203,9 +1214,9 @@ static int conv32_forward_impl(const float *in, const float *w, const float *bia
         if (rt0 > 0 && B * s0 * 2 <= cus) extra += std::min(a.Ho, cus / (2 * B)) - s0;
     }
     a.RT = pick_rt(a.Ho, 32 * Wi, 2, kBufLds, &a.S, extra);
-    AUGCL_REQUIRE(a.RT > 0, "%s: image row too wide for LDS (W=%d)", name, Wi);
+    AUGCL_REQUIRE(a.RT > 0 && (a.RT + 2) * Wi <= kConvPlane, "%s: image row too wide for LDS (W=%d)", name, Wi);
     a.n_items = B * a.S;
-    const size_t bufw = (size_t)32 * (((a.RT + 2) * Wi + 3) & ~3);
+    const size_t bufw = (size_t)32 * kConvPlane; // fixed plane stride (compile-time ds_read offsets)
     const size_t lds = (std::max(2 * bufw, bufw + 32 * 292) + 32) * 4; // two tile buffers, or one + the weight staging
     if (int rc = set_lds(k_conv32<0>, lds, name)) return rc;
     int grid = grid_for(a.n_items, 1);
@@ -1244,10 +1255,10 @@ int augcl_enc_conv32_backward_data(const float *dz, const float *w, const float 
     // 4-wave tile rounds per image -- fewer, larger strips starve the loader/compute pipeline)
     // the dZ tile is kept zero-padded in LDS: row pitch Wo + 2, + 2 words behind the last row
     a.RT = pick_rt(a.Ho, 32 * (Wo + 2), 2, kBufLds - 32 * 8, &a.S, augcl::extra_strips(1, Wo));
-    AUGCL_REQUIRE(a.RT > 0, "%s: image row too wide for LDS (W=%d)", name, Wo);
+    AUGCL_REQUIRE(a.RT > 0 && (a.RT + 2) * (Wo + 2) + 2 <= kConvPlane, "%s: image row too wide for LDS (W=%d)", name, Wo);
     a.n_items = B * a.S;
     a.magic_wi = (uint32_t)(0x100000000ull / (unsigned)Wo) + 1u;
-    const size_t bufw = (size_t)32 * (((a.RT + 2) * (Wo + 2) + 2 + 3) & ~3);
+    const size_t bufw = (size_t)32 * kConvPlane;
     const size_t lds = (std::max(2 * bufw, bufw + 32 * 292) + 32) * 4;
     if (int rc = set_lds(k_conv32<1>, lds, name)) return rc;
     hipLaunchKernelGGL(k_conv32<1>, dim3(grid_for(a.n_items, 1)), dim3(512), lds, as_stream(stream), a);

@@ -207,8 +207,8 @@ static void launch_conv(const float *in, const float *w, const float *bias, cons
 {
     ConvArgs a{}; a.in = in; a.w = w; a.bias = bias; a.mask = mask; a.out = out; a.B = B; a.Hi = Hi; a.Wi = Wi; a.relu = 1;
     size_t lds;
-    if (MODE == 0) { a.Ho = Hi - 2; a.Wo = Wi - 2; a.RT = pick_rt(a.Ho, 32 * Wi, 2, kBufLds, &a.S); const size_t bw = (size_t)32 * (((a.RT + 2) * Wi + 3) & ~3); lds = (std::max(2 * bw, bw + 32 * 292) + 32) * 4; }
-    else { a.Ho = Hi + 2; a.Wo = Wi + 2; a.RT = pick_rt(a.Ho, 32 * (Wi + 2), 2, kBufLds - 32 * 8, &a.S); a.magic_wi = (uint32_t)(0x100000000ull / (unsigned)Wi) + 1u; const size_t bw = (size_t)32 * (((a.RT + 2) * (Wi + 2) + 2 + 3) & ~3); lds = (std::max(2 * bw, bw + 32 * 292) + 32) * 4; }
+    if (MODE == 0) { a.Ho = Hi - 2; a.Wo = Wi - 2; a.RT = pick_rt(a.Ho, 32 * Wi, 2, kBufLds, &a.S); const size_t bw = (size_t)32 * kConvPlane; lds = (std::max(2 * bw, bw + 32 * 292) + 32) * 4; }
+    else { a.Ho = Hi + 2; a.Wo = Wi + 2; a.RT = pick_rt(a.Ho, 32 * (Wi + 2), 2, kBufLds - 32 * 8, &a.S); a.magic_wi = (uint32_t)(0x100000000ull / (unsigned)Wi) + 1u; const size_t bw = (size_t)32 * kConvPlane; lds = (std::max(2 * bw, bw + 32 * 292) + 32) * 4; }
     a.n_items = B * a.S;
     set_lds(k_conv32<MODE, ABL>, lds, "x");
     hipLaunchKernelGGL((k_conv32<MODE, ABL>), dim3(grid_for(a.n_items, per_cu)), dim3(512), lds, 0, a);
@@ -289,8 +289,8 @@ int main(int argc, char **argv)
             ConvArgs a{}; a.in = in; a.w = w; a.bias = MODEV ? nullptr : bias; a.mask = MODEV ? mask : nullptr; a.out = out; a.B = B; a.Hi = H; a.Wi = H; a.relu = 1;
             a.bias2 = reinterpret_cast<const float *>(dbg); a.dual = 0;
             size_t lds;
-            if (MODEV == 0) { a.Ho = H - 2; a.Wo = H - 2; a.RT = pick_rt(a.Ho, 32 * H, 2, kBufLds, &a.S); const size_t bw = (size_t)32 * (((a.RT + 2) * H + 3) & ~3); lds = (std::max(2 * bw, bw + 32 * 292) + 32) * 4; }
-            else { a.Ho = H + 2; a.Wo = H + 2; a.RT = pick_rt(a.Ho, 32 * (H + 2), 2, kBufLds - 32 * 8, &a.S); a.magic_wi = (uint32_t)(0x100000000ull / (unsigned)H) + 1u; const size_t bw = (size_t)32 * (((a.RT + 2) * (H + 2) + 2 + 3) & ~3); lds = (std::max(2 * bw, bw + 32 * 292) + 32) * 4; }
+            if (MODEV == 0) { a.Ho = H - 2; a.Wo = H - 2; a.RT = pick_rt(a.Ho, 32 * H, 2, kBufLds, &a.S); const size_t bw = (size_t)32 * kConvPlane; lds = (std::max(2 * bw, bw + 32 * 292) + 32) * 4; }
+            else { a.Ho = H + 2; a.Wo = H + 2; a.RT = pick_rt(a.Ho, 32 * (H + 2), 2, kBufLds - 32 * 8, &a.S); a.magic_wi = (uint32_t)(0x100000000ull / (unsigned)H) + 1u; const size_t bw = (size_t)32 * kConvPlane; lds = (std::max(2 * bw, bw + 32 * 292) + 32) * 4; }
             a.n_items = B * a.S;
             set_lds(kern, lds, "x");
             for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(kern, dim3(grid_for(a.n_items, 1)), dim3(512), lds, 0, a);
