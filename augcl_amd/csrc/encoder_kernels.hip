@@ -286,6 +286,8 @@ __global__ __launch_bounds__(512, 2) void k_conv32(ConvArgs a)
             const float *lds = lds_raw + (it & 1) * bufw;
             // ---- M-tiles of 32 consecutive strip pixels, round-robin over the 4 compute waves
             const int ntiles = (npix + 31) >> 5;
+            float gv[16]; // backward-data: this lane's 16 ReLU gates of the CURRENT tile
+            bool gv_ready = false; // (wave-uniform) fetched ahead, in front of the previous tile's stores
             for (int tile = cw; tile < ntiles; tile += 4) {
                 if (ABL == 4) stamp(0);
                 int m = tile * 32 + l31;
@@ -308,13 +310,13 @@ __global__ __launch_bounds__(512, 2) void k_conv32(ConvArgs a)
                 // s[rsrc], soff offen`), i.e. no vector address arithmetic per access.  hipcc's flat-pointer code carried a
                 // 64-bit vector address from row to row and selected the ReLU per element -- 6 vector instructions per
                 // row, ~1040 of a tile's ~11300 cycles (tools/ebench, per-tile s_memtime stamps).
-                float gv[16];
-                if (MODE == 1 && a.mask != nullptr) {
+                auto gates = [&](unsigned bo, float (&g)[16]) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        gv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                              rs_mask, boff, (unsigned)(((r & 3) + 8 * (r >> 2)) * chw) * 4u, 0));
-                }
+                        g[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                             rs_mask, bo, (unsigned)(((r & 3) + 8 * (r >> 2)) * chw) * 4u, 0));
+                };
+                if (MODE == 1 && a.mask != nullptr && !gv_ready) gates(boff, gv); // a strip's first tile
                 f32x16 acc;
                 // explicit software pipeline: the 9 taps of channel cil+1 are in flight while the 9 MFMAs of
                 // channel cil issue (one wave per SIMD must never wait on a just-issued ds_read)
@@ -350,6 +352,22 @@ __global__ __launch_bounds__(512, 2) void k_conv32(ConvArgs a)
                 }
 #undef LDSV
                 if (ABL == 4) stamp(acc[0] == 12345.678f ? 3 : 1); // after the MFMA chain has drained (reads acc)
+                // Backward-data epilogue in three steps: gate the 16 accumulator rows in place; request the NEXT tile's gates
+                // (into the registers the current ones just vacated); store.  The vector-memory counter is in-order and a
+                // store is only counted off when memory acknowledges it (longer than a whole tile, tools/ebench stamps):
+                // gates requested at their own tile's start sat behind the previous tile's 16 stores, and the wait for
+                // them waited for those stores -- 924-1500 cycles per epilogue against the forward's 556.
+                if (MODE == 1 && a.mask != nullptr) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = gv[r] > 0.0f ? acc[r] : 0.0f;
+                    gv_ready = tile + 4 < ntiles;
+                    if (gv_ready) {
+                        int m2 = (tile + 4) * 32 + l31;
+                        if (m2 >= npix) m2 = npix - 1;
+                        const int yy2 = m2 / a.Wo, xx2 = m2 - yy2 * a.Wo;
+                        gates((unsigned)((b * 32 * a.Ho + (y0 + yy2)) * a.Wo + xx2 + 4 * h * chw) * 4u, gv);
+                    }
+                }
                 if (valid && (ABL != 3 || acc[0] == 12345.678f)) {
                     // rows in accumulator order: co = 0,1,2,3, 8,9,10,11, ... (+4 h in the lane offset).  Forward ReLU on
                     // the bit pattern is one v_max_i32 (negative floats are negative integers; floor INT_MIN = no ReLU).
@@ -357,7 +375,6 @@ __global__ __launch_bounds__(512, 2) void k_conv32(ConvArgs a)
                     for (int r = 0; r < 16; ++r) {
                         float v = acc[r];
                         if (MODE == 0) v = __int_as_float(max(__float_as_int(v), relu_floor));
-                        else if (a.mask != nullptr) v = gv[r] > 0.0f ? v : 0.0f;
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_out, boff,
                                                               (unsigned)(((r & 3) + 8 * (r >> 2)) * chw) * 4u, 0);
                     }
