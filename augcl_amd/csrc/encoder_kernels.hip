@@ -148,48 +148,6 @@ __global__ __launch_bounds__(512, 2) void k_conv32(ConvArgs a)
     constexpr int WROW = 292;            // weight staging row pitch (16-byte aligned rows, conflict-free reads)
     float *lbias = lds_raw + max(2 * bufw, bufw + 32 * WROW);
 
-    // weights: all 512 threads copy the 36 KB into LDS with coalesced 16-byte loads (the region of tile buffer 1,
-    // first written by the loader after the second barrier), then each compute lane picks its 144 out of LDS.
-    // (Gathered straight from global memory they cost ~4 us per launch: 2304 cache lines per wave.)
-    {
-        typedef float wf4 __attribute__((ext_vector_type(4)));
-        float *wst = lds_raw + bufw;
-        const wf4 *w4 = reinterpret_cast<const wf4 *>((a.dual && (blockIdx.x & 1)) ? a.w2 : a.w);
-        for (int i = tid; i < 32 * 288 / 4; i += 512) {
-            const int row = (4 * i) / 288, col = 4 * i - row * 288;
-            *reinterpret_cast<wf4 *>(wst + row * WROW + col) = w4[i];
-        }
-        const float *bsrc = (a.dual && (blockIdx.x & 1)) ? a.bias2 : a.bias;
-        if (tid < 32) lbias[tid] = (MODE == 0 && bsrc) ? bsrc[tid] : 0.0f;
-    }
-    __syncthreads();
-    float wreg[144];
-    if (!loader) {
-        const float *wst = lds_raw + bufw;
-        if (MODE == 0) {
-            const float *wp = wst + l31 * WROW + h * 144; // contiguous 144 floats
-#pragma unroll
-            for (int k = 0; k < 144; k += 4) {
-                const float4 v = *reinterpret_cast<const float4 *>(wp + k);
-                wreg[k] = v.x; wreg[k + 1] = v.y; wreg[k + 2] = v.z; wreg[k + 3] = v.w;
-            }
-        } else {
-#pragma unroll
-            for (int cil = 0; cil < 16; ++cil)
-#pragma unroll
-                for (int t = 0; t < 9; ++t) // W'[ci=l31][co=cil+16h][ky][kx] = W[co][ci][2-ky][2-kx]
-                    wreg[cil * 9 + t] = wst[(cil + 16 * h) * WROW + l31 * 9 + (8 - t)];
-        }
-    }
-    f32x16 bias16; // accumulator seed: C operand of a tile's first MFMA
-#pragma unroll
-    for (int r = 0; r < 16; ++r) bias16[r] = lbias[acc_row(r, h)];
-    const int relu_floor = __builtin_amdgcn_readfirstlane(a.relu ? 0 : (int)0x80000000); // opaque: stays ONE v_max_i32
-    // raw buffer resources (base, stride 0, no bound, gfx9 dword-3 flags): offsets < 2^32 by the host's size check
-    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, -1, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_mask =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(MODE == 1 && a.mask ? a.mask : a.in), 0, -1, 0x00020000);
-
     // stage item `it` into buffer `bi` (loader waves only): wave cw copies channels 8cw .. 8cw+7, four
     // channel pairs back to back => 24 dwordx4 per lane in flight, one exposed latency per item
     auto stage = [&](int item, int bi, bool first_use) {
@@ -272,8 +230,52 @@ __global__ __launch_bounds__(512, 2) void k_conv32(ConvArgs a)
             ++ndbg;
         }
     };
-    if (loader && first < n_end && ABL != 1) stage(first, 0, true);
+    // Prologue: the 4 compute waves copy the 36 KB of weights into LDS with coalesced 16-byte loads (into the region of tile
+    // buffer 1, which the loaders first write after the second barrier) WHILE the 4 loader waves already stage the first
+    // strip into buffer 0 -- the two memory latencies overlap; then each compute lane picks its 144 weights out of LDS.
+    // (Gathered straight from global memory they cost ~4 us per launch: 2304 cache lines per wave.)
+    if (!loader) {
+        typedef float wf4 __attribute__((ext_vector_type(4)));
+        float *wst = lds_raw + bufw;
+        const wf4 *w4 = reinterpret_cast<const wf4 *>((a.dual && (blockIdx.x & 1)) ? a.w2 : a.w);
+        for (int i = tid; i < 32 * 288 / 4; i += 256) {
+            const int row = (4 * i) / 288, col = 4 * i - row * 288;
+            *reinterpret_cast<wf4 *>(wst + row * WROW + col) = w4[i];
+        }
+        const float *bsrc = (a.dual && (blockIdx.x & 1)) ? a.bias2 : a.bias;
+        if (tid < 32) lbias[tid] = (MODE == 0 && bsrc) ? bsrc[tid] : 0.0f;
+    } else if (first < n_end && ABL != 1) {
+        stage(first, 0, true);
+    }
     __syncthreads();
+    float wreg[144];
+    if (!loader) {
+        const float *wst = lds_raw + bufw;
+        if (MODE == 0) {
+            const float *wp = wst + l31 * WROW + h * 144; // contiguous 144 floats
+#pragma unroll
+            for (int k = 0; k < 144; k += 4) {
+                const float4 v = *reinterpret_cast<const float4 *>(wp + k);
+                wreg[k] = v.x; wreg[k + 1] = v.y; wreg[k + 2] = v.z; wreg[k + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int cil = 0; cil < 16; ++cil)
+#pragma unroll
+                for (int t = 0; t < 9; ++t) // W'[ci=l31][co=cil+16h][ky][kx] = W[co][ci][2-ky][2-kx]
+                    wreg[cil * 9 + t] = wst[(cil + 16 * h) * WROW + l31 * 9 + (8 - t)];
+        }
+    }
+    f32x16 bias16; // accumulator seed: C operand of a tile's first MFMA
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bias16[r] = lbias[acc_row(r, h)];
+    const int relu_floor = __builtin_amdgcn_readfirstlane(a.relu ? 0 : (int)0x80000000); // opaque: stays ONE v_max_i32
+    // raw buffer resources (base, stride 0, no bound, gfx9 dword-3 flags): offsets < 2^32 by the host's size check
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_mask =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(MODE == 1 && a.mask ? a.mask : a.in), 0, -1, 0x00020000);
+
+    __syncthreads(); // the weights are in registers: buffer 1 may be overwritten
     for (int item = first; item < n_end; item += NG, ++it) {
         const int next = item + NG;
         if (loader) {
