@@ -82,10 +82,13 @@ for prec in ("f32", "bf16"):
             e = pm.setdefault(name, {}).setdefault(c, {"avg": 0.0, "n": 0})
             e["avg"] = (e["avg"] * e["n"] + x["avg"] * x["n"]) / (e["n"] + x["n"])
             e["n"] += x["n"]
-    dur = {}
+    tot = {}
     for r in csv.reader(l for l in open(G(f"update_{prec}.csv")) if not l.startswith("#")):
-        if r and r[0] != "name":
-            dur[r[0]] = (float(r[3]), int(r[1]))  # avg_us, calls
+        if r and r[0] != "name":  # name, grid, calls, total_us, ...: one row per launch grid -> merged per kernel
+            t = tot.setdefault(r[0], [0.0, 0])
+            t[0] += float(r[3])
+            t[1] += int(r[2])
+    dur = {n: (t[0] / t[1], t[1]) for n, t in tot.items()}  # avg_us, calls
     per, num, den = {}, 0.0, 0.0
     for k, v in pm.items():
         mf = v.get("SQ_VALU_MFMA_BUSY_CYCLES", {}).get("avg", 0.0)
