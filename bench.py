@@ -198,7 +198,10 @@ def timed(fn, steps, warmup, dist, torch, min_s=MIN_TIMED_S, max_repeats=2000):
             break
     order = sorted(range(len(walls)), key=lambda k: walls[k])
     med = order[len(order) // 2]
-    return {"wall": walls[med], "dev_ms": sorted(devs)[len(devs) // 2], "repeats": len(walls), "timed_s": sum(walls),
+    # dev_ms: the AVERAGE launch duration over everything timed (what a rocprofv3 --stats average of the same command
+    # shows), not the median block: on a noisy box the two differ by a few per cent
+    return {"wall": walls[med], "dev_ms": sum(devs) / len(devs), "dev_ms_median": sorted(devs)[len(devs) // 2],
+            "repeats": len(walls), "timed_s": sum(walls),
             "wall_min": walls[order[0]], "wall_max": walls[order[-1]]}
 
 
