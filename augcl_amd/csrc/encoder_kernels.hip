@@ -103,6 +103,36 @@ __device__ __forceinline__ void wave_copy_runs2(const float *__restrict__ g0, co
     }
 }
 
+// NCH channels (stride cs in global memory, stride plane in LDS) of one contiguous run each, ALL loads of the batch in
+// flight before the first LDS write: one exposed memory latency for the whole set (8 channels x UN dwordx4 per lane).
+// Destination planes have odd strides: dword LDS stores.
+template <int UN, int NCH>
+__device__ __forceinline__ void wave_copy_runs_n(const float *__restrict__ g, size_t cs, float *__restrict__ d, int plane,
+                                                 int run, int lane)
+{
+    const int nfull = run >> 2;
+    for (int c0 = 0; c0 < nfull; c0 += 64 * UN) {
+        f32x4ua v[NCH][UN];
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+            for (int u = 0; u < UN; ++u) // branch-free: chunks past the end are clamped to the last one (idempotent)
+                v[ch][u] = *reinterpret_cast<const f32x4ua *>(g + ch * cs + 4 * min(c0 + u * 64 + lane, nfull - 1));
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                float *o = d + ch * plane + 4 * min(c0 + u * 64 + lane, nfull - 1);
+                o[0] = v[ch][u].x; o[1] = v[ch][u].y; o[2] = v[ch][u].z; o[3] = v[ch][u].w;
+            }
+    }
+    const int t = (nfull << 2) + lane; // < 4 leftover floats per channel
+    if (t < run) {
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) d[ch * plane + t] = g[ch * cs + t];
+    }
+}
+
 struct XfScale { // x / scale with the exact 3-op path for 255
     float scale;
     __device__ __forceinline__ float operator()(float v) const
@@ -650,27 +680,19 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, 1) void k_wgrad32(WgradArgs a)
         const float *sz = a.dz + ((size_t)b * 32 * a.Ho + y0) * a.Wo;
         const size_t csA = (size_t)a.Hi * a.Wi, csZ = (size_t)a.Ho * a.Wo;
         float *ldsA = lds + bi * bufw, *ldsZ = ldsA + 32 * planeA;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int c = 8 * lw + 2 * k;
-            wave_copy_runs2<2, false>(src + c * csA, src + (c + 1) * csA, ldsA + c * planeA, ldsA + (c + 1) * planeA, runA, lane,
-                                      XfId());
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int c = 8 * lw + 2 * k;
-            wave_copy_runs2<1, false>(sz + c * csZ, sz + (c + 1) * csZ, ldsZ + c * planeZ, ldsZ + (c + 1) * planeZ, runZ, lane,
-                                      XfId());
-        }
+        // all 8 channels of a tile in flight at once: TWO exposed memory latencies per strip (A, dZ) instead of eight --
+        // the loaders, walking channel pair after channel pair, needed as long per strip as the MFMA waves
+        wave_copy_runs_n<2, 8>(src + (size_t)(8 * lw) * csA, csA, ldsA + 8 * lw * planeA, planeA, runA, lane);
+        wave_copy_runs_n<1, 8>(sz + (size_t)(8 * lw) * csZ, csZ, ldsZ + 8 * lw * planeZ, planeZ, runZ, lane);
     };
 
     // ABL == 4 (tools/ebench only): accumulating wave 0 of workgroup 0 logs (event, shader clock) behind the slabs:
     // 0 strip start, 4 before / 5 after the strip's barrier, 6 loop done, 7 slab written
     unsigned long long *dbg = nullptr;
     int ndbg = 0;
-    if (ABL == 4 && blockIdx.x == 0 && wave == 0) dbg = reinterpret_cast<unsigned long long *>(a.partial + (size_t)gridDim.x * WG_SLAB + 8 * WG_SLAB);
+    if ((ABL == 4 || ABL == 5) && blockIdx.x == 0 && wave == 0) dbg = reinterpret_cast<unsigned long long *>(a.partial + (size_t)gridDim.x * WG_SLAB + 8 * WG_SLAB);
     auto stamp = [&](int id) {
-        if (ABL == 4 && dbg != nullptr && ndbg < 500) {
+        if ((ABL == 4 || ABL == 5) && dbg != nullptr && ndbg < 500) {
             const unsigned long long t = __builtin_amdgcn_s_memtime();
             if (lane == 0) dbg[ndbg] = (t << 4) | (unsigned)id;
             ++ndbg;
@@ -694,7 +716,7 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, 1) void k_wgrad32(WgradArgs a)
         if (SPLIT && loader && next < a.n_items && ABL != 1) stage(next, (it + 1) & 1);
         __builtin_amdgcn_sched_barrier(0);
         if (!loader) {
-            if (ABL == 4) stamp(0);
+            if (ABL == 4 || ABL == 5) stamp(0);
             const int s = item % a.S;
             const int y0 = s * a.RT;
             const int rows = min(a.RT, a.Ho - y0);
@@ -739,16 +761,18 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, 1) void k_wgrad32(WgradArgs a)
                 mf(cur, 0);
                 AUGCL_SB();
                 const float *pz = reinterpret_cast<const float *>(zc + tn.x), *pa = reinterpret_cast<const float *>(ac + tn.y);
-                tp += 8;
-                tn = *tp;
+                if (ABL != 5) { // (ABL 5, tools/ebench: the MFMA loop without its operand fetch)
+                    tp += 8;
+                    tn = *tp;
+                }
                 AUGCL_SB();
                 if (ABL != 2) mf(cur, 1);
                 AUGCL_SB();
-                rd1(pa, pz, nxt);
+                if (ABL != 5) rd1(pa, pz, nxt);
                 AUGCL_SB();
                 if (ABL != 2) mf(cur, 2);
                 AUGCL_SB();
-                rd2(pa, nxt);
+                if (ABL != 5) rd2(pa, nxt);
                 AUGCL_SB();
                 if (ABL != 2) {
 #pragma unroll
@@ -774,11 +798,11 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, 1) void k_wgrad32(WgradArgs a)
 #undef AUGCL_SB
         }
         if (!SPLIT && next < a.n_items && ABL != 1) commit(next, (it + 1) & 1, pf);
-        if (ABL == 4 && !loader) stamp(4);
+        if ((ABL == 4 || ABL == 5) && !loader) stamp(4);
         __syncthreads();
-        if (ABL == 4 && !loader) stamp(5);
+        if ((ABL == 4 || ABL == 5) && !loader) stamp(5);
     }
-    if (ABL == 4 && !loader) stamp(6);
+    if ((ABL == 4 || ABL == 5) && !loader) stamp(6);
     // ---- fixed-order reduction over the 4 waves through LDS, then one slab per workgroup
     // lane (ci = l31, h) holds dW[co = acc_row(r,h)][ci][t] in acc[t][r]
     float *slab = a.partial + (size_t)blockIdx.x * WG_SLAB;

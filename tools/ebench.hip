@@ -259,17 +259,18 @@ int main(int argc, char **argv)
     vs.push_back({"wgrad pair loop: + addresses", 2.0 * 32 * 32 * 2 * 9 * 4000.0 * 4 * 256, [&] { hipLaunchKernelGGL(k_wg_pair<2>, dim3(256), dim3(256), 0, 0, out, 4000, 0.5f); }});
     vs.push_back({"wgrad pair loop: + select/sum", 2.0 * 32 * 32 * 2 * 9 * 4000.0 * 4 * 256, [&] { hipLaunchKernelGGL(k_wg_pair<3>, dim3(256), dim3(256), 0, 0, out, 4000, 0.5f); }});
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    if (argc > 3 && atoi(argv[3]) == -3) { // per-strip shader-clock stamps of k_wgrad32<4, false, true>, workgroup 0 / wave 0
+    if (argc > 3 && (atoi(argv[3]) == -3 || atoi(argv[3]) == -4)) { // -4: the same without the operand fetch (ABL 5) // per-strip shader-clock stamps of k_wgrad32<4, false, true>, workgroup 0 / wave 0
         WgradArgs a{}; a.act = in; a.dz = out; a.partial = ws; a.B = B; a.Hi = H; a.Wi = H; a.Ho = H - 2; a.Wo = H - 2;
         int rt = (kBufLds / 4 - 64 * H - 64 - 32 - 600) / (32 * H + 32 * a.Wo); rt = std::min(rt, std::min(512 / H - 2, 256 / a.Wo)); if (rt > a.Ho) rt = a.Ho;
         a.S = (a.Ho + rt - 1) / rt; a.RT = (a.Ho + a.S - 1) / a.S; a.n_items = B * a.S;
         const int planeA = ((a.RT + 2) * H) | 1, planeZ = (a.RT * a.Wo + 1) | 1; size_t lds = 2 * (size_t)(32 * planeA + 32 * planeZ) * 4 + (size_t)2 * 2 * (((a.RT * a.Wo + 1) >> 1) + 8) * 8;
         const int grid = grid_for(a.n_items, 1);
-        set_lds(k_wgrad32<4, false, true>, lds, "x");
+        const bool nofetch = atoi(argv[3]) == -4;
+        if (nofetch) set_lds(k_wgrad32<5, false, true>, lds, "x"); else set_lds(k_wgrad32<4, false, true>, lds, "x");
         unsigned long long *dbg = reinterpret_cast<unsigned long long *>(ws + (size_t)grid * WG_SLAB + 8 * WG_SLAB);
         if ((size_t)(grid + 8) * WG_SLAB * 4 + 500 * 8 > wsb + 8192) { printf("workspace too small for stamps\n"); return 1; }
         CK(hipMemset(dbg, 0, 500 * 8));
-        for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL((k_wgrad32<4, false, true>), dim3(grid), dim3(512), lds, 0, a);
+        for (int rep = 0; rep < 3; ++rep) { if (nofetch) hipLaunchKernelGGL((k_wgrad32<5, false, true>), dim3(grid), dim3(512), lds, 0, a); else hipLaunchKernelGGL((k_wgrad32<4, false, true>), dim3(grid), dim3(512), lds, 0, a); }
         CK(hipDeviceSynchronize());
         printf("RT=%d S=%d npix=%d pairs/wave=%.1f items/WG=%.1f\n", a.RT, a.S, a.RT * a.Wo, a.RT * a.Wo / 8.0, (double)a.n_items / grid);
         std::vector<unsigned long long> hd(500); CK(hipMemcpy(hd.data(), dbg, 500 * 8, hipMemcpyDeviceToHost));
