@@ -106,7 +106,7 @@ __device__ __forceinline__ void wave_copy_runs2(const float *__restrict__ g0, co
 // NCH channels (stride cs in global memory, stride plane in LDS) of one contiguous run each, ALL loads of the batch in
 // flight before the first LDS write: one exposed memory latency for the whole set (8 channels x UN dwordx4 per lane).
 // Destination planes have odd strides: dword LDS stores.
-template <int UN, int NCH>
+template <int UN, int NCH, bool VECST = false>
 __device__ __forceinline__ void wave_copy_runs_n(const float *__restrict__ g, size_t cs, float *__restrict__ d, int plane,
                                                  int run, int lane)
 {
@@ -123,7 +123,11 @@ __device__ __forceinline__ void wave_copy_runs_n(const float *__restrict__ g, si
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
                 float *o = d + ch * plane + 4 * min(c0 + u * 64 + lane, nfull - 1);
-                o[0] = v[ch][u].x; o[1] = v[ch][u].y; o[2] = v[ch][u].z; o[3] = v[ch][u].w;
+                if (VECST) { // 16-byte aligned planes: one ds_write_b128
+                    *reinterpret_cast<float4 *>(o) = make_float4(v[ch][u].x, v[ch][u].y, v[ch][u].z, v[ch][u].w);
+                } else {
+                    o[0] = v[ch][u].x; o[1] = v[ch][u].y; o[2] = v[ch][u].z; o[3] = v[ch][u].w;
+                }
             }
     }
     const int t = (nfull << 2) + lane; // < 4 leftover floats per channel
@@ -190,13 +194,10 @@ __global__ __launch_bounds__(512, 2) void k_conv32(ConvArgs a)
         const float *src = a.in + ((size_t)b * 32 * a.Hi + r0) * Wi;
         const size_t cs = (size_t)a.Hi * Wi;
         float *dst = lds_raw + bi * bufw;
-        if (MODE == 0) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int ci = 8 * cw + 2 * k;
-                wave_copy_runs2<3>(src + ci * cs, src + (ci + 1) * cs, dst + ci * plane, dst + (ci + 1) * plane, run, lane,
-                                   XfId());
-            }
+        if (MODE == 0) { // four channels in flight at a time: two exposed memory latencies per strip (eight would not fit
+                         // the register budget next to the MFMA waves' 228)
+            wave_copy_runs_n<3, 4, true>(src + (size_t)(8 * cw) * cs, cs, dst + 8 * cw * plane, plane, run, lane);
+            wave_copy_runs_n<3, 4, true>(src + (size_t)(8 * cw + 4) * cs, cs, dst + (8 * cw + 4) * plane, plane, run, lane);
             return;
         }
         // MODE 1: tile row j = dZ row (y0 - 2 + j) at words [j * pitch + 2, j * pitch + 2 + Wi) of its channel plane
@@ -217,7 +218,8 @@ __global__ __launch_bounds__(512, 2) void k_conv32(ConvArgs a)
                 d8[c * plane + j * pitch + 2 + x] = 0.0f;
             }
         }
-        // row by row, lanes along x: 4 channels x 8 rows = 32 dwords per lane in flight, then 32 conflict-free ds_write_b32 at
+        // row by row, lanes along x: 4 channels x 8 rows = 32 dwords per lane in flight (64 spill next to the MFMA waves' 247
+        // registers: +6 %), then 32 conflict-free ds_write_b32 at
         // row base + immediate -- no per-element address arithmetic (a chunked copy of the contiguous run needs a division
         // per element to find its row, and made the loaders the slower half of the pipeline; walking the (channel, row)
         // pairs as one list without the duplicate rows of a ragged last batch measured 20 % slower: scalar bookkeeping)
