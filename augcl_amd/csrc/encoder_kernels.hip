@@ -194,10 +194,8 @@ __global__ __launch_bounds__(512, 2) void k_conv32(ConvArgs a)
         const float *src = a.in + ((size_t)b * 32 * a.Hi + r0) * Wi;
         const size_t cs = (size_t)a.Hi * Wi;
         float *dst = lds_raw + bi * bufw;
-        if (MODE == 0) { // four channels in flight at a time: two exposed memory latencies per strip (eight would not fit
-                         // the register budget next to the MFMA waves' 228)
-            wave_copy_runs_n<3, 4, true>(src + (size_t)(8 * cw) * cs, cs, dst + 8 * cw * plane, plane, run, lane);
-            wave_copy_runs_n<3, 4, true>(src + (size_t)(8 * cw + 4) * cs, cs, dst + (8 * cw + 4) * plane, plane, run, lane);
+        if (MODE == 0) { // the wave's 8 channels in flight at once: ONE exposed memory latency per strip
+            wave_copy_runs_n<3, 8, true>(src + (size_t)(8 * cw) * cs, cs, dst + 8 * cw * plane, plane, run, lane);
             return;
         }
         // MODE 1: tile row j = dZ row (y0 - 2 + j) at words [j * pitch + 2, j * pitch + 2 + Wi) of its channel plane
@@ -218,27 +216,25 @@ __global__ __launch_bounds__(512, 2) void k_conv32(ConvArgs a)
                 d8[c * plane + j * pitch + 2 + x] = 0.0f;
             }
         }
-        // row by row, lanes along x: 4 channels x 8 rows = 32 dwords per lane in flight (64 spill next to the MFMA waves' 247
-        // registers: +6 %), then 32 conflict-free ds_write_b32 at
+        // row by row, lanes along x: 8 channels x 8 rows = 64 dwords per lane in flight, then 64 conflict-free ds_write_b32 at
         // row base + immediate -- no per-element address arithmetic (a chunked copy of the contiguous run needs a division
         // per element to find its row, and made the loaders the slower half of the pipeline; walking the (channel, row)
         // pairs as one list without the duplicate rows of a ragged last batch measured 20 % slower: scalar bookkeeping)
         for (int x0 = 0; x0 < Wi; x0 += 64) {
             const int x = min(x0 + lane, Wi - 1); // lanes past the row end repeat its last word
+            {
+                const float *s8 = src + (size_t)(8 * cw) * cs + x;
+                float *dd = d8 + top * pitch + 2 + x;
+                for (int rb = 0; rb < nrow; rb += 8) { // ceil(nrow / 8) exposed latencies per strip
+                    float v[8][8];
 #pragma unroll
-            for (int hc = 0; hc < 2; ++hc) {
-                const float *s4 = src + (size_t)(8 * cw + 4 * hc) * cs + x;
-                float *d4 = d8 + 4 * hc * plane + top * pitch + 2 + x;
-                for (int rb = 0; rb < nrow; rb += 8) {
-                    float v[4][8];
+                    for (int c = 0; c < 8; ++c)
 #pragma unroll
-                    for (int c = 0; c < 4; ++c)
+                        for (int r = 0; r < 8; ++r) v[c][r] = s8[c * cs + (size_t)min(rb + r, nrow - 1) * Wi];
 #pragma unroll
-                        for (int r = 0; r < 8; ++r) v[c][r] = s4[c * cs + (size_t)min(rb + r, nrow - 1) * Wi];
+                    for (int c = 0; c < 8; ++c)
 #pragma unroll
-                    for (int c = 0; c < 4; ++c)
-#pragma unroll
-                        for (int r = 0; r < 8; ++r) d4[c * plane + min(rb + r, nrow - 1) * pitch] = v[c][r];
+                        for (int r = 0; r < 8; ++r) dd[c * plane + min(rb + r, nrow - 1) * pitch] = v[c][r];
                 }
             }
         }
@@ -308,11 +304,19 @@ __global__ __launch_bounds__(512, 2) void k_conv32(ConvArgs a)
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(MODE == 1 && a.mask ? a.mask : a.in), 0, -1, 0x00020000);
 
     __syncthreads(); // the weights are in registers: buffer 1 may be overwritten
-    for (int item = first; item < n_end; item += NG, ++it) {
-        const int next = item + NG;
-        if (loader) {
+    // The two roles run SEPARATE loops with the same barrier sequence (one per strip): in a shared loop the 144 weight and 16
+    // accumulator registers of the compute waves are live across the loaders' branch as well and leave them ~60 registers
+    // for loads in flight; on their own the loaders have the whole file (fewer, larger batches = fewer exposed latencies).
+    if (loader) {
+        for (int item = first; item < n_end; item += NG, ++it) {
+            const int next = item + NG;
             if (next < n_end && ABL != 1) stage(next, (it + 1) & 1, it == 0);
-        } else {
+            __syncthreads();
+        }
+        return;
+    }
+    for (int item = first; item < n_end; item += NG, ++it) {
+        {
             const int b = item / a.S, s = item - b * a.S;
             const int y0 = s * a.RT;
             const int rows = min(a.RT, a.Ho - y0); // output rows of this strip
@@ -416,9 +420,9 @@ __global__ __launch_bounds__(512, 2) void k_conv32(ConvArgs a)
                 if (ABL == 4) stamp(2);
             }
         }
-        if (ABL == 4 && !loader) stamp(4);
+        if (ABL == 4) stamp(4);
         __syncthreads(); // next tile landed AND current tile's readers are done
-        if (ABL == 4 && !loader) stamp(5);
+        if (ABL == 4) stamp(5);
     }
 }
 
