@@ -686,10 +686,37 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, 1) void k_wgrad32(WgradArgs a)
         const float *sz = a.dz + ((size_t)b * 32 * a.Ho + y0) * a.Wo;
         const size_t csA = (size_t)a.Hi * a.Wi, csZ = (size_t)a.Ho * a.Wo;
         float *ldsA = lds + bi * bufw, *ldsZ = ldsA + 32 * planeA;
-        // all 8 channels of a tile in flight at once: TWO exposed memory latencies per strip (A, dZ) instead of eight --
-        // the loaders, walking channel pair after channel pair, needed as long per strip as the MFMA waves
-        wave_copy_runs_n<2, 8>(src + (size_t)(8 * lw) * csA, csA, ldsA + 8 * lw * planeA, planeA, runA, lane);
-        wave_copy_runs_n<1, 8>(sz + (size_t)(8 * lw) * csZ, csZ, ldsZ + 8 * lw * planeZ, planeZ, runZ, lane);
+        // all 8 channels of BOTH tiles in flight at once (the host caps an A run at 512 and a dZ run at 256 floats: 2 + 1
+        // dwordx4 per lane and channel): ONE exposed memory latency per strip instead of eight -- the loaders, walking
+        // channel pair after channel pair, needed as long per strip as the MFMA waves
+        {
+            const float *gA = src + (size_t)(8 * lw) * csA, *gZ = sz + (size_t)(8 * lw) * csZ;
+            float *dA = ldsA + 8 * lw * planeA, *dZ = ldsZ + 8 * lw * planeZ;
+            const int nfA = runA >> 2, nfZ = runZ >> 2;
+            f32x4ua va[8][2], vz[8];
+#pragma unroll
+            for (int ch = 0; ch < 8; ++ch) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) va[ch][u] = *reinterpret_cast<const f32x4ua *>(gA + ch * csA + 4 * min(u * 64 + lane, nfA - 1));
+                vz[ch] = *reinterpret_cast<const f32x4ua *>(gZ + ch * csZ + 4 * min(lane, nfZ - 1));
+            }
+#pragma unroll
+            for (int ch = 0; ch < 8; ++ch) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    float *o = dA + ch * planeA + 4 * min(u * 64 + lane, nfA - 1);
+                    o[0] = va[ch][u].x; o[1] = va[ch][u].y; o[2] = va[ch][u].z; o[3] = va[ch][u].w;
+                }
+                float *o = dZ + ch * planeZ + 4 * min(lane, nfZ - 1);
+                o[0] = vz[ch].x; o[1] = vz[ch].y; o[2] = vz[ch].z; o[3] = vz[ch].w;
+            }
+            const int tA = (nfA << 2) + lane, tZ = (nfZ << 2) + lane; // < 4 leftover floats per channel
+#pragma unroll
+            for (int ch = 0; ch < 8; ++ch) {
+                if (tA < runA) dA[ch * planeA + tA] = gA[ch * csA + tA];
+                if (tZ < runZ) dZ[ch * planeZ + tZ] = gZ[ch * csZ + tZ];
+            }
+        }
     };
 
     // ABL == 4 (tools/ebench only): accumulating wave 0 of workgroup 0 logs (event, shader clock) behind the slabs:
@@ -716,12 +743,24 @@ __global__ __launch_bounds__(SPLIT ? 512 : 256, 1) void k_wgrad32(WgradArgs a)
         }
     }
     __syncthreads();
+    if (SPLIT && loader) { // the loaders' own loop (same barriers as the accumulating waves' loop and reduction below): in a
+        // shared loop the 144 accumulator registers stay live across the loaders' branch and cap their loads in flight
+        for (int item = first; item < a.n_items; item += gridDim.x, ++it) {
+            const int next = item + gridDim.x;
+            if (next < a.n_items && ABL != 1) stage(next, (it + 1) & 1);
+            __syncthreads();
+        }
+        for (int w = 1; w < 4; ++w) {
+            __syncthreads();
+            __syncthreads();
+        }
+        return;
+    }
     for (int item = first; item < a.n_items; item += gridDim.x, ++it) {
         const int next = item + gridDim.x;
         if (!SPLIT && next < a.n_items && ABL != 1) issue(next, pf);
-        if (SPLIT && loader && next < a.n_items && ABL != 1) stage(next, (it + 1) & 1);
         __builtin_amdgcn_sched_barrier(0);
-        if (!loader) {
+        {
             if (ABL == 4 || ABL == 5) stamp(0);
             const int s = item % a.S;
             const int y0 = s * a.RT;
