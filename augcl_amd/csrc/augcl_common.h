@@ -42,7 +42,7 @@ inline int extra_strips(int kind, int W)
     if (const char *e = getenv("AUGCL_EXTRA_STRIPS")) return atoi(e);
 #endif
     switch (kind) {
-    case 0: return W == 41 ? 4 : W == 39 ? 1 : W == 37 ? 2 : 0;
+    case 0: return W == 41 ? 4 : W == 37 ? 2 : 0;
     case 1: return W == 39 ? 4 : W == 33 ? 2 : W == 23 ? 4 : 0; // re-measured for the zero-padded dZ tile (pitch W + 2)
     case 2: return W == 41 ? 2 : W == 39 ? 4 : 0;
     case 3: return W == 39 ? 2 : W == 33 ? 2 : 0;
