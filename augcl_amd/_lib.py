@@ -111,6 +111,9 @@ _SIGS = {
     "augcl_enc_conv32_forward": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "augcl_enc_conv32_backward_data": [_P, _P, _P, _P, _I, _I, _I, _P],
     "augcl_enc_wgrad_workspace_bytes": [_I],
+    "augcl_enc_x3_conv32_forward": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "augcl_enc_x3_conv32_backward_data": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "augcl_enc_x3_conv32_backward_weights": [_P, _P, _P, _P, _P, _SZ, _I, _I, _I, _P],
     "augcl_enc_conv32_backward_weights": [_P, _P, _P, _P, _P, _SZ, _I, _I, _I, _P],
     "augcl_enc_conv_first_backward_weights": [_P, _P, _P, _P, _P, _SZ, _I, _I, _I, _I, _I, _F, _P],
 }

@@ -7,21 +7,23 @@ extern "C" {
 
 static inline int out_hw(int h, int stride) { return (h - 3) / stride + 1; }
 
-// precision: 0 = f32 NCHW activations (parity path), 1 = bf16 NHWC activations (performance mode).
+// precision: 0 = f32 NCHW activations, f32 MFMA; 1 = bf16 NHWC activations (performance mode); 2 = f32 NCHW activations
+// with the 32 -> 32 layers on the split-bf16 kernels (float32-accurate products on the bf16 pipe: the parity path).
 // acts_out[i] = output buffer of layer i; the last layer always writes f32 NCHW.
 int augcl_enc_stack_forward(const float *x, const float *const *w, const float *const *b, void *const *acts_out,
                             int n_layers, int B, int C, int H, int W, int first_stride, float scale, int precision,
                             augcl_stream_t stream)
 {
     AUGCL_REQUIRE(x && w && b && acts_out && n_layers >= 1, "augcl_enc_stack_forward: bad argument");
-    AUGCL_REQUIRE(precision == 0 || n_layers >= 2, "augcl_enc_stack_forward: bf16 mode needs >= 2 layers");
+    AUGCL_REQUIRE(precision >= 0 && precision <= 2, "augcl_enc_stack_forward: precision must be 0, 1 or 2");
+    AUGCL_REQUIRE(precision != 1 || n_layers >= 2, "augcl_enc_stack_forward: bf16 mode needs >= 2 layers");
     int h = H, ww = W, rc;
     const void *cur = x;
     for (int i = 0; i < n_layers; ++i) {
         const int relu = i < n_layers - 1;
         const bool last = i == n_layers - 1;
         if (i == 0) {
-            if (precision == 0)
+            if (precision != 1)
                 rc = augcl_enc_conv_first_forward(x, w[0], b[0], (float *)acts_out[0], B, C, h, ww, first_stride, scale, relu,
                                                   stream);
             else
@@ -32,6 +34,8 @@ int augcl_enc_stack_forward(const float *x, const float *const *w, const float *
         } else {
             if (precision == 0)
                 rc = augcl_enc_conv32_forward((const float *)cur, w[i], b[i], (float *)acts_out[i], B, h, ww, relu, stream);
+            else if (precision == 2)
+                rc = augcl_enc_x3_conv32_forward((const float *)cur, w[i], b[i], (float *)acts_out[i], B, h, ww, relu, stream);
             else
                 rc = augcl_enc_bf16_conv32_forward(cur, w[i], b[i], acts_out[i], B, h, ww, relu, last ? 1 : 0, stream);
             h -= 2;
@@ -46,6 +50,9 @@ int augcl_enc_stack_forward(const float *x, const float *const *w, const float *
 int augcl_internal_conv32_forward_dual(const float *in, const float *w, const float *bias, const float *w2,
                                        const float *bias2, float *out, int B2, int Hi, int Wi, int relu,
                                        augcl_stream_t stream);
+int augcl_internal_x3_conv32_forward_dual(const float *in, const float *w, const float *bias, const float *w2,
+                                          const float *bias2, float *out, int B2, int Hi, int Wi, int relu,
+                                          augcl_stream_t stream);
 int augcl_internal_bf16_conv32_forward_dual(const void *in_bf16_nhwc, const float *w, const float *bias, const float *w2,
                                             const float *bias2, void *out, int B2, int Hi, int Wi, int relu,
                                             int out_f32_nchw, augcl_stream_t stream);
@@ -71,6 +78,9 @@ int augcl_enc_stack_forward_dual(const float *x, const float *const *wA, const f
         if (precision == 0)
             rc = augcl_internal_conv32_forward_dual((const float *)acts_out[i - 1], wA[i], bA[i], wB[i], bB[i],
                                                     (float *)acts_out[i], B2, h, ww, relu, stream);
+        else if (precision == 2)
+            rc = augcl_internal_x3_conv32_forward_dual((const float *)acts_out[i - 1], wA[i], bA[i], wB[i], bB[i],
+                                                       (float *)acts_out[i], B2, h, ww, relu, stream);
         else
             rc = augcl_internal_bf16_conv32_forward_dual(acts_out[i - 1], wA[i], bA[i], wB[i], bB[i], acts_out[i], B2, h, ww,
                                                          relu, i == n_layers - 1 ? 1 : 0, stream);
@@ -118,6 +128,9 @@ int augcl_enc_stack_backward(const void *const *acts_in, const float *const *w, 
         if (precision == 0)
             rc = augcl_enc_conv32_backward_weights((const float *)acts_in[i], (const float *)dz, dw[i], db[i], ws_i, ws_i_bytes, B,
                                                    hs[i], wsz[i], stream);
+        else if (precision == 2)
+            rc = augcl_enc_x3_conv32_backward_weights((const float *)acts_in[i], (const float *)dz, dw[i], db[i], ws_i, ws_i_bytes,
+                                                      B, hs[i], wsz[i], stream);
         else if (bf16_wgrad_mfma)
             rc = augcl_enc_bf16_conv32_backward_weights_mfma(acts_in[i], dz, dw[i], db[i], ws_i, ws_i_bytes, B, hs[i], wsz[i],
                                                              stream);
@@ -127,13 +140,16 @@ int augcl_enc_stack_backward(const void *const *acts_in, const float *const *w, 
         if (precision == 0)
             rc = augcl_enc_conv32_backward_data((const float *)dz, w[i], (const float *)acts_in[i], (float *)nxt, B, hs[i + 1],
                                                 wsz[i + 1], stream);
+        else if (precision == 2)
+            rc = augcl_enc_x3_conv32_backward_data((const float *)dz, w[i], (const float *)acts_in[i], (float *)nxt, B, hs[i + 1],
+                                                   wsz[i + 1], stream);
         else
             rc = augcl_enc_bf16_conv32_backward_data(dz, w[i], acts_in[i], nxt, B, hs[i + 1], wsz[i + 1], stream);
         if (rc != AUGCL_OK) return rc;
         dz = nxt;
         nxt = (nxt == dz_a) ? dz_b : dz_a;
     }
-    if (precision == 0)
+    if (precision != 1)
         rc = augcl_enc_conv_first_backward_weights((const float *)acts_in[0], (const float *)dz, dw[0], db[0], ws_first,
                                                    ws_first_bytes, B, C, H, W, first_stride, scale, stream);
     else

@@ -1,0 +1,765 @@
+// encoder_x3.hip -- the 32 -> 32 layers of the shared conv encoder (src/algorithms/modules.py:145-165) with
+// FLOAT32-ACCURATE products on the bf16 matrix pipe: the parity path past the f32-MFMA wall.
+//
+// v_mfma_f32_32x32x2_f32 runs at the f32 vector rate (64 FLOP/clk/SIMD), v_mfma_f32_32x32x16_bf16 at 16x that.  Every
+// float32 is EXACTLY the sum of three bf16 numbers (24 significand bits = 3 x 8: x = hi + mid + lo with hi = bf16(x),
+// mid = bf16(x - hi), lo = bf16(x - hi - mid), each residual exact in f32), a bf16 x bf16 product is exact in f32, and
+// the MFMA accumulates in f32.  Of the nine cross products of w = wh + wm + wl and x = xh + xm + xl the six with
+// weight >= 2^-16 -- hh, hm, mh, hl, lh, mm -- carry everything float32 can resolve: measured on this chip
+// (tools/x3probe.hip, K = 288, against float64) 2.6e-7 relative L2 for the six terms, the SAME for all nine, 3.0e-7 for
+// the native f32 MFMA chain and 2.8e-6 with five terms.  Six bf16 MFMAs replace eight f32 MFMAs of twice the duration:
+// 2.67x the matrix rate at float32 accuracy, activations / gradients stay f32 NCHW in HBM, so every other kernel
+// (first layer, projection, heads) is untouched.
+//
+//   forward / backward-data (k_conv32_x3): 4 LOADER waves read the strip's f32 NCHW rows (dwordx4 along x, 8 channels per
+//     lane), split every value on the VALU and write the three bf16 planes PIXEL-MAJOR into a double-buffered LDS tile
+//     (pixel slot = hi | mid | lo x 32 channels + pad = 208 B: a tap's operand is one conflict-free ds_read_b128 at
+//     row base + immediate); 4 COMPUTE waves keep the weights' hi and mid fragments in registers (144 VGPRs), read the lo
+//     fragment and the three pixel fragments from LDS, issue 6 MFMAs per (tap, channel half) = 108 per 32-pixel tile
+//     (3456 cycles instead of 9216) and store f32 NCHW with the f32 kernels' epilogue (pixels on lanes: coalesced
+//     rows, bias / ReLU / ReLU gate fused).
+//   backward-weights (k_wgrad32_x3): D_t[co][ci] = sum_p dZ[p][co] A[p + tap_t][ci], 16 pixels per MFMA; both operands are
+//     split by the loaders, ds_read_b64_tr_b16 delivers the pixel-major tiles transposed; per-workgroup slabs + the
+//     fixed-order reduction of the f32 path (bitwise reproducible).
+#include "augcl_common.h"
+
+#include <algorithm>
+
+namespace augcl {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t vu4 __attribute__((ext_vector_type(4))); // native vectors: register arrays of them stay in registers
+typedef float vf4 __attribute__((ext_vector_type(4)));
+typedef float vf4ua __attribute__((ext_vector_type(4), aligned(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int X3_SLOT = 208;        // LDS bytes per pixel slot: 3 planes x 64 B + 16 B pad (52 p mod 64: 16 consecutive
+                                    // pixels x one 16-byte chunk fall into 16 distinct bank quads)
+constexpr int X3_NU = 2;            // loader rounds per strip: 256 lanes x X3_NU units of (4 pixels x 8 channels)
+constexpr int X3_WROW = 292;        // f32 weight staging row pitch (16-byte aligned rows, conflict-free reads)
+constexpr int X3_WST = 32 * X3_WROW * 4;
+constexpr int X3_WLF = 18 * 64 * 16; // the weights' lo fragments: [18 operands][64 lanes] x 16 B
+constexpr int X3_MAXTILE = 70912;   // bytes per tile buffer: 2 x this + lo fragments + bias <= 160 KiB
+
+__device__ __forceinline__ int acc_row_x(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b) // v_cvt_pk_bf16_f32: (lo half = a, hi half = b), RNE
+{
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, bf16x2));
+}
+__device__ __forceinline__ float bf_lo(uint32_t p) { return __uint_as_float(p << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t p) { return __uint_as_float(p & 0xffff0000u); }
+
+// two floats -> their (hi, mid, lo) bf16 pairs; hi + mid + lo == the float, exactly (both residuals are exact in f32)
+__device__ __forceinline__ void split2(float a, float b, uint32_t &h, uint32_t &m, uint32_t &l)
+{
+    h = pk_bf16(a, b);
+    const float ra = a - bf_lo(h), rb = b - bf_hi(h);
+    m = pk_bf16(ra, rb);
+    l = pk_bf16(ra - bf_lo(m), rb - bf_hi(m));
+}
+
+struct ConvX3Args {
+    const float *in;     // forward: a_{l-1} (post-ReLU) (B,32,Hi,Wi);  bwd-data: dZ_l
+    const float *w;      // (32,32,3,3) forward weights
+    const float *bias;   // (32) or null                       [MODE 0]
+    const float *mask;   // a_{l-1} (B,32,Ho,Wo) or null       [MODE 1]
+    float *out;          // (B,32,Ho,Wo)
+    int B, Hi, Wi, Ho, Wo, RT, S, relu, n_items;
+    uint32_t magic_wo;   // floor(2^32 / Wo) + 1
+    uint32_t magic_qw;   // MODE 1: floor(2^32 / QW) + 1, QW = quads per dZ row
+    const float *w2, *bias2; // two-weight-set forward: images [B/2, B) use w2 / bias2 (odd workgroups)
+    int dual;
+};
+
+// MODE 0: forward (valid 3x3).  MODE 1: backward-data = full correlation of dZ with the flipped, transposed weights; its
+// LDS tile keeps every dZ row with 2 zero pixels in front (which double as the 2 behind the previous row) and zero rows
+// outside the image, so no tap needs masking.
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void k_conv32_x3(ConvX3Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) char ldsx[];
+    // LDS: [lo fragments of the weights][bias][tile buffer 0][tile buffer 1]; the f32 weights are staged over buffer 1
+    constexpr int P = MODE ? 2 : 0;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = wave >= 4;
+    const int cw = wave & 3;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int Wi = a.Wi;
+    const int Wl = MODE ? Wi + 2 : Wi;                     // LDS row pitch in pixels
+    const int tilepix = (a.RT + 2) * Wl + (MODE ? 2 : 0);
+    const int bufbytes = max(tilepix * X3_SLOT, X3_WST);
+    char *wlf = ldsx;
+    float *lbias = reinterpret_cast<float *>(ldsx + X3_WLF);
+    char *tiles = ldsx + X3_WLF + 128;
+    const int grp = a.dual ? (int)(blockIdx.x & 1) : 0, nhalf = a.n_items >> 1;
+    const int first = a.dual ? grp * nhalf + (int)(blockIdx.x >> 1) : xcd_slot((int)blockIdx.x, (int)gridDim.x);
+    const int NG = a.dual ? (int)(gridDim.x >> 1) : (int)gridDim.x;
+    const int n = a.dual ? (grp + 1) * nhalf : a.n_items;
+
+    // ---- weights: all 512 threads copy the 36 KB of f32 masters into LDS with coalesced 16-byte loads (the region of tile
+    // buffer 1, which the loaders first write after the second barrier)
+    {
+        float *wst = reinterpret_cast<float *>(tiles + bufbytes);
+        const vf4 *w4 = reinterpret_cast<const vf4 *>(grp ? a.w2 : a.w);
+        const float *bsrc = grp ? a.bias2 : a.bias;
+        for (int i = tid; i < 32 * 288 / 4; i += 512) {
+            const int row = (4 * i) / 288, col = 4 * i - row * 288;
+            *reinterpret_cast<vf4 *>(wst + row * X3_WROW + col) = w4[i];
+        }
+        if (tid < 32) lbias[tid] = (MODE == 0 && bsrc) ? bsrc[tid] : 0.0f;
+    }
+    __syncthreads();
+
+    // The two roles run DIFFERENT code with the same barrier sequence (2 + one per item): the branch is wave-uniform, and
+    // the separate branches keep the loaders' prefetch registers and the compute waves' weight fragments apart.
+    if (loader) {
+        // unit = (4 consecutive pixels of the strip's input rows) x (8 channels): 8 dwordx4 loads (4-byte aligned: rows
+        // are W floats wide), then per pixel one split of its 8 channels and three 16-byte LDS stores.  A strip is
+        // X3_NU rounds; the loader runs TWO strips ahead: strip i is read from LDS buffer i&1, strip i+1 is written into
+        // the other buffer from registers whose loads were issued two iterations ago, strips i+2 / i+3 are in flight.
+        const int lt = cw * 64 + lane; // 0..255 among the loader threads
+        struct Regs {
+            vf4ua d[X3_NU][8];
+        };
+        struct Geo {
+            int b, y0, rows, r0, r1, rbase, nq;
+        };
+        const int QW = (Wi + 3) >> 2; // MODE 1: quads per dZ row (the last one overlaps its neighbour)
+        auto geom = [&](int item) {
+            Geo g;
+            g.b = item / a.S;
+            const int s = item - g.b * a.S;
+            g.y0 = s * a.RT;
+            g.rows = min(a.RT, a.Ho - g.y0);
+            g.rbase = g.y0 - P;                                   // image row of tile row 0
+            g.r0 = MODE ? max(0, g.rbase) : g.y0;                 // image rows [r0, r1) exist
+            g.r1 = MODE ? min(a.Hi, g.y0 + g.rows) : g.y0 + g.rows + 2;
+            g.nq = MODE ? (g.r1 - g.r0) * QW : ((g.r1 - g.r0) * Wi + 3) >> 2;
+            return g;
+        };
+        // unit -> (channel group cg, first pixel as an offset into the channel plane of the image, LDS pixel of it)
+        auto locate = [&](const Geo &g, int u, int &cg, int &goff, int &lp) {
+            const int unit = u * 256 + lt;
+            cg = unit & 3;
+            const int qd = min(unit >> 2, g.nq - 1); // branch-free: units past the strip repeat its last quad (idempotent)
+            if (MODE == 0) {
+                const int p0 = min(4 * qd, (g.r1 - g.r0) * Wi - 4);
+                goff = g.r0 * Wi + p0;
+                lp = p0;
+            } else {
+                const int row = (int)__umulhi((uint32_t)qd, a.magic_qw), x0 = min(4 * (qd - row * QW), Wi - 4);
+                goff = (g.r0 + row) * Wi + x0;
+                lp = (row + g.r0 - g.rbase) * Wl + 2 + x0;
+            }
+        };
+        const size_t cs = (size_t)a.Hi * Wi;
+        auto issue = [&](int item, Regs &R) {
+            const Geo g = geom(item);
+#pragma unroll
+            for (int u = 0; u < X3_NU; ++u) {
+                int cg, goff, lp;
+                locate(g, u, cg, goff, lp);
+                const float *src = a.in + ((size_t)g.b * 32 + 8 * cg) * cs + goff;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) R.d[u][c] = *reinterpret_cast<const vf4ua *>(src + c * cs);
+            }
+        };
+        auto commit = [&](int item, int bi, const Regs &R, bool first_use) {
+            const Geo g = geom(item);
+            char *dst = tiles + bi * bufbytes;
+#pragma unroll
+            for (int u = 0; u < X3_NU; ++u) {
+                int cg, goff, lp;
+                locate(g, u, cg, goff, lp);
+                char *o = dst + lp * X3_SLOT + cg * 16;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    vu4 hi, mid, lo;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        uint32_t th, tm, tl;
+                        split2(R.d[u][2 * e][j], R.d[u][2 * e + 1][j], th, tm, tl);
+                        hi[e] = th; mid[e] = tm; lo[e] = tl;
+                    }
+                    *reinterpret_cast<vu4 *>(o + j * X3_SLOT) = hi;
+                    *reinterpret_cast<vu4 *>(o + j * X3_SLOT + 64) = mid;
+                    *reinterpret_cast<vu4 *>(o + j * X3_SLOT + 128) = lo;
+                }
+            }
+            if (MODE == 1) {
+                const vu4 zero = {0u, 0u, 0u, 0u};
+                // the 2 pad pixels in front of every tile row (and behind the last one): data never lands on them, so once
+                // per buffer is enough (12 chunks of 16 B per pixel slot)
+                if (first_use)
+                    for (int id = lt; id < (a.RT + 3) * 24; id += 256) {
+                        const int pr = id / 24, rem = id - pr * 24, px = rem / 12, ch = rem - px * 12;
+                        *reinterpret_cast<vu4 *>(dst + (pr * Wl + px) * X3_SLOT + ch * 16) = zero;
+                    }
+                // tile rows above / below the image (first / last strip)
+                const int top = g.r0 - g.rbase, bot = g.rbase + g.rows + 2 - g.r1, rowch = Wi * 12;
+                for (int id = lt; id < (top + bot) * rowch; id += 256) {
+                    const int jr = id / rowch, rem = id - jr * rowch, x = rem / 12, ch = rem - x * 12;
+                    const int j = jr < top ? jr : (g.r1 - g.rbase) + (jr - top);
+                    *reinterpret_cast<vu4 *>(dst + (j * Wl + x + 2) * X3_SLOT + ch * 16) = zero;
+                }
+            }
+        };
+        Regs ra, rb;
+        if (first < n) {
+            issue(first, ra);
+            commit(first, 0, ra, true);
+        }
+        if (first + NG < n) issue(first + NG, ra);
+        if (first + 2 * NG < n) issue(first + 2 * NG, rb);
+        __syncthreads();
+        bool fresh1 = true;
+        for (int item = first; item < n; item += 2 * NG) {
+            if (item + NG < n) commit(item + NG, 1, ra, fresh1); // even half: the compute waves read buffer 0
+            fresh1 = false;
+            if (item + 3 * NG < n) issue(item + 3 * NG, ra);
+            __syncthreads();
+            if (item + NG >= n) break;
+            if (item + 2 * NG < n) commit(item + 2 * NG, 0, rb, false); // odd half: they read buffer 1
+            if (item + 4 * NG < n) issue(item + 4 * NG, rb);
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ---- compute waves.  Operand i = (tap t = i / 2, channel half s = i & 1); A fragment: W_eff[row l31][k = 16 s + 8 h + j][t].
+    // hi and mid parts live in registers for the whole launch, the lo part (one of the six products) is read from LDS.
+    bf16x8 wh[18], wm[18];
+    {
+        const float *wst = reinterpret_cast<const float *>(tiles + bufbytes);
+#pragma unroll
+        for (int i = 0; i < 18; ++i) {
+            const int t = i >> 1, s = i & 1;
+            vu4 fh, fm, fl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v0, v1;
+                if (MODE == 0) { // W[co = l31][ci = k][t]
+                    v0 = wst[l31 * X3_WROW + (16 * s + 8 * h + 2 * e) * 9 + t];
+                    v1 = wst[l31 * X3_WROW + (16 * s + 8 * h + 2 * e + 1) * 9 + t];
+                } else {         // W'[ci = l31][co = k][t] = W[co][ci][8 - t]
+                    v0 = wst[(16 * s + 8 * h + 2 * e) * X3_WROW + l31 * 9 + (8 - t)];
+                    v1 = wst[(16 * s + 8 * h + 2 * e + 1) * X3_WROW + l31 * 9 + (8 - t)];
+                }
+                uint32_t th, tm, tl;
+                split2(v0, v1, th, tm, tl);
+                fh[e] = th; fm[e] = tm; fl[e] = tl;
+            }
+            wh[i] = __builtin_bit_cast(bf16x8, fh);
+            wm[i] = __builtin_bit_cast(bf16x8, fm);
+            if ((i & 3) == cw) *reinterpret_cast<vu4 *>(wlf + (i * 64 + lane) * 16) = fl; // every wave computes the same values
+        }
+    }
+    const int rowb = Wl * X3_SLOT; // LDS bytes between tile rows
+    const int relu_floor = __builtin_amdgcn_readfirstlane(a.relu ? 0 : (int)0x80000000); // opaque: stays ONE v_max_i32
+    // raw buffer resources (base, stride 0, no bound, gfx9 dword-3 flags): offsets < 2^32 by the host's size check
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_mask =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(MODE == 1 && a.mask ? a.mask : a.in), 0, -1, 0x00020000);
+    const int chw = a.Ho * a.Wo; // 32-bit offsets: the host checks B*32*Ho*Wo < 2^30
+
+    auto compute = [&](int item, int bi) {
+        const int b = item / a.S, s = item - b * a.S;
+        const int y0 = s * a.RT;
+        const int rows = min(a.RT, a.Ho - y0);
+        const int npix = rows * a.Wo;
+        const char *tile = tiles + bi * bufbytes;
+        const int ntiles = (npix + 31) >> 5;
+        if (cw >= ntiles) return; // wave-uniform
+        // this lane's pixel of tile tl: index m in the strip, (yy, xx), the LDS byte of its top-left tap (both modes: tile
+        // row yy + ky, tile pixel xx + kx -- backward-data's +2 shift cancels its -2 taps) and its output byte offset
+        auto locate = [&](int tl, bool &valid_, int &off_, unsigned &boff_) {
+            int m_ = tl * 32 + l31;
+            valid_ = m_ < npix;
+            if (!valid_) m_ = npix - 1; // read a real pixel, discard the result
+            const int yy_ = (int)__umulhi((uint32_t)m_, a.magic_wo), xx_ = m_ - yy_ * a.Wo;
+            off_ = (yy_ * Wl + xx_) * X3_SLOT + h * 16;
+            boff_ = (unsigned)((b * 32 * a.Ho + (y0 + yy_)) * a.Wo + xx_ + 4 * h * chw) * 4u;
+        };
+        struct Ops {
+            vu4 xh, xm, xl, wl;
+        };
+        // operand i of the pixel at `off_`: three ds_read_b128 at row base + immediate (+ the lo weight fragment)
+        auto rd = [&](int off_, int i, Ops &o) {
+            const int t = i >> 1;
+            const char *p = tile + off_ + (t / 3) * rowb + ((t % 3) * X3_SLOT + (i & 1) * 32);
+            o.xh = *reinterpret_cast<const vu4 *>(p);
+            o.xm = *reinterpret_cast<const vu4 *>(p + 64);
+            o.xl = *reinterpret_cast<const vu4 *>(p + 128);
+            o.wl = *reinterpret_cast<const vu4 *>(wlf + (i * 64 + lane) * 16);
+        };
+        auto gates = [&](unsigned bo, float (&g)[16]) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                g[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                     rs_mask, bo, (unsigned)(((r & 3) + 8 * (r >> 2)) * chw) * 4u, 0));
+        };
+        bool valid;
+        int off;
+        unsigned boff;
+        locate(cw, valid, off, boff);
+        float gv[16]; // backward-data: this lane's 16 ReLU gates of the CURRENT tile (requested one tile ahead)
+        if (MODE == 1 && a.mask != nullptr) gates(boff, gv);
+        Ops o0, o1;
+        rd(off, 0, o0);
+        for (int tl = cw; tl < ntiles; tl += 4) {
+            bool valid2;
+            int off2;
+            unsigned boff2;
+            locate(tl + 4 < ntiles ? tl + 4 : tl, valid2, off2, boff2); // no next tile: re-read this one
+            f32x16 acc;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) { // accumulator seed = bias of rows 8 g4 + 4 h + (0..3)
+                const vf4 b4 = *reinterpret_cast<const vf4 *>(lbias + 8 * g4 + 4 * h);
+                acc[4 * g4] = b4[0]; acc[4 * g4 + 1] = b4[1]; acc[4 * g4 + 2] = b4[2]; acc[4 * g4 + 3] = b4[3];
+            }
+#define X3_MM(A_, B_) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, __builtin_bit_cast(bf16x8, B_), acc, 0, 0, 0)
+#pragma unroll
+            for (int i = 0; i < 18; ++i) {
+                Ops &cur = (i & 1) ? o1 : o0;
+                Ops &nxt = (i & 1) ? o0 : o1;
+                if (i < 17) rd(off, i + 1, nxt); // the next operand's reads run one 6-MFMA group (192 cycles) ahead
+                else rd(off2, 0, nxt);           // ... across the tile boundary
+                __builtin_amdgcn_sched_barrier(0);
+                // smallest products first: wm xm, wl xh, wh xl, wm xh, wh xm, wh xh
+                X3_MM(wm[i], cur.xm);
+                X3_MM(__builtin_bit_cast(bf16x8, cur.wl), cur.xh);
+                X3_MM(wh[i], cur.xl);
+                X3_MM(wm[i], cur.xh);
+                X3_MM(wh[i], cur.xm);
+                X3_MM(wh[i], cur.xh);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#undef X3_MM
+            // 18 is even: the next tile's operand 0 sits in o0 again
+            if (MODE == 1 && a.mask != nullptr) { // gate in place, request the NEXT tile's gates, then store
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = gv[r] > 0.0f ? acc[r] : 0.0f;
+                if (tl + 4 < ntiles) gates(boff2, gv);
+            }
+            if (valid) {
+                // rows in accumulator order: co = 0,1,2,3, 8,9,10,11, ... (+4 h in the lane offset).  Forward ReLU on the bit
+                // pattern is one v_max_i32 (negative floats are negative integers; floor INT_MIN = no ReLU).
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[r];
+                    if (MODE == 0) v = __int_as_float(max(__float_as_int(v), relu_floor));
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_out, boff,
+                                                          (unsigned)(((r & 3) + 8 * (r >> 2)) * chw) * 4u, 0);
+                }
+            }
+            valid = valid2; off = off2; boff = boff2;
+        }
+    };
+    __syncthreads();
+    for (int item = first; item < n; item += 2 * NG) {
+        compute(item, 0);
+        __syncthreads();
+        if (item + NG >= n) break;
+        compute(item + NG, 1);
+        __syncthreads();
+    }
+}
+
+// =========================================================================================
+// backward-weights: D_t[co][ci] = sum_p dZ[p][co] * A[p + tap_t][ci], K = 16 pixels per MFMA.  Both operands need 8
+// consecutive PIXELS of one channel per lane while the tiles hold 32 channels of one pixel per 64-byte row:
+// ds_read_b64_tr_b16 delivers exactly that transpose.  Tiles per buffer: {A hi, A mid, A lo, dZ hi, dZ mid, dZ lo}.
+// =========================================================================================
+struct WgX3Args {
+    const float *act; // a_{l-1} f32 NCHW (B,32,Hi,Wi)
+    const float *dz;  // f32 NCHW (B,32,Ho,Wo)
+    float *partial;   // [gridDim.x][32*288 + 32]
+    int B, Hi, Wi, Ho, Wo, RT, S, n_items;
+    uint32_t magic_wo;
+};
+
+constexpr int WGX_SLAB = 32 * 288 + 32;
+constexpr int WGX_NU = 2; // loader rounds per item: 256 lanes x 2 units of (4 pixels x 8 channels) >= A + dZ quads x 4
+
+__device__ __forceinline__ s16x4 lds_tr_x(const char *p)
+{
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)(p));
+}
+
+__global__ __launch_bounds__(512, 2) void k_wgrad32_x3(WgX3Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) char ldsw[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = wave >= 4;
+    const int cw = wave & 3;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int Wi = a.Wi, Wo = a.Wo;
+    const int apix = (a.RT + 2) * Wi;                // A tile pixels
+    const int zpix = (a.RT * Wo + 15) & ~15;         // dZ tile pixels, zero-padded to whole 16-pixel steps
+    const int abytes = apix * 64, zbytes = zpix * 64; // one plane
+    const int bufbytes = 3 * (abytes + zbytes);
+    // this lane's part in the transposed reads: it SUPPLIES row q, columns 4pp..4pp+3 of its group's 16-channel block
+    const int q = (lane & 15) >> 2, pp = lane & 3, cblk = (lane >> 4) & 1;
+    const int colbyte = (16 * cblk + 4 * pp) * 2;
+    const int G = gridDim.x, n = a.n_items, first = xcd_slot((int)blockIdx.x, G);
+
+    if (loader) {
+        const int lt = cw * 64 + lane;
+        struct Regs {
+            vf4ua d[WGX_NU][8];
+        };
+        struct Geo {
+            int b, y0, rows, na, nz, nqa, nqz;
+        };
+        auto geom = [&](int item) {
+            Geo g;
+            g.b = item / a.S;
+            const int s = item - g.b * a.S;
+            g.y0 = s * a.RT;
+            g.rows = min(a.RT, a.Ho - g.y0);
+            g.na = (g.rows + 2) * Wi;
+            g.nz = g.rows * Wo;
+            g.nqa = (g.na + 3) >> 2;
+            g.nqz = (g.nz + 3) >> 2;
+            return g;
+        };
+        // unit -> (channel group, source pointer of its 4 pixels, LDS byte of the first pixel's row in plane 0)
+        auto locate = [&](const Geo &g, int u, const float *&src, size_t &cs, int &lo) {
+            const int unit = u * 256 + lt;
+            const int cg = unit & 3;
+            const int qd = min(unit >> 2, g.nqa + g.nqz - 1); // units past the item repeat its last quad (idempotent)
+            if (qd < g.nqa) {
+                const int p0 = min(4 * qd, g.na - 4);
+                cs = (size_t)a.Hi * Wi;
+                src = a.act + ((size_t)g.b * 32 + 8 * cg) * cs + (size_t)g.y0 * Wi + p0;
+                lo = p0 * 64 + cg * 16;
+            } else {
+                const int p0 = min(4 * (qd - g.nqa), g.nz - 4);
+                cs = (size_t)a.Ho * Wo;
+                src = a.dz + ((size_t)g.b * 32 + 8 * cg) * cs + (size_t)g.y0 * Wo + p0;
+                lo = 3 * abytes + p0 * 64 + cg * 16;
+            }
+        };
+        auto issue = [&](int item, Regs &R) {
+            const Geo g = geom(item);
+#pragma unroll
+            for (int u = 0; u < WGX_NU; ++u) {
+                const float *src;
+                size_t cs;
+                int lo;
+                locate(g, u, src, cs, lo);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) R.d[u][c] = *reinterpret_cast<const vf4ua *>(src + c * cs);
+            }
+        };
+        auto commit = [&](int item, int bi, const Regs &R) {
+            const Geo g = geom(item);
+            char *dst = ldsw + bi * bufbytes;
+#pragma unroll
+            for (int u = 0; u < WGX_NU; ++u) {
+                const float *src;
+                size_t cs;
+                int lo;
+                locate(g, u, src, cs, lo);
+                const int pstride = lo >= 3 * abytes ? zbytes : abytes; // bytes between the hi / mid / lo planes
+                char *o = dst + lo;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    vu4 hi, mid, lw;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        uint32_t th, tm, tl;
+                        split2(R.d[u][2 * e][j], R.d[u][2 * e + 1][j], th, tm, tl);
+                        hi[e] = th; mid[e] = tm; lw[e] = tl;
+                    }
+                    *reinterpret_cast<vu4 *>(o + j * 64) = hi;
+                    *reinterpret_cast<vu4 *>(o + j * 64 + pstride) = mid;
+                    *reinterpret_cast<vu4 *>(o + j * 64 + 2 * pstride) = lw;
+                }
+            }
+            // zero the padded dZ pixels of all three planes (16-byte chunks: 4 per pixel)
+            char *dzl = dst + 3 * abytes;
+            const int npad = (zpix - g.nz) * 4;
+            for (int c = lt; c < 3 * npad; c += 256) {
+                const int pl = c / npad, r = c - pl * npad;
+                *reinterpret_cast<vu4 *>(dzl + pl * zbytes + g.nz * 64 + r * 16) = vu4{0u, 0u, 0u, 0u};
+            }
+        };
+        Regs ra, rb;
+        if (first < n) {
+            issue(first, ra);
+            commit(first, 0, ra);
+        }
+        if (first + G < n) issue(first + G, ra);
+        if (first + 2 * G < n) issue(first + 2 * G, rb);
+        __syncthreads();
+        for (int item = first; item < n; item += 2 * G) {
+            if (item + G < n) commit(item + G, 1, ra);
+            if (item + 3 * G < n) issue(item + 3 * G, ra);
+            __syncthreads();
+            if (item + G >= n) break;
+            if (item + 2 * G < n) commit(item + 2 * G, 0, rb);
+            if (item + 4 * G < n) issue(item + 4 * G, rb);
+            __syncthreads();
+        }
+        for (int w = 0; w < 6; ++w) __syncthreads(); // the compute waves' reduction barriers
+        return;
+    }
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    float dbacc = 0.0f;
+    auto compute = [&](int item, int bi) {
+        const int s = item % a.S;
+        const int rows = min(a.RT, a.Ho - s * a.RT);
+        const int npix = rows * Wo;
+        const char *At = ldsw + bi * bufbytes;
+        const char *Zt = At + 3 * abytes;
+        const int nsteps = (npix + 15) >> 4;
+        for (int k = cw; k < nsteps; k += 4) { // 16 strip pixels per step; all 64 lanes stay active (tr reads)
+            bf16x8 zf[3];
+            const char *pa[2];
+            {
+                s16x4 zr[3][2];
+#pragma unroll
+                for (int rd = 0; rd < 2; ++rd) {
+                    const int m = 16 * k + 8 * h + 4 * rd + q; // the pixel whose row this lane supplies
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) zr[pl][rd] = lds_tr_x(Zt + pl * zbytes + m * 64 + colbyte);
+                    const int mc = min(m, npix - 1);            // padded pixels: dZ is zero, read any real activation
+                    const int yy = (int)__umulhi((uint32_t)mc, a.magic_wo), xx = mc - yy * Wo;
+                    pa[rd] = At + (yy * Wi + xx) * 64 + colbyte;
+                }
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    zf[pl] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(zr[pl][0], zr[pl][1], 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dbacc += ((float)zf[0][j] + (float)zf[1][j]) + (float)zf[2][j];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) { // one kernel row at a time keeps 9 operand fragments live
+                s16x4 xr[3][3][2];
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                        for (int rd = 0; rd < 2; ++rd) xr[kx][pl][rd] = lds_tr_x(pa[rd] + pl * abytes + (ky * Wi + kx) * 64);
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    bf16x8 xf[3];
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        xf[pl] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(xr[kx][pl][0], xr[kx][pl][1], 0, 1, 2, 3, 4, 5, 6, 7));
+                    f32x16 &c = acc[ky * 3 + kx];
+                    // smallest products first: zm xm, zl xh, zh xl, zm xh, zh xm, zh xh
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zf[1], xf[1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zf[2], xf[0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zf[0], xf[2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zf[1], xf[0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zf[0], xf[1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zf[0], xf[0], c, 0, 0, 0);
+                }
+            }
+        }
+    };
+    __syncthreads();
+    for (int item = first; item < n; item += 2 * G) {
+        compute(item, 0);
+        __syncthreads();
+        if (item + G >= n) break;
+        compute(item + G, 1);
+        __syncthreads();
+    }
+    // ---- fixed-order reduction over the 4 compute waves through LDS, then one slab per workgroup
+    float *lds = reinterpret_cast<float *>(ldsw);
+    float *slab = a.partial + (size_t)blockIdx.x * WGX_SLAB;
+    for (int w = 1; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) lds[(t * 16 + r) * 64 + lane] = acc[t][r];
+            lds[144 * 64 + lane] = dbacc;
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] += lds[(t * 16 + r) * 64 + lane];
+            dbacc += lds[144 * 64 + lane];
+        }
+        __syncthreads();
+    }
+    if (wave == 0) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) slab[(size_t)acc_row_x(r, h) * 288 + l31 * 9 + t] = acc[t][r];
+        const float other = __shfl_xor(dbacc, 32, 64); // lanes (co, h=0/1) hold pixels 8h..8h+7 of every step
+        if (h == 0) slab[32 * 288 + l31] = dbacc + other;
+    }
+}
+
+} // namespace augcl
+
+using namespace augcl;
+
+namespace {
+
+int cu_count_x3()
+{
+    int dev = 0, v = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) v = n;
+    }
+    return v;
+}
+
+// +1: the shape is outside what the x3 kernels cover (the caller runs the native f32 MFMA kernel instead)
+template <int MODE>
+int launch_conv_x3(ConvX3Args &a, const char *name, hipStream_t s)
+{
+    const int Wi = a.Wi;
+    const int Wl = MODE ? Wi + 2 : Wi;
+    if (Wi < (MODE ? 5 : 4)) return 1; // a quad of 4 pixels per unit; MODE 1 divides by QW >= 2
+    // rows per strip: the tile fits its LDS buffer and one strip is X3_NU rounds of loader units
+    int rt = (X3_MAXTILE / X3_SLOT - (MODE ? 2 : 0)) / Wl - 2;
+    const int QW = (Wi + 3) >> 2;
+    rt = std::min(rt, (MODE ? 64 * X3_NU / QW : 256 * X3_NU / Wi) - 2); // quads of the tile's RT + 2 input rows <= 64 * X3_NU
+    if (rt < 1) return 1;
+    if (rt > a.Ho) rt = a.Ho;
+    a.S = (a.Ho + rt - 1) / rt;
+    const int cus = cu_count_x3();
+    while ((long)a.B * a.S < 2L * cus && a.S < a.Ho) ++a.S; // small batches: enough strips to go around
+    a.RT = (a.Ho + a.S - 1) / a.S;
+    a.S = (a.Ho + a.RT - 1) / a.RT;
+    a.n_items = a.B * a.S;
+    a.magic_wo = (uint32_t)(0x100000000ull / (unsigned)a.Wo) + 1u;
+    a.magic_qw = (uint32_t)(0x100000000ull / (unsigned)QW) + 1u;
+    const int tilepix = (a.RT + 2) * Wl + (MODE ? 2 : 0);
+    const int bufbytes = std::max(tilepix * X3_SLOT, X3_WST);
+    const size_t lds = (size_t)X3_WLF + 128 + 2 * (size_t)bufbytes;
+    if (lds > 160 * 1024) return 1;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv32_x3<MODE>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return augcl::fail(AUGCL_E_LAUNCH, "%s: cannot set dynamic LDS %zu: %s", name, lds, hipGetErrorString(e));
+    int grid = a.n_items < cus ? a.n_items : cus;
+    if (a.dual) grid &= ~1; // even / odd workgroups serve the two halves
+    hipLaunchKernelGGL((k_conv32_x3<MODE>), dim3(grid), dim3(512), lds, s, a);
+    return augcl::check_launch(name);
+}
+
+} // namespace
+
+extern "C" {
+
+int augcl_internal_conv32_forward_dual(const float *in, const float *w, const float *bias, const float *w2,
+                                       const float *bias2, float *out, int B2, int Hi, int Wi, int relu,
+                                       augcl_stream_t stream);
+
+static int x3_forward_impl(const float *in, const float *w, const float *bias, const float *w2, const float *bias2, float *out,
+                           int B, int Hi, int Wi, int relu, augcl_stream_t stream, const char *name)
+{
+    AUGCL_REQUIRE(B >= 0 && Hi >= 3 && Wi >= 3, "%s: bad shape", name);
+    if (B == 0) return AUGCL_OK;
+    AUGCL_REQUIRE(in && w && out, "%s: null tensor", name);
+    AUGCL_REQUIRE(aligned16(w) && aligned16(w2), "%s: weights must be 16-byte aligned", name);
+    AUGCL_REQUIRE(aligned4(in) && aligned4(out), "%s: tensors must be 4-byte aligned", name);
+    AUGCL_REQUIRE(w2 == nullptr || (B & 1) == 0, "%s: a two-weight-set batch must be even", name);
+    AUGCL_REQUIRE((size_t)B * 32 * Hi * Wi < ((size_t)1 << 30), "%s: tensor too large for 32-bit byte offsets (2^30 elements)", name);
+    ConvX3Args a{};
+    a.in = in; a.w = w; a.bias = bias; a.mask = nullptr; a.out = out;
+    a.w2 = w2; a.bias2 = bias2; a.dual = w2 != nullptr;
+    a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ho = Hi - 2; a.Wo = Wi - 2; a.relu = relu;
+    const int rc = launch_conv_x3<0>(a, name, as_stream(stream));
+    if (rc <= 0) return rc;
+    // rows too wide for the split tile: the native f32 MFMA kernel computes the same layer
+    if (w2) return augcl_internal_conv32_forward_dual(in, w, bias, w2, bias2, out, B, Hi, Wi, relu, stream);
+    return augcl_enc_conv32_forward(in, w, bias, out, B, Hi, Wi, relu, stream);
+}
+
+int augcl_enc_x3_conv32_forward(const float *in, const float *w, const float *bias, float *out, int B, int Hi, int Wi,
+                                int relu, augcl_stream_t stream)
+{
+    return x3_forward_impl(in, w, bias, nullptr, nullptr, out, B, Hi, Wi, relu, stream, "augcl_enc_x3_conv32_forward");
+}
+
+// internal (encoder_stack.cpp): B2 images, the first half with (w, bias), the second with (w2, bias2)
+int augcl_internal_x3_conv32_forward_dual(const float *in, const float *w, const float *bias, const float *w2,
+                                          const float *bias2, float *out, int B2, int Hi, int Wi, int relu,
+                                          augcl_stream_t stream)
+{
+    return x3_forward_impl(in, w, bias, w2, bias2, out, B2, Hi, Wi, relu, stream, "augcl_enc_stack_forward_dual");
+}
+
+int augcl_enc_x3_conv32_backward_data(const float *dz, const float *w, const float *act_prev, float *dact, int B, int Ho,
+                                      int Wo, augcl_stream_t stream)
+{
+    const char *name = "augcl_enc_x3_conv32_backward_data";
+    AUGCL_REQUIRE(B >= 0 && Ho >= 1 && Wo >= 1, "%s: bad shape", name);
+    if (B == 0) return AUGCL_OK;
+    AUGCL_REQUIRE(dz && w && dact, "%s: null tensor", name);
+    AUGCL_REQUIRE(aligned16(w), "%s: weights must be 16-byte aligned", name);
+    AUGCL_REQUIRE(aligned4(dz) && aligned4(dact) && aligned4(act_prev), "%s: tensors must be 4-byte aligned", name);
+    AUGCL_REQUIRE((size_t)B * 32 * (Ho + 2) * (Wo + 2) < ((size_t)1 << 30), "%s: tensor too large for 32-bit byte offsets (2^30 elements)", name);
+    ConvX3Args a{};
+    a.in = dz; a.w = w; a.bias = nullptr; a.mask = act_prev; a.out = dact;
+    a.B = B; a.Hi = Ho; a.Wi = Wo; a.Ho = Ho + 2; a.Wo = Wo + 2; a.relu = 0;
+    const int rc = launch_conv_x3<1>(a, name, as_stream(stream));
+    if (rc <= 0) return rc;
+    return augcl_enc_conv32_backward_data(dz, w, act_prev, dact, B, Ho, Wo, stream);
+}
+
+int augcl_enc_x3_conv32_backward_weights(const float *act_prev, const float *dz, float *dw, float *db, float *workspace,
+                                         size_t workspace_bytes, int B, int Hi, int Wi, augcl_stream_t stream)
+{
+    const char *name = "augcl_enc_x3_conv32_backward_weights";
+    AUGCL_REQUIRE(B >= 1 && Hi >= 3 && Wi >= 3, "%s: bad shape", name);
+    AUGCL_REQUIRE(act_prev && dz && dw && db && workspace, "%s: null tensor", name);
+    AUGCL_REQUIRE(aligned4(act_prev) && aligned4(dz), "%s: tensors must be 4-byte aligned", name);
+    WgX3Args a{};
+    a.act = act_prev; a.dz = dz; a.partial = workspace;
+    a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ho = Hi - 2; a.Wo = Wi - 2;
+    // per buffer: 3 planes x ((RT+2)*Wi + roundup16(RT*Wo)) pixels of 64 bytes; one item = WGX_NU rounds of loader units
+    const int budget_pix = 80 * 1024 / 192;
+    int rt = (budget_pix - 2 * Wi - 16) / (Wi + a.Wo);
+    rt = std::min(rt, (256 * WGX_NU - 2 * Wi - 8) / (Wi + a.Wo)); // quads of A + quads of dZ <= 64 * WGX_NU
+    if (rt < 1 || a.Wo < 4) // rows too wide (or too narrow) for the split tiles: the native f32 MFMA kernel
+        return augcl_enc_conv32_backward_weights(act_prev, dz, dw, db, workspace, workspace_bytes, B, Hi, Wi, stream);
+    if (rt > a.Ho) rt = a.Ho;
+    a.S = (a.Ho + rt - 1) / rt;
+    const int cus = cu_count_x3();
+    while ((long)B * a.S < 2L * cus && a.S < a.Ho) ++a.S;
+    a.RT = (a.Ho + a.S - 1) / a.S;
+    a.S = (a.Ho + a.RT - 1) / a.RT;
+    a.n_items = B * a.S;
+    a.magic_wo = (uint32_t)(0x100000000ull / (unsigned)a.Wo) + 1u;
+    const int apix = (a.RT + 2) * Wi, zpix = (a.RT * a.Wo + 15) & ~15;
+    size_t lds = (size_t)2 * 3 * (apix + zpix) * 64;
+    const size_t red = (size_t)(145 * 64) * 4;
+    if (lds < red) lds = red;
+    const int grid = a.n_items < cus ? a.n_items : cus;
+    AUGCL_REQUIRE(workspace_bytes >= (size_t)(grid + 8) * WGX_SLAB * 4, "%s: workspace too small", name);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wgrad32_x3),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return augcl::fail(AUGCL_E_LAUNCH, "%s: cannot set dynamic LDS %zu: %s", name, lds, hipGetErrorString(e));
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(k_wgrad32_x3, dim3(grid), dim3(512), lds, s, a);
+    if (int rc = augcl::check_launch(name)) return rc;
+    return augcl::reduce_slabs(ReduceDesc{workspace, workspace + (size_t)grid * WGX_SLAB, dw, db, grid, WGX_SLAB, 32 * 288}, s, name);
+}
+
+} // extern "C"

@@ -107,6 +107,11 @@ class ConvStackLayerwiseFn(torch.autograd.Function):  # per-layer calls: HeadCNN
 # point keeps the f32 MFMA pipe with bf16 inputs widened while staging (59 us).  Switchable for A/B timing.
 _BF16_WGRAD = "augcl_enc_bf16_conv32_backward_weights_mfma"
 
+# precision name -> the C ABI's precision code (include/augcl.h, augcl_enc_stack_*): "f32" = f32 NCHW activations with
+# the 32 -> 32 layers' products split onto the bf16 matrix pipe (float32-accurate, the parity path); "f32_mfma" = the
+# same tensors on the native f32 MFMA pipe (round 1-2's parity path, kept for A/B); "bf16" = bf16 NHWC performance mode.
+PRECISION_CODE = {"f32_mfma": 0, "bf16": 1, "f32": 2}
+
 
 def _ptr_array(ptrs):
     return (_lib.ctypes.c_void_p * len(ptrs))(*ptrs)
@@ -134,14 +139,16 @@ def conv_stack_dual(x, weights_a, biases_a, weights_b, biases_b, first_stride, i
     ptrs = [arena.data_ptr() + (i & 1) * big * arena.element_size() for i in range(n_layers - 1)] + [out.data_ptr()]
     d = lambda ts: _ptr_array([t.detach().data_ptr() for t in ts])  # noqa: E731
     _lib.call("augcl_enc_stack_forward_dual", x.data_ptr(), d(weights_a), d(biases_a), d(weights_b), d(biases_b),
-              _ptr_array(ptrs), n_layers, B, C, H, W, first_stride, input_scale, 1 if bf16 else 0, _lib.current_stream(dev))
+              _ptr_array(ptrs), n_layers, B, C, H, W, first_stride, input_scale, PRECISION_CODE[precision],
+              _lib.current_stream(dev))
     return out
 
 
 class ConvStackFn(torch.autograd.Function):
     """The SharedCNN stack through the whole-stack C entry points: ONE FFI call per forward, one per backward, one
-    activation arena per pass.  precision "f32" = parity path (f32 NCHW activations, f32 MFMA), "bf16" = performance
-    mode (bf16 NHWC activations, bf16 MFMA, f32 accumulation / master weights / weight gradients)."""
+    activation arena per pass.  precision "f32" = parity path (f32 NCHW activations; 32 -> 32 layers with float32-accurate
+    products on the bf16 MFMA pipe), "f32_mfma" = the same on the native f32 MFMA pipe, "bf16" = performance mode (bf16
+    NHWC activations, bf16 MFMA, f32 accumulation / master weights / weight gradients)."""
 
     @staticmethod
     def forward(ctx, x, first_stride, input_scale, precision, n_layers, *wb):
@@ -175,7 +182,7 @@ class ConvStackFn(torch.autograd.Function):
         ptrs.append(out.data_ptr())
         _lib.call("augcl_enc_stack_forward", x.data_ptr(), _ptr_array([t.data_ptr() for t in weights]),
                   _ptr_array([t.data_ptr() for t in biases]), _ptr_array(ptrs), n_layers, B, C, H, W, first_stride,
-                  input_scale, 1 if bf16 else 0, _lib.current_stream(dev))
+                  input_scale, PRECISION_CODE[precision], _lib.current_stream(dev))
         if need_grad:
             ctx.save_for_backward(x, arena, *weights)
             ctx.meta = (first_stride, input_scale, precision, n_layers, ptrs[:-1], max(numel))
@@ -199,5 +206,5 @@ class ConvStackFn(torch.autograd.Function):
                   _ptr_array([w.data_ptr() for w in weights]), g.data_ptr(), _ptr_array([t.data_ptr() for t in dws]),
                   _ptr_array([dbs[i].data_ptr() for i in range(n_layers)]), dz.data_ptr(), dz.data_ptr() + half,
                   ws32.data_ptr(), ws32.numel() * 4, wsf.data_ptr(), wsf.numel() * 4, n_layers, B, C, H, W, first_stride,
-                  input_scale, 1 if bf16 else 0, 1 if _BF16_WGRAD.endswith("_mfma") else 0, _lib.current_stream(dev))
+                  input_scale, PRECISION_CODE[precision], 1 if _BF16_WGRAD.endswith("_mfma") else 0, _lib.current_stream(dev))
         return (None, None, None, None, None, *dws, *[dbs[i] for i in range(n_layers)])

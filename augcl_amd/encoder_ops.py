@@ -4,9 +4,11 @@ backward-data / backward-weights with fused /255, bias, ReLU and ReLU-mask epilo
 stack, activations kept post-ReLU in a per-call arena.  There is no other backend: without the library or a GPU
 tensor the op raises.  (tools/aten_encoder.py swaps an ATen stack in for A/B timing -- outside the package.)
 
-Precision: "f32" = parity path (f32 NCHW activations, f32 MFMA); "bf16" = performance mode of BASELINE config 2
-(bf16 NHWC activations, bf16 MFMA, f32 accumulation / master weights / weight gradients), selected per process with
-`set_precision` or per agent with `args.precision`.
+Precision: "f32" = parity path (f32 NCHW activations; the 32 -> 32 layers split every f32 operand exactly into three bf16
+parts and run the six significant cross products on the bf16 MFMA pipe with f32 accumulation -- float32 accuracy at
+2.67x the f32 MFMA rate, csrc/encoder_x3.hip); "f32_mfma" = the same tensors on the native f32 MFMA pipe (kept for
+A/B); "bf16" = performance mode of BASELINE config 2 (bf16 NHWC activations, bf16 MFMA, f32 accumulation / master
+weights / weight gradients).  One precision per process, selected with `set_precision` (`args.precision` calls it).
 """
 import torch
 
@@ -17,8 +19,8 @@ PRECISION = "f32"
 
 def set_precision(name):
     global PRECISION
-    if name not in ("f32", "bf16"):
-        raise ValueError(f"precision must be 'f32' or 'bf16', got {name!r}")
+    if name not in ("f32", "f32_mfma", "bf16"):
+        raise ValueError(f"precision must be 'f32', 'f32_mfma' or 'bf16', got {name!r}")
     PRECISION = name
 
 

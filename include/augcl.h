@@ -293,6 +293,22 @@ int augcl_enc_conv_first_backward_weights(const float *x /* (B,C,Hi,Wi) raw */, 
                                           float *db, float *workspace, size_t workspace_bytes, int B, int C, int Hi,
                                           int Wi, int stride, float scale, augcl_stream_t stream);
 
+/* ---- the same three 32 -> 32 layer operators with FLOAT32-ACCURATE products on the bf16 matrix pipe (the default
+ * parity path since round 3; replaces the f32-MFMA form of src/algorithms/modules.py:145-165's Conv2d(32,32,3)).
+ * Same tensors, dtypes (f32 NCHW) and semantics as augcl_enc_conv32_*: every f32 operand is split exactly into three
+ * bf16 parts (x = hi + mid + lo) while it is staged into LDS, and the six cross products of weight >= 2^-16 run on
+ * v_mfma_f32_32x32x16_bf16 with f32 accumulation -- 2.6e-7 relative L2 against float64 at K = 288 (3.0e-7 for the
+ * native f32 MFMA chain) at 2.67x its matrix rate.  Not bit-identical to augcl_enc_conv32_* (different summation
+ * tree), both within float32 rounding of the exact result.  Inputs with |x| >= 2^127.99 (bf16 rounds them to
+ * infinity) give NaN.  Row widths the split tiles do not fit run the augcl_enc_conv32_* kernel. */
+int augcl_enc_x3_conv32_forward(const float *in /* (B,32,Hi,Wi) */, const float *w /* (32,32,3,3) */, const float *bias,
+                                float *out /* (B,32,Hi-2,Wi-2) */, int B, int Hi, int Wi, int relu, augcl_stream_t stream);
+int augcl_enc_x3_conv32_backward_data(const float *dz /* (B,32,Ho,Wo) */, const float *w, const float *act_prev,
+                                      float *dact /* (B,32,Ho+2,Wo+2) */, int B, int Ho, int Wo, augcl_stream_t stream);
+int augcl_enc_x3_conv32_backward_weights(const float *act_prev /* (B,32,Hi,Wi) */, const float *dz /* (B,32,Hi-2,Wi-2) */,
+                                         float *dw /* (32,32,3,3) */, float *db /* (32) */, float *workspace,
+                                         size_t workspace_bytes, int B, int Hi, int Wi, augcl_stream_t stream);
+
 /* ---- bf16 PERFORMANCE MODE of the same conv stack (BASELINE config 2 "bf16"; NOT the parity path).
  * Activations are bf16 NHWC (B,H,W,32) in HBM, products on v_mfma_f32_32x32x16_bf16 with f32 accumulation,
  * weights/biases stay f32 masters (rounded to bf16 per launch).  The last layer can emit f32 NCHW for the
@@ -317,7 +333,8 @@ int augcl_enc_bf16_conv_first_backward_weights(const float *x /* f32 raw */, con
 int augcl_enc_nchw_f32_to_nhwc_bf16(const float *in, void *out_bf16_nhwc, int B, int H, int W, augcl_stream_t stream);
 
 /* ---- whole-stack entry points: every layer of the encoder forward / backward behind ONE call (the host pays one
- * FFI crossing per pass).  precision 0 = f32 NCHW (parity path), 1 = bf16 NHWC (performance mode).
+ * FFI crossing per pass).  precision 0 = f32 NCHW on the f32 MFMA pipe, 1 = bf16 NHWC (performance mode), 2 = f32 NCHW
+ * with the 32 -> 32 layers on the split-bf16 kernels (augcl_enc_x3_*: float32-accurate, the default parity path).
  * forward: acts_out[i] = output buffer of layer i (the last layer always writes f32 NCHW).
  * backward: acts_in[i] = input of layer i (acts_in[0] = the raw f32 image batch); dz_a / dz_b = two scratch buffers
  * of the largest activation's size; dw[i] / db[i] receive the weight / bias gradients. */
