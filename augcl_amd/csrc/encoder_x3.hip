@@ -74,6 +74,8 @@ struct ConvX3Args {
     uint32_t magic_qw;   // MODE 1: floor(2^32 / QW) + 1, QW = quads per dZ row
     const float *w2, *bias2; // two-weight-set forward: images [B/2, B) use w2 / bias2 (odd workgroups)
     int dual;
+    int abl;                 // tuning builds only: ablation bits (1: no MFMA loop, 2: loaders skip the LDS stores, 4: ... the split)
+    unsigned long long *dbg; // tuning builds only (-DAUGCL_TUNING): (shader clock << 8 | event id) records of workgroup 0
 };
 
 // MODE 0: forward (valid 3x3).  MODE 1: backward-data = full correlation of dZ with the flipped, transposed weights; its
@@ -101,20 +103,44 @@ __global__ __launch_bounds__(512, 2) void k_conv32_x3(ConvX3Args a)
     const int first = a.dual ? grp * nhalf + (int)(blockIdx.x >> 1) : xcd_slot((int)blockIdx.x, (int)gridDim.x);
     const int NG = a.dual ? (int)(gridDim.x >> 1) : (int)gridDim.x;
     const int n = a.dual ? (grp + 1) * nhalf : a.n_items;
+#ifdef AUGCL_TUNING
+    // per-phase time stamps of compute wave 0 (records 0..) and loader wave 4 (records 4096..) of workgroup 0; record 8190/8191 =
+    // s_memrealtime (100 MHz) at start / end of compute wave 0: shader clock = d(memtime) / d(memrealtime) x 100 MHz
+    int ndbg = 0;
+    unsigned long long *dbgp = (a.dbg && blockIdx.x == 0 && (wave == 0 || wave == 4)) ? a.dbg + (wave ? 4096 : 0) : nullptr;
+    auto stamp = [&](int id) {
+        if (dbgp != nullptr && ndbg < 4000) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            if (lane == 0) dbgp[ndbg] = (t << 8) | (unsigned)id;
+            ++ndbg;
+        }
+    };
+    if (dbgp && wave == 0 && lane == 0) a.dbg[8190] = __builtin_amdgcn_s_memrealtime();
+#define X3_STAMP(id) stamp(id)
+#else
+#define X3_STAMP(id)
+#endif
+    X3_STAMP(0);
 
-    // ---- weights: all 512 threads copy the 36 KB of f32 masters into LDS with coalesced 16-byte loads (the region of tile
-    // buffer 1, which the loaders first write after the second barrier)
-    {
+    // ---- weights: the 4 compute waves copy the 36 KB of f32 masters into LDS with coalesced 16-byte loads (into the region
+    // of tile buffer 1, which the loaders first write after the second barrier) WHILE the loaders already have the first
+    // strip's loads in flight: the two memory latencies of the prologue overlap
+    if (!loader) {
         float *wst = reinterpret_cast<float *>(tiles + bufbytes);
         const vf4 *w4 = reinterpret_cast<const vf4 *>(grp ? a.w2 : a.w);
         const float *bsrc = grp ? a.bias2 : a.bias;
-        for (int i = tid; i < 32 * 288 / 4; i += 512) {
-            const int row = (4 * i) / 288, col = 4 * i - row * 288;
-            *reinterpret_cast<vf4 *>(wst + row * X3_WROW + col) = w4[i];
+        vf4 wv[9];
+#pragma unroll
+        for (int u = 0; u < 9; ++u) wv[u] = w4[tid + 256 * u]; // 2304 chunks = 9 per thread, all in flight at once
+#pragma unroll
+        for (int u = 0; u < 9; ++u) {
+            const int i = tid + 256 * u, row = (4 * i) / 288, col = 4 * i - row * 288;
+            *reinterpret_cast<vf4 *>(wst + row * X3_WROW + col) = wv[u];
         }
         if (tid < 32) lbias[tid] = (MODE == 0 && bsrc) ? bsrc[tid] : 0.0f;
+        __syncthreads();
+        X3_STAMP(1);
     }
-    __syncthreads();
 
     // The two roles run DIFFERENT code with the same barrier sequence (2 + one per item): the branch is wave-uniform, and
     // the separate branches keep the loaders' prefetch registers and the compute waves' weight fragments apart.
@@ -181,12 +207,23 @@ __global__ __launch_bounds__(512, 2) void k_conv32_x3(ConvX3Args a)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     vu4 hi, mid, lo;
+#ifdef AUGCL_TUNING
+                    if (a.abl & 4) { // ablation: no split
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            hi[e] = __float_as_uint(R.d[u][2 * e][j]); mid[e] = __float_as_uint(R.d[u][2 * e + 1][j]); lo[e] = hi[e] ^ mid[e];
+                        }
+                    } else
+#endif
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         uint32_t th, tm, tl;
                         split2(R.d[u][2 * e][j], R.d[u][2 * e + 1][j], th, tm, tl);
                         hi[e] = th; mid[e] = tm; lo[e] = tl;
                     }
+#ifdef AUGCL_TUNING
+                    if ((a.abl & 2) && hi[0] != 0x12345678u) continue; // ablation: no LDS stores (the values stay live)
+#endif
                     *reinterpret_cast<vu4 *>(o + j * X3_SLOT) = hi;
                     *reinterpret_cast<vu4 *>(o + j * X3_SLOT + 64) = mid;
                     *reinterpret_cast<vu4 *>(o + j * X3_SLOT + 128) = lo;
@@ -210,56 +247,103 @@ __global__ __launch_bounds__(512, 2) void k_conv32_x3(ConvX3Args a)
                 }
             }
         };
+        // The loaders' VALU work (the split: ~450 instructions per lane and strip) shares each SIMD's issue port with a compute
+        // wave that issues an MFMA every 32 cycles; at equal priority it got one instruction in per ~20 cycles and the strip's
+        // commit, 8100 cycles, was longer than the strip's MFMAs (tools/x3_stamps.py).  With priority the loaders take their
+        // slots at once -- an MFMA needs the port for 8 of its 32 cycles -- and are done in a fraction of a strip time.
+        __builtin_amdgcn_s_setprio(2);
         Regs ra, rb;
+        if (first < n) issue(first, ra);
+        X3_STAMP(20);
+        __syncthreads(); // (the compute waves' weight staging barrier)
         if (first < n) {
-            issue(first, ra);
             commit(first, 0, ra, true);
+            X3_STAMP(21);
         }
         if (first + NG < n) issue(first + NG, ra);
         if (first + 2 * NG < n) issue(first + 2 * NG, rb);
+        X3_STAMP(22);
         __syncthreads();
+        X3_STAMP(23);
         bool fresh1 = true;
         for (int item = first; item < n; item += 2 * NG) {
+            X3_STAMP(20);
+#ifdef AUGCL_TUNING
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); // (stamps only) ra's loads have landed; rb's 16 may be in flight
+            X3_STAMP(24);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            X3_STAMP(25);
+#endif
             if (item + NG < n) commit(item + NG, 1, ra, fresh1); // even half: the compute waves read buffer 0
             fresh1 = false;
+            X3_STAMP(21);
             if (item + 3 * NG < n) issue(item + 3 * NG, ra);
+            X3_STAMP(22);
             __syncthreads();
+            X3_STAMP(23);
             if (item + NG >= n) break;
+            X3_STAMP(20);
+#ifdef AUGCL_TUNING
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            X3_STAMP(24);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            X3_STAMP(25);
+#endif
             if (item + 2 * NG < n) commit(item + 2 * NG, 0, rb, false); // odd half: they read buffer 1
+            X3_STAMP(21);
             if (item + 4 * NG < n) issue(item + 4 * NG, rb);
+            X3_STAMP(22);
             __syncthreads();
+            X3_STAMP(23);
         }
         return;
     }
 
     // ---- compute waves.  Operand i = (tap t = i / 2, channel half s = i & 1); A fragment: W_eff[row l31][k = 16 s + 8 h + j][t].
     // hi and mid parts live in registers for the whole launch, the lo part (one of the six products) is read from LDS.
+    // The fragments of the ODD operands (channels 16..31) are NEGATED and accumulate into a second accumulator; the result is
+    // P - N.  Reason: the bf16 MFMA's internal accumulation truncates toward -infinity somewhere below the f32 ulp -- a bias
+    // of ~ -1.5e-9 sum|w x| per output (tools/x3probe.hip), harmless per element but COHERENT over a gradient map, and the
+    // backward-weights / bias sums over 10^4..10^6 nearly cancelling pixels amplify a coherent error by sqrt(#pixels)
+    // (measured: db 1.2e-5 off float64 ten layers down at B = 8).  Two accumulators of opposite sign carry the same bias, so
+    // it cancels in the difference (mean error -1.4e-9 -> -2e-12, rel-L2 2.6e-7 -> 1.8e-7: two shorter chains).
     bf16x8 wh[18], wm[18];
     {
         const float *wst = reinterpret_cast<const float *>(tiles + bufbytes);
 #pragma unroll
-        for (int i = 0; i < 18; ++i) {
-            const int t = i >> 1, s = i & 1;
-            vu4 fh, fm, fl;
+        for (int s = 0; s < 2; ++s) {
+            vf4 tmp[18]; // MODE 0: the 72 contiguous floats W[co = l31][ci = 16 s + 8 h .. + 7][0..8] (conflict-free ds_read_b128)
+            if (MODE == 0) {
+                const vf4 *src = reinterpret_cast<const vf4 *>(wst + l31 * X3_WROW + (16 * s + 8 * h) * 9);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float v0, v1;
-                if (MODE == 0) { // W[co = l31][ci = k][t]
-                    v0 = wst[l31 * X3_WROW + (16 * s + 8 * h + 2 * e) * 9 + t];
-                    v1 = wst[l31 * X3_WROW + (16 * s + 8 * h + 2 * e + 1) * 9 + t];
-                } else {         // W'[ci = l31][co = k][t] = W[co][ci][8 - t]
-                    v0 = wst[(16 * s + 8 * h + 2 * e) * X3_WROW + l31 * 9 + (8 - t)];
-                    v1 = wst[(16 * s + 8 * h + 2 * e + 1) * X3_WROW + l31 * 9 + (8 - t)];
-                }
-                uint32_t th, tm, tl;
-                split2(v0, v1, th, tm, tl);
-                fh[e] = th; fm[e] = tm; fl[e] = tl;
+                for (int v = 0; v < 18; ++v) tmp[v] = src[v];
             }
-            wh[i] = __builtin_bit_cast(bf16x8, fh);
-            wm[i] = __builtin_bit_cast(bf16x8, fm);
-            if ((i & 3) == cw) *reinterpret_cast<vu4 *>(wlf + (i * 64 + lane) * 16) = fl; // every wave computes the same values
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int i = 2 * t + s;
+                vu4 fh, fm, fl;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v0, v1;
+                    if (MODE == 0) { // W[co = l31][ci = k][t]
+                        v0 = tmp[((2 * e) * 9 + t) >> 2][((2 * e) * 9 + t) & 3];
+                        v1 = tmp[((2 * e + 1) * 9 + t) >> 2][((2 * e + 1) * 9 + t) & 3];
+                    } else {         // W'[ci = l31][co = k][t] = W[co][ci][8 - t]  (lanes 9 words apart: conflict-free)
+                        v0 = wst[(16 * s + 8 * h + 2 * e) * X3_WROW + l31 * 9 + (8 - t)];
+                        v1 = wst[(16 * s + 8 * h + 2 * e + 1) * X3_WROW + l31 * 9 + (8 - t)];
+                    }
+                    if (s) { v0 = -v0; v1 = -v1; } // the split of -v is minus the split of v (round-to-nearest-even is symmetric)
+                    uint32_t th, tm, tl;
+                    split2(v0, v1, th, tm, tl);
+                    fh[e] = th; fm[e] = tm; fl[e] = tl;
+                }
+                wh[i] = __builtin_bit_cast(bf16x8, fh);
+                wm[i] = __builtin_bit_cast(bf16x8, fm);
+                if ((i & 3) == cw) *reinterpret_cast<vu4 *>(wlf + (i * 64 + lane) * 16) = fl; // every wave computes the same values
+            }
         }
     }
+    X3_STAMP(2);
     const int rowb = Wl * X3_SLOT; // LDS bytes between tile rows
     const int relu_floor = __builtin_amdgcn_readfirstlane(a.relu ? 0 : (int)0x80000000); // opaque: stays ONE v_max_i32
     // raw buffer resources (base, stride 0, no bound, gfx9 dword-3 flags): offsets < 2^32 by the host's size check
@@ -276,6 +360,9 @@ __global__ __launch_bounds__(512, 2) void k_conv32_x3(ConvX3Args a)
         const char *tile = tiles + bi * bufbytes;
         const int ntiles = (npix + 31) >> 5;
         if (cw >= ntiles) return; // wave-uniform
+#ifdef AUGCL_TUNING
+        if (a.abl & 1) return; // ablation: the loaders alone
+#endif
         // this lane's pixel of tile tl: index m in the strip, (yy, xx), the LDS byte of its top-left tap (both modes: tile
         // row yy + ky, tile pixel xx + kx -- backward-data's +2 shift cancels its -2 taps) and its output byte offset
         auto locate = [&](int tl, bool &valid_, int &off_, unsigned &boff_) {
@@ -317,13 +404,16 @@ __global__ __launch_bounds__(512, 2) void k_conv32_x3(ConvX3Args a)
             int off2;
             unsigned boff2;
             locate(tl + 4 < ntiles ? tl + 4 : tl, valid2, off2, boff2); // no next tile: re-read this one
-            f32x16 acc;
+            X3_STAMP(11);
+            f32x16 acc, accn; // even operands (+w) / odd operands (-w): the result is acc - accn
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) { // accumulator seed = bias of rows 8 g4 + 4 h + (0..3)
                 const vf4 b4 = *reinterpret_cast<const vf4 *>(lbias + 8 * g4 + 4 * h);
                 acc[4 * g4] = b4[0]; acc[4 * g4 + 1] = b4[1]; acc[4 * g4 + 2] = b4[2]; acc[4 * g4 + 3] = b4[3];
             }
-#define X3_MM(A_, B_) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, __builtin_bit_cast(bf16x8, B_), acc, 0, 0, 0)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accn[r] = 0.0f;
+#define X3_MM(C_, A_, B_) C_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, __builtin_bit_cast(bf16x8, B_), C_, 0, 0, 0)
 #pragma unroll
             for (int i = 0; i < 18; ++i) {
                 Ops &cur = (i & 1) ? o1 : o0;
@@ -332,15 +422,27 @@ __global__ __launch_bounds__(512, 2) void k_conv32_x3(ConvX3Args a)
                 else rd(off2, 0, nxt);           // ... across the tile boundary
                 __builtin_amdgcn_sched_barrier(0);
                 // smallest products first: wm xm, wl xh, wh xl, wm xh, wh xm, wh xh
-                X3_MM(wm[i], cur.xm);
-                X3_MM(__builtin_bit_cast(bf16x8, cur.wl), cur.xh);
-                X3_MM(wh[i], cur.xl);
-                X3_MM(wm[i], cur.xh);
-                X3_MM(wh[i], cur.xm);
-                X3_MM(wh[i], cur.xh);
+                if (i & 1) {
+                    X3_MM(accn, wm[i], cur.xm);
+                    X3_MM(accn, __builtin_bit_cast(bf16x8, cur.wl), cur.xh);
+                    X3_MM(accn, wh[i], cur.xl);
+                    X3_MM(accn, wm[i], cur.xh);
+                    X3_MM(accn, wh[i], cur.xm);
+                    X3_MM(accn, wh[i], cur.xh);
+                } else {
+                    X3_MM(acc, wm[i], cur.xm);
+                    X3_MM(acc, __builtin_bit_cast(bf16x8, cur.wl), cur.xh);
+                    X3_MM(acc, wh[i], cur.xl);
+                    X3_MM(acc, wm[i], cur.xh);
+                    X3_MM(acc, wh[i], cur.xm);
+                    X3_MM(acc, wh[i], cur.xh);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
 #undef X3_MM
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] -= accn[r];
+            X3_STAMP(acc[0] == 12345.678f ? 99 : 12); // (reads acc: after the MFMA chain has drained)
             // 18 is even: the next tile's operand 0 sits in o0 again
             if (MODE == 1 && a.mask != nullptr) { // gate in place, request the NEXT tile's gates, then store
 #pragma unroll
@@ -358,18 +460,31 @@ __global__ __launch_bounds__(512, 2) void k_conv32_x3(ConvX3Args a)
                                                           (unsigned)(((r & 3) + 8 * (r >> 2)) * chw) * 4u, 0);
                 }
             }
+            X3_STAMP(13);
             valid = valid2; off = off2; boff = boff2;
         }
     };
     __syncthreads();
+    X3_STAMP(3);
     for (int item = first; item < n; item += 2 * NG) {
         compute(item, 0);
+        X3_STAMP(14);
         __syncthreads();
+        X3_STAMP(15);
         if (item + NG >= n) break;
         compute(item + NG, 1);
+        X3_STAMP(14);
         __syncthreads();
+        X3_STAMP(15);
     }
+#ifdef AUGCL_TUNING
+    if (dbgp && wave == 0 && lane == 0) {
+        a.dbg[8191] = __builtin_amdgcn_s_memrealtime();
+        a.dbg[8189] = (unsigned long long)ndbg;
+    }
+#endif
 }
+#undef X3_STAMP
 
 // =========================================================================================
 // backward-weights: D_t[co][ci] = sum_p dZ[p][co] * A[p + tap_t][ci], K = 16 pixels per MFMA.  Both operands need 8
@@ -409,6 +524,10 @@ __global__ __launch_bounds__(512, 2) void k_wgrad32_x3(WgX3Args a)
     const int q = (lane & 15) >> 2, pp = lane & 3, cblk = (lane >> 4) & 1;
     const int colbyte = (16 * cblk + 4 * pp) * 2;
     const int G = gridDim.x, n = a.n_items, first = xcd_slot((int)blockIdx.x, G);
+    // The bf16 MFMA's accumulation is biased toward -infinity by a fraction of an ulp per instruction (see k_conv32_x3); a
+    // workgroup's accumulators take hundreds of them.  Odd workgroups therefore accumulate -dW (their loaders negate dZ --
+    // exact) and negate the slab when they write it: the bias of the slab sum cancels between even and odd workgroups.
+    const bool wg_neg = (blockIdx.x & 1) != 0;
 
     if (loader) {
         const int lt = cw * 64 + lane;
@@ -468,7 +587,9 @@ __global__ __launch_bounds__(512, 2) void k_wgrad32_x3(WgX3Args a)
                 size_t cs;
                 int lo;
                 locate(g, u, src, cs, lo);
-                const int pstride = lo >= 3 * abytes ? zbytes : abytes; // bytes between the hi / mid / lo planes
+                const bool isz = lo >= 3 * abytes;
+                const int pstride = isz ? zbytes : abytes; // bytes between the hi / mid / lo planes
+                const float sg = (isz && wg_neg) ? -1.0f : 1.0f; // odd workgroups accumulate -dW (see the slab write)
                 char *o = dst + lo;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -476,7 +597,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad32_x3(WgX3Args a)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         uint32_t th, tm, tl;
-                        split2(R.d[u][2 * e][j], R.d[u][2 * e + 1][j], th, tm, tl);
+                        split2(sg * R.d[u][2 * e][j], sg * R.d[u][2 * e + 1][j], th, tm, tl);
                         hi[e] = th; mid[e] = tm; lw[e] = tl;
                     }
                     *reinterpret_cast<vu4 *>(o + j * 64) = hi;
@@ -606,9 +727,9 @@ __global__ __launch_bounds__(512, 2) void k_wgrad32_x3(WgX3Args a)
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) slab[(size_t)acc_row_x(r, h) * 288 + l31 * 9 + t] = acc[t][r];
+            for (int r = 0; r < 16; ++r) slab[(size_t)acc_row_x(r, h) * 288 + l31 * 9 + t] = wg_neg ? -acc[t][r] : acc[t][r];
         const float other = __shfl_xor(dbacc, 32, 64); // lanes (co, h=0/1) hold pixels 8h..8h+7 of every step
-        if (h == 0) slab[32 * 288 + l31] = dbacc + other;
+        if (h == 0) slab[32 * 288 + l31] = wg_neg ? -(dbacc + other) : dbacc + other;
     }
 }
 
@@ -627,6 +748,10 @@ int cu_count_x3()
     }
     return v;
 }
+
+#ifdef AUGCL_TUNING
+unsigned long long *g_x3_dbg_get();
+#endif
 
 // +1: the shape is outside what the x3 kernels cover (the caller runs the native f32 MFMA kernel instead)
 template <int MODE>
@@ -653,6 +778,10 @@ int launch_conv_x3(ConvX3Args &a, const char *name, hipStream_t s)
     const int bufbytes = std::max(tilepix * X3_SLOT, X3_WST);
     const size_t lds = (size_t)X3_WLF + 128 + 2 * (size_t)bufbytes;
     if (lds > 160 * 1024) return 1;
+#ifdef AUGCL_TUNING
+    a.dbg = g_x3_dbg_get();
+    a.abl = getenv("AUGCL_X3_ABL") ? atoi(getenv("AUGCL_X3_ABL")) : 0;
+#endif
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv32_x3<MODE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return augcl::fail(AUGCL_E_LAUNCH, "%s: cannot set dynamic LDS %zu: %s", name, lds, hipGetErrorString(e));
@@ -690,6 +819,21 @@ static int x3_forward_impl(const float *in, const float *w, const float *bias, c
     if (w2) return augcl_internal_conv32_forward_dual(in, w, bias, w2, bias2, out, B, Hi, Wi, relu, stream);
     return augcl_enc_conv32_forward(in, w, bias, out, B, Hi, Wi, relu, stream);
 }
+
+#ifdef AUGCL_TUNING
+static thread_local unsigned long long *g_x3_dbg = nullptr;
+} // extern "C"
+namespace {
+unsigned long long *g_x3_dbg_get() { return g_x3_dbg; }
+} // namespace
+extern "C" {
+// tuning builds: the next x3 forward / backward-data launch of this thread writes its phase stamps to dbg (8192 u64, device)
+int augcl_tuning_x3_set_stamps(void *dbg)
+{
+    g_x3_dbg = reinterpret_cast<unsigned long long *>(dbg);
+    return AUGCL_OK;
+}
+#endif
 
 int augcl_enc_x3_conv32_forward(const float *in, const float *w, const float *bias, float *out, int B, int Hi, int Wi,
                                 int relu, augcl_stream_t stream)

@@ -26,9 +26,14 @@ def _out_hw(h, stride):
     return (h - 3) // stride + 1
 
 
+def _conv32_entry(precision):
+    """prefix of the three 32 -> 32 layer entry points for a precision name (the per-layer path has no bf16 form)"""
+    return "augcl_enc_conv32" if precision == "f32_mfma" else "augcl_enc_x3_conv32"
+
+
 class ConvStackLayerwiseFn(torch.autograd.Function):  # per-layer calls: HeadCNN stacks (relu_first) only
     @staticmethod
-    def forward(ctx, x, first_stride, input_scale, relu_first, n_layers, *wb):
+    def forward(ctx, x, first_stride, input_scale, relu_first, n_layers, precision, *wb):
         weights, biases = wb[:n_layers], wb[n_layers:]
         assert x.dtype == torch.float32 and x.is_contiguous()
         B, C, H, W = x.shape
@@ -51,7 +56,7 @@ class ConvStackLayerwiseFn(torch.autograd.Function):  # per-layer calls: HeadCNN
             else:
                 ho, wo = h - 2, w_ - 2
                 out = torch.empty((B, 32, ho, wo), dtype=torch.float32, device=x.device)
-                call("augcl_enc_conv32_forward", p(acts[-1]), p(wi), p(bi), p(out), B, h, w_, relu, st)
+                call(_conv32_entry(precision) + "_forward", p(acts[-1]), p(wi), p(bi), p(out), B, h, w_, relu, st)
             if need_grad or i == n_layers - 1:
                 acts.append(out)
             else:
@@ -60,12 +65,13 @@ class ConvStackLayerwiseFn(torch.autograd.Function):  # per-layer calls: HeadCNN
         out = acts[-1]
         if need_grad:
             ctx.save_for_backward(*acts[:-1], *[t.detach() for t in weights])
-            ctx.meta = (first_stride, input_scale, n_layers, tuple(x.shape), bool(relu_first))
+            ctx.meta = (first_stride, input_scale, n_layers, tuple(x.shape), bool(relu_first), precision)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        first_stride, input_scale, n_layers, xshape, relu_first = ctx.meta
+        first_stride, input_scale, n_layers, xshape, relu_first, precision = ctx.meta
+        pre = _conv32_entry(precision)
         want_dx = ctx.needs_input_grad[0]
         dx = None
         saved = ctx.saved_tensors
@@ -86,21 +92,21 @@ class ConvStackLayerwiseFn(torch.autograd.Function):  # per-layer calls: HeadCNN
                 call("augcl_enc_conv_first_backward_weights", p(a_prev), p(dz), p(dw), p(db), p(ws), ws.numel() * 4, B,
                      wi.shape[1], a_prev.shape[2], a_prev.shape[3], first_stride, input_scale, st)
             else:
-                call("augcl_enc_conv32_backward_weights", p(a_prev), p(dz), p(dw), p(db), p(ws), ws.numel() * 4, B,
+                call(pre + "_backward_weights", p(a_prev), p(dz), p(dw), p(db), p(ws), ws.numel() * 4, B,
                      a_prev.shape[2], a_prev.shape[3], st)
             dws[i], dbs[i] = dw, db
             if i > 0:
                 dact = torch.empty_like(a_prev)
-                call("augcl_enc_conv32_backward_data", p(dz), p(wi), p(a_prev), p(dact), B, dz.shape[2], dz.shape[3], st)
+                call(pre + "_backward_data", p(dz), p(wi), p(a_prev), p(dact), B, dz.shape[2], dz.shape[3], st)
                 dz = dact
             elif want_dx:
                 if first:
                     raise NotImplementedError("gradient w.r.t. the image input of the strided first layer is not "
                                               "needed on the SAC path and not implemented")
                 dx = torch.empty_like(a_prev)  # HeadCNN: input is the shared CNN's (pre-ReLU) output
-                call("augcl_enc_conv32_backward_data", p(dz), p(wi), p(a_prev) if relu_first else None, p(dx), B,
+                call(pre + "_backward_data", p(dz), p(wi), p(a_prev) if relu_first else None, p(dx), B,
                      dz.shape[2], dz.shape[3], st)
-        return (dx, None, None, None, None, *dws, *dbs)
+        return (dx, None, None, None, None, None, *dws, *dbs)
 
 
 # backward-weights of the bf16 mode: "…_mfma" = bf16 MFMA with transposed LDS reads (37 us / layer); the other entry

@@ -44,8 +44,8 @@ def conv_stack(x, weights, biases, first_stride=2, input_scale=255.0, relu_first
     _lib.require_cuda(x, "conv_stack input")
     from . import encoder_hip
     if relu_first:  # HeadCNN stacks (num_head_layers > 0): per-layer path, f32
-        return encoder_hip.ConvStackLayerwiseFn.apply(x, first_stride, float(input_scale), True, len(weights), *weights,
-                                                      *biases)
+        return encoder_hip.ConvStackLayerwiseFn.apply(x, first_stride, float(input_scale), True, len(weights),
+                                                      "f32_mfma" if PRECISION == "f32_mfma" else "f32", *weights, *biases)
     for w in weights:
         assert w.shape[0] == 32 and w.is_contiguous(), "encoder kernels are built for 32 contiguous filters"
     precision = PRECISION if len(weights) > 1 else "f32"

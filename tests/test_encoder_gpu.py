@@ -147,7 +147,7 @@ def test_bf16_perf_mode_tracks_f32(cuda, B, gate_safe):
             assert float(g @ r / (g.norm() * r.norm())) > 0.95, f"dW layer {i} direction"
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16"])
+@pytest.mark.parametrize("precision", ["f32", "f32_mfma", "bf16"])
 @pytest.mark.parametrize("B", [1, 6, 256])
 def test_dual_stack_forward_equals_two_passes(cuda, B, precision):
     """augcl_enc_stack_forward_dual: two weight sets over the same input in one launch per layer give exactly what two
@@ -174,11 +174,15 @@ def test_dual_stack_forward_equals_two_passes(cuda, B, precision):
                                            [w[:, :3].contiguous() if i == 0 else w for i, w in enumerate(wb)], bb) is None
 
 
-@pytest.mark.parametrize("B,H,W", [(2, 12, 70), (3, 70, 12), (1, 10, 100), (2, 33, 35), (5, 11, 11), (1, 3, 9)])
-def test_conv32_layer_entry_points_on_odd_shapes(cuda, B, H, W):
-    """The three 32 -> 32 layer kernels through the C ABI on shapes the square training stack never produces: wide rows
-    (more than one 64-lane chunk per row in the backward-data loader), tall thin images, single-strip images, the smallest
-    legal size -- against float64 ATen convolutions.  H x W is the layer's INPUT size."""
+@pytest.mark.parametrize("pre", ["augcl_enc_x3_conv32", "augcl_enc_conv32"])
+@pytest.mark.parametrize("B,H,W", [(2, 12, 70), (3, 70, 12), (1, 10, 100), (2, 33, 35), (5, 11, 11), (1, 3, 9), (1, 5, 6), (2, 6, 9),
+                                   (1, 9, 130), (260, 41, 41), (3, 23, 23)])
+def test_conv32_layer_entry_points_on_odd_shapes(cuda, B, H, W, pre):
+    """The three 32 -> 32 layer kernels through the C ABI -- the split-bf16 form (augcl_enc_x3_*: the parity path) and the
+    native f32 MFMA form -- on shapes the square training stack never produces: wide rows (more than one 64-lane chunk per
+    row in the backward-data loader; rows too wide for the split tiles, which hand over to the f32 MFMA kernel), tall thin
+    images, single-strip images, the smallest legal sizes (one quad per row), a batch that is not a multiple of the grid --
+    against float64 ATen convolutions.  H x W is the layer's INPUT size."""
     import ctypes
     import torch.nn.functional as F
     from augcl_amd import _lib
@@ -192,22 +196,22 @@ def test_conv32_layer_entry_points_on_odd_shapes(cuda, B, H, W):
     p = lambda t: t.data_ptr()  # noqa: E731
     # forward (+ ReLU)
     y = torch.full((B, 32, H - 2, W - 2), float("nan"), device=cuda)
-    _lib.call("augcl_enc_conv32_forward", p(x), p(w), p(bias), p(y), B, H, W, 1, st)
+    _lib.call(pre + "_forward", p(x), p(w), p(bias), p(y), B, H, W, 1, st)
     want = torch.relu(F.conv2d(x.double(), w.double(), bias.double()))
     assert float((y.double() - want).abs().max()) <= 2e-5 * float(want.abs().max())
     # backward-data, gated by the layer input's ReLU
     dx = torch.full((B, 32, H, W), float("nan"), device=cuda)
-    _lib.call("augcl_enc_conv32_backward_data", p(dz), p(w), p(x), p(dx), B, H - 2, W - 2, st)
+    _lib.call(pre + "_backward_data", p(dz), p(w), p(x), p(dx), B, H - 2, W - 2, st)
     want = F.conv_transpose2d(dz.double(), w.double()) * (x > 0)
     assert float((dx.double() - want).abs().max()) <= 2e-5 * float(want.abs().max())
     # ... and without a gate
-    _lib.call("augcl_enc_conv32_backward_data", p(dz), p(w), None, p(dx), B, H - 2, W - 2, st)
+    _lib.call(pre + "_backward_data", p(dz), p(w), None, p(dx), B, H - 2, W - 2, st)
     assert float((dx.double() - F.conv_transpose2d(dz.double(), w.double())).abs().max()) <= 2e-5 * float(want.abs().max() + 1)
     # backward-weights
     if W - 2 >= 8:  # the kernel's documented width range (10 <= W <= 170)
         ws = torch.empty(L.augcl_enc_wgrad_workspace_bytes(32) // 4, device=cuda)
         dw, db = torch.full((32, 32, 3, 3), float("nan"), device=cuda), torch.full((32,), float("nan"), device=cuda)
-        _lib.call("augcl_enc_conv32_backward_weights", p(x), p(dz), p(dw), p(db), p(ws), ws.numel() * 4, B, H, W, st)
+        _lib.call(pre + "_backward_weights", p(x), p(dz), p(dw), p(db), p(ws), ws.numel() * 4, B, H, W, st)
         xd = x.double().requires_grad_(False)
         wd = w.double().clone().requires_grad_(True)
         F.conv2d(xd, wd).backward(dz.double())

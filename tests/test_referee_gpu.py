@@ -132,8 +132,8 @@ def hip_forward(x, ws, bs):
     for _ in range(1, n):
         hs.append(hs[-1] - 2)
     acts = [torch.empty((B, 32, h, h), dtype=torch.float32, device=x.device) for h in hs]
-    _lib.call("augcl_enc_stack_forward", x.data_ptr(), _ptrs(ws), _ptrs(bs), _ptrs(acts), n, B, C, H, W, 2, 255.0, 0,
-              _lib.current_stream(x.device))
+    _lib.call("augcl_enc_stack_forward", x.data_ptr(), _ptrs(ws), _ptrs(bs), _ptrs(acts), n, B, C, H, W, 2, 255.0,
+              encoder_hip.PRECISION_CODE[encoder_ops.PRECISION], _lib.current_stream(x.device))
     return acts
 
 
@@ -149,12 +149,16 @@ def hip_backward(x, acts_in, ws, gout):
     ws32, wsf = encoder_hip._workspace(dev, 32, max(1, n - 1)), encoder_hip._workspace(dev, C)
     _lib.call("augcl_enc_stack_backward", _ptrs(acts_in), _ptrs(ws), gout.data_ptr(), _ptrs(dws), _ptrs(dbs), dz.data_ptr(),
               dz.data_ptr() + 4 * big, ws32.data_ptr(), ws32.numel() * 4, wsf.data_ptr(), wsf.numel() * 4, n, B, C, H, W, 2,
-              255.0, 0, 0, _lib.current_stream(dev))
+              255.0, encoder_hip.PRECISION_CODE[encoder_ops.PRECISION], 0, _lib.current_stream(dev))
     return dws, dbs
 
 
-@pytest.mark.parametrize("B,init", [(8, "he"), (8, "delta"), (256, "he"), (256, "delta"), (512, "he")])
-def test_encoder_against_f64_referee(cuda, B, init):
+@pytest.mark.parametrize("B,init,precision", [(8, "he", "f32"), (8, "delta", "f32"), (256, "he", "f32"), (256, "delta", "f32"),
+                                              (512, "he", "f32"), (8, "he", "f32_mfma"), (256, "he", "f32_mfma")])
+def test_encoder_against_f64_referee(cuda, monkeypatch, B, init, precision):
+    """precision "f32" = the parity path (32 -> 32 layers: float32-accurate products on the bf16 MFMA pipe, csrc/encoder_x3.hip);
+    "f32_mfma" = the native f32 MFMA kernels, held to the same bounds."""
+    monkeypatch.setattr(encoder_ops, "PRECISION", precision)
     t0 = time.time()
     _, cs = make_states(init, 6, 11)
     ids = so.conv_layer_ids(11)
@@ -171,7 +175,7 @@ def test_encoder_against_f64_referee(cuda, B, init):
     xd, gd = x.to(cuda), gout.to(cuda)
     wd, bd = [w.to(cuda) for w in ws], [b.to(cuda) for b in bs]
     acts = hip_forward(xd, wd, bd)
-    rep = {"B": B, "init": init, "referee_device": str(rdev)}
+    rep = {"B": B, "init": init, "precision": precision, "referee_device": str(rdev)}
 
     # (1) forward: continuous, so the plain criterion applies
     e_hip, e_cpu = rel_l2(acts[-1], out64), rel_l2(out32, out64)
@@ -218,7 +222,7 @@ def test_encoder_against_f64_referee(cuda, B, init):
                        "hip_pooled": pooled([(a.grad, b) for a, b in zip(wg + bg, dw64 + db64)]),
                        "cpu32_pooled": pooled(list(zip(dw32 + db32, dw64 + db64)))}
     rep["seconds"] = time.time() - t0
-    dump(f"encoder_B{B}_{init}", rep)
+    dump(f"encoder_B{B}_{init}_{precision}", rep)
     # The plain criterion only means something when BOTH float32 evaluations crossed a fair number of near-zero gates
     # (each differing gate is a discrete ~1/sqrt(#pixels) event; with 3 on one side and 0 on the other -- B=256 on the
     # reference's own init -- the ratio says nothing, and (3)/(4) above are the rigorous statement).

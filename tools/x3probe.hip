@@ -12,7 +12,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int K = 288, NT = 64; // NT independent 32x32 problems
+constexpr int K = 288, NT = 512; // NT independent 32x32 problems
 
 __device__ __forceinline__ float bf_hi_rn(float x, float &rest)
 {
@@ -38,13 +38,14 @@ __device__ __forceinline__ void split3(float x, __bf16 &h, __bf16 &m, __bf16 &l)
 }
 
 // mode 0: f32 MFMA; 1: 3 terms (hh, hm, mh); 2: 5 terms (+ hl, lh); 3: 6 terms (+ mm); 4: 9 terms; 5: 6 terms, truncation split
-// 6: 6 terms, small products first
+// 6: 6 terms, small products first; 7: 6 terms, two accumulators of opposite sign (even k-steps +A, odd k-steps -A), D = P - N:
+// the bf16 MFMA's accumulation has a tiny bias toward -infinity (mean error column); it cancels in P - N
 __global__ void k_probe(const float *A, const float *B, float *D, int mode)
 {
     const int lane = threadIdx.x, l31 = lane & 31, h = lane >> 5;
     const float *a = A + (size_t)blockIdx.x * 32 * K, *b = B + (size_t)blockIdx.x * K * 32;
-    f32x16 acc;
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    f32x16 acc, accn;
+    for (int r = 0; r < 16; ++r) acc[r] = accn[r] = 0.0f;
     if (mode == 0) {
         for (int k = 0; k < K; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[l31 * K + k + h], b[(k + h) * 32 + l31], acc, 0, 0, 0);
     } else {
@@ -58,7 +59,15 @@ __global__ void k_probe(const float *A, const float *B, float *D, int mode)
                 bh[j] = x; bm[j] = y; bl[j] = z;
             }
 #define MM(x, y) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, acc, 0, 0, 0)
-            if (mode == 6) {
+            if (mode == 7) {
+                if ((k >> 4) & 1) {
+                    for (int j = 0; j < 8; ++j) { ah[j] = -ah[j]; am[j] = -am[j]; al[j] = -al[j]; }
+#define MN(x, y) accn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, accn, 0, 0, 0)
+                    MN(am, bm); MN(al, bh); MN(ah, bl); MN(am, bh); MN(ah, bm); MN(ah, bh);
+                } else {
+                    MM(am, bm); MM(al, bh); MM(ah, bl); MM(am, bh); MM(ah, bm); MM(ah, bh);
+                }
+            } else if (mode == 6) {
                 MM(am, bm); MM(al, bh); MM(ah, bl); MM(am, bh); MM(ah, bm); MM(ah, bh);
             } else {
                 MM(ah, bh); MM(ah, bm); MM(am, bh);
@@ -69,7 +78,7 @@ __global__ void k_probe(const float *A, const float *B, float *D, int mode)
         }
     }
     float *d = D + (size_t)blockIdx.x * 1024;
-    for (int r = 0; r < 16; ++r) d[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + l31] = acc[r];
+    for (int r = 0; r < 16; ++r) d[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + l31] = acc[r] - accn[r];
 }
 
 int main()
@@ -78,7 +87,8 @@ int main()
     float *dA, *dB, *dD;
     hipMalloc(&dA, A.size() * 4); hipMalloc(&dB, B.size() * 4); hipMalloc(&dD, D.size() * 4);
     const char *names[] = {"f32 mfma 32x32x2", "bf16x3: 3 terms", "bf16x3: 5 terms", "bf16x3: 6 terms", "bf16x3: 9 terms",
-                           "bf16x3: 6 terms, truncation split", "bf16x3: 6 terms, small first"};
+                           "bf16x3: 6 terms, truncation split", "bf16x3: 6 terms, small first",
+                           "bf16x3: 6 terms, +/- accumulators"};
     for (int dist = 0; dist < 4; ++dist) {
         srand(1234 + dist);
         auto rnd = []() { return (rand() + 0.5) / (RAND_MAX + 1.0); };
@@ -95,7 +105,7 @@ int main()
         hipMemcpy(dB, B.data(), B.size() * 4, hipMemcpyHostToDevice);
         const char *dn[] = {"gauss", "relu(gauss)", "1e-6*gauss", "gauss*exp(8*gauss)"};
         printf("== B operand: %s\n", dn[dist]);
-        for (int mode = 0; mode < 7; ++mode) {
+        for (int mode = 0; mode < 8; ++mode) {
             hipLaunchKernelGGL(k_probe, dim3(NT), dim3(64), 0, 0, dA, dB, dD, mode);
             hipMemcpy(D.data(), dD, D.size() * 4, hipMemcpyDeviceToHost);
             double num = 0, den = 0, maxrel = 0, bias = 0, sabs = 0;
