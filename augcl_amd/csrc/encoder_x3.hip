@@ -71,6 +71,7 @@ struct ConvX3Args {
     float *out;          // (B,32,Ho,Wo)
     int B, Hi, Wi, Ho, Wo, RT, S, relu, n_items;
     uint32_t magic_wo;   // floor(2^32 / Wo) + 1
+    uint32_t magic_s;    // floor(2^32 / S) + 1: item / S == umulhi(item, magic_s) for S >= 2 (S == 1 is tested for)
     uint32_t magic_qw;   // MODE 1: floor(2^32 / QW) + 1, QW = quads per dZ row
     const float *w2, *bias2; // two-weight-set forward: images [B/2, B) use w2 / bias2 (odd workgroups)
     int dual;
@@ -151,49 +152,56 @@ __global__ __launch_bounds__(512, 2) void k_conv32_x3(ConvX3Args a)
         // the other buffer from registers whose loads were issued two iterations ago, strips i+2 / i+3 are in flight.
         const int lt = cw * 64 + lane; // 0..255 among the loader threads
         struct Regs {
-            vf4ua d[X3_NU][8];
+            vu4 d[X3_NU][8];
         };
+        // Geometry of an item lives in SGPRs (item is wave-uniform; divisions are multiplications by host-made reciprocals) and
+        // the loads are BUFFER loads: address = resource base + this lane's 32-bit byte offset + a scalar offset that carries
+        // image, first row and channel -- two vector instructions per unit instead of a 64-bit vector address per load.  (The
+        // first version spent ~3500 of a strip's ~11000 cycles in the loaders' integer arithmetic: tools/x3_stamps.py.)
         struct Geo {
-            int b, y0, rows, r0, r1, rbase, nq;
+            int rows, r0, nrow, top;
+            unsigned base; // byte offset of (image b, channel 0, row r0)
         };
         const int QW = (Wi + 3) >> 2; // MODE 1: quads per dZ row (the last one overlaps its neighbour)
+        const unsigned cs4 = (unsigned)(a.Hi * Wi) * 4u; // bytes per channel plane
+        const int cg = lt & 3, q0 = lt >> 2;             // this lane's channel group (8 channels) and first quad
+        const unsigned lane_c = (unsigned)cg * 8u * cs4;
+        const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.in), 0, -1, 0x00020000);
         auto geom = [&](int item) {
             Geo g;
-            g.b = item / a.S;
-            const int s = item - g.b * a.S;
-            g.y0 = s * a.RT;
-            g.rows = min(a.RT, a.Ho - g.y0);
-            g.rbase = g.y0 - P;                                   // image row of tile row 0
-            g.r0 = MODE ? max(0, g.rbase) : g.y0;                 // image rows [r0, r1) exist
-            g.r1 = MODE ? min(a.Hi, g.y0 + g.rows) : g.y0 + g.rows + 2;
-            g.nq = MODE ? (g.r1 - g.r0) * QW : ((g.r1 - g.r0) * Wi + 3) >> 2;
+            const int b = a.S == 1 ? item : (int)__umulhi((uint32_t)item, a.magic_s);
+            const int y0 = (item - b * a.S) * a.RT;
+            g.rows = min(a.RT, a.Ho - y0);
+            const int rbase = y0 - P;                             // image row of tile row 0
+            g.r0 = MODE ? max(0, rbase) : y0;                     // image rows [r0, r0 + nrow) exist
+            g.nrow = (MODE ? min(a.Hi, y0 + g.rows) : y0 + g.rows + 2) - g.r0;
+            g.top = g.r0 - rbase;
+            g.base = (unsigned)((b * 32 * a.Hi + g.r0) * Wi) * 4u;
             return g;
         };
-        // unit -> (channel group cg, first pixel as an offset into the channel plane of the image, LDS pixel of it)
-        auto locate = [&](const Geo &g, int u, int &cg, int &goff, int &lp) {
-            const int unit = u * 256 + lt;
-            cg = unit & 3;
-            const int qd = min(unit >> 2, g.nq - 1); // branch-free: units past the strip repeat its last quad (idempotent)
-            if (MODE == 0) {
-                const int p0 = min(4 * qd, (g.r1 - g.r0) * Wi - 4);
-                goff = g.r0 * Wi + p0;
-                lp = p0;
+        // unit u of this lane -> (byte offset of its 4 pixels inside the lane's first channel plane, LDS byte of the first pixel)
+        auto locate = [&](const Geo &g, int u, unsigned &voff, int &lb) {
+            if (MODE == 0) { // the strip's input rows are one contiguous run: quad qd = pixels 4 qd .. 4 qd + 3 of it
+                const int p0 = min(4 * (q0 + 64 * u), g.nrow * Wi - 4); // units past the run repeat its last quad (idempotent)
+                voff = lane_c + 4u * (unsigned)p0;
+                lb = p0 * X3_SLOT + cg * 16;
             } else {
+                const int qd = min(q0 + 64 * u, g.nrow * QW - 1);
                 const int row = (int)__umulhi((uint32_t)qd, a.magic_qw), x0 = min(4 * (qd - row * QW), Wi - 4);
-                goff = (g.r0 + row) * Wi + x0;
-                lp = (row + g.r0 - g.rbase) * Wl + 2 + x0;
+                voff = lane_c + 4u * (unsigned)(row * Wi + x0);
+                lb = ((row + g.top) * Wl + 2 + x0) * X3_SLOT + cg * 16;
             }
         };
-        const size_t cs = (size_t)a.Hi * Wi;
         auto issue = [&](int item, Regs &R) {
             const Geo g = geom(item);
 #pragma unroll
             for (int u = 0; u < X3_NU; ++u) {
-                int cg, goff, lp;
-                locate(g, u, cg, goff, lp);
-                const float *src = a.in + ((size_t)g.b * 32 + 8 * cg) * cs + goff;
+                unsigned voff;
+                int lb;
+                locate(g, u, voff, lb);
 #pragma unroll
-                for (int c = 0; c < 8; ++c) R.d[u][c] = *reinterpret_cast<const vf4ua *>(src + c * cs);
+                for (int c = 0; c < 8; ++c)
+                    R.d[u][c] = __builtin_bit_cast(vu4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, voff, g.base + (unsigned)c * cs4, 0));
             }
         };
         auto commit = [&](int item, int bi, const Regs &R, bool first_use) {
@@ -201,9 +209,10 @@ __global__ __launch_bounds__(512, 2) void k_conv32_x3(ConvX3Args a)
             char *dst = tiles + bi * bufbytes;
 #pragma unroll
             for (int u = 0; u < X3_NU; ++u) {
-                int cg, goff, lp;
-                locate(g, u, cg, goff, lp);
-                char *o = dst + lp * X3_SLOT + cg * 16;
+                unsigned voff;
+                int lb;
+                locate(g, u, voff, lb);
+                char *o = dst + lb;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     vu4 hi, mid, lo;
@@ -211,14 +220,14 @@ __global__ __launch_bounds__(512, 2) void k_conv32_x3(ConvX3Args a)
                     if (a.abl & 4) { // ablation: no split
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            hi[e] = __float_as_uint(R.d[u][2 * e][j]); mid[e] = __float_as_uint(R.d[u][2 * e + 1][j]); lo[e] = hi[e] ^ mid[e];
+                            hi[e] = R.d[u][2 * e][j]; mid[e] = R.d[u][2 * e + 1][j]; lo[e] = hi[e] ^ mid[e];
                         }
                     } else
 #endif
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         uint32_t th, tm, tl;
-                        split2(R.d[u][2 * e][j], R.d[u][2 * e + 1][j], th, tm, tl);
+                        split2(__uint_as_float(R.d[u][2 * e][j]), __uint_as_float(R.d[u][2 * e + 1][j]), th, tm, tl);
                         hi[e] = th; mid[e] = tm; lo[e] = tl;
                     }
 #ifdef AUGCL_TUNING
@@ -239,19 +248,25 @@ __global__ __launch_bounds__(512, 2) void k_conv32_x3(ConvX3Args a)
                         *reinterpret_cast<vu4 *>(dst + (pr * Wl + px) * X3_SLOT + ch * 16) = zero;
                     }
                 // tile rows above / below the image (first / last strip)
-                const int top = g.r0 - g.rbase, bot = g.rbase + g.rows + 2 - g.r1, rowch = Wi * 12;
+                const int top = g.top, bot = g.rows + 2 - g.top - g.nrow, rowch = Wi * 12;
                 for (int id = lt; id < (top + bot) * rowch; id += 256) {
                     const int jr = id / rowch, rem = id - jr * rowch, x = rem / 12, ch = rem - x * 12;
-                    const int j = jr < top ? jr : (g.r1 - g.rbase) + (jr - top);
+                    const int j = jr < top ? jr : g.nrow + jr; // below the image: tile rows top + nrow + (jr - top)
                     *reinterpret_cast<vu4 *>(dst + (j * Wl + x + 2) * X3_SLOT + ch * 16) = zero;
                 }
             }
         };
-        // The loaders' VALU work (the split: ~450 instructions per lane and strip) shares each SIMD's issue port with a compute
-        // wave that issues an MFMA every 32 cycles; at equal priority it got one instruction in per ~20 cycles and the strip's
-        // commit, 8100 cycles, was longer than the strip's MFMAs (tools/x3_stamps.py).  With priority the loaders take their
-        // slots at once -- an MFMA needs the port for 8 of its 32 cycles -- and are done in a fraction of a strip time.
-        __builtin_amdgcn_s_setprio(2);
+#ifdef AUGCL_TUNING
+        switch ((a.abl >> 3) & 3) { // tuning: loader priority 0 (product) / 1 / 2 / 3
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        case 3: __builtin_amdgcn_s_setprio(3); break;
+        default: break;
+        }
+#else
+        // (product: default priority.  Raised, the loaders' commit took 3700 instead of 3900 cycles but the compute waves'
+        // epilogue 1450 instead of 950: 3.5 % slower over the ten layer sizes -- tools/x3_sweep.py)
+#endif
         Regs ra, rb;
         if (first < n) issue(first, ra);
         X3_STAMP(20);
@@ -344,16 +359,36 @@ __global__ __launch_bounds__(512, 2) void k_conv32_x3(ConvX3Args a)
         }
     }
     X3_STAMP(2);
+#ifdef AUGCL_TUNING
+    switch ((a.abl >> 5) & 3) { // tuning: compute-wave priority 0 (product) / 1 / 2 / 3
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    case 3: __builtin_amdgcn_s_setprio(3); break;
+    default: break;
+    }
+#endif
     const int rowb = Wl * X3_SLOT; // LDS bytes between tile rows
     const int relu_floor = __builtin_amdgcn_readfirstlane(a.relu ? 0 : (int)0x80000000); // opaque: stays ONE v_max_i32
-    // raw buffer resources (base, stride 0, no bound, gfx9 dword-3 flags): offsets < 2^32 by the host's size check
-    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, -1, 0x00020000);
+    // raw buffer resources (base, stride 0, gfx9 dword-3 flags): offsets < 2^32 by the host's size check.  The output's
+    // resource is bounded by the tensor's size, so a lane with nothing to store just names an offset beyond it (kNoStore):
+    // the hardware drops the store and the epilogue needs no branch.
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)((unsigned)(a.B * 32 * a.Ho * a.Wo) * 4u), 0x00020000);
+    constexpr unsigned kNoStore = 0xfffffff0u;
     const __amdgpu_buffer_rsrc_t rs_mask =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(MODE == 1 && a.mask ? a.mask : a.in), 0, -1, 0x00020000);
     const int chw = a.Ho * a.Wo; // 32-bit offsets: the host checks B*32*Ho*Wo < 2^30
 
+    // A tile's 16 output rows are stored WHILE the next tile's MFMAs run (one store after the first MFMA of each of its first
+    // 16 operand groups), also across the strip's barrier: bunched behind the tile they kept the matrix pipe idle for
+    // 950-1450 of a tile's ~5300 cycles (tools/x3_stamps.py; without any stores the ten layers took 14 % less time).
+    float res[16];            // the previous tile's results (bias, ReLU / gate applied)
+    unsigned pboff = kNoStore; // ... and this lane's byte offset for them
+    auto store_row = [&](int r) {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, res[r]), rs_out, pboff,
+                                              (unsigned)(((r & 3) + 8 * (r >> 2)) * chw) * 4u, 0);
+    };
     auto compute = [&](int item, int bi) {
-        const int b = item / a.S, s = item - b * a.S;
+        const int b = a.S == 1 ? item : (int)__umulhi((uint32_t)item, a.magic_s), s = item - b * a.S;
         const int y0 = s * a.RT;
         const int rows = min(a.RT, a.Ho - y0);
         const int npix = rows * a.Wo;
@@ -377,26 +412,33 @@ __global__ __launch_bounds__(512, 2) void k_conv32_x3(ConvX3Args a)
             vu4 xh, xm, xl, wl;
         };
         // operand i of the pixel at `off_`: three ds_read_b128 at row base + immediate (+ the lo weight fragment)
-        auto rd = [&](int off_, int i, Ops &o) {
+        auto rd1 = [&](int off_, int i, Ops &o, int part) { // one of the operand's four reads
             const int t = i >> 1;
             const char *p = tile + off_ + (t / 3) * rowb + ((t % 3) * X3_SLOT + (i & 1) * 32);
-            o.xh = *reinterpret_cast<const vu4 *>(p);
-            o.xm = *reinterpret_cast<const vu4 *>(p + 64);
-            o.xl = *reinterpret_cast<const vu4 *>(p + 128);
-            o.wl = *reinterpret_cast<const vu4 *>(wlf + (i * 64 + lane) * 16);
+            if (part == 0) o.xh = *reinterpret_cast<const vu4 *>(p);
+            else if (part == 1) o.xm = *reinterpret_cast<const vu4 *>(p + 64);
+            else if (part == 2) o.xl = *reinterpret_cast<const vu4 *>(p + 128);
+            else o.wl = *reinterpret_cast<const vu4 *>(wlf + (i * 64 + lane) * 16);
         };
-        auto gates = [&](unsigned bo, float (&g)[16]) {
+        auto rd = [&](int off_, int i, Ops &o) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                g[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                     rs_mask, bo, (unsigned)(((r & 3) + 8 * (r >> 2)) * chw) * 4u, 0));
+            for (int part = 0; part < 4; ++part) rd1(off_, i, o, part);
         };
         bool valid;
         int off;
         unsigned boff;
         locate(cw, valid, off, boff);
-        float gv[16]; // backward-data: this lane's 16 ReLU gates of the CURRENT tile (requested one tile ahead)
-        if (MODE == 1 && a.mask != nullptr) gates(boff, gv);
+        // backward-data: this lane's 16 ReLU gates (the layer input at the addresses it will store to).  Row r of the previous
+        // tile is stored and gate r of the CURRENT tile requested in the same slot of the MFMA stream -- the result register
+        // the store frees is the one the gate lands in -- two rows per operand group over the first eight groups, so the last
+        // gate has ten groups (~2000 cycles) to arrive.
+        float gv[16];
+        auto side_row = [&](int r) {
+            store_row(r);
+            if (a.mask != nullptr)
+                gv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                      rs_mask, boff, (unsigned)(((r & 3) + 8 * (r >> 2)) * chw) * 4u, 0));
+        };
         Ops o0, o1;
         rd(off, 0, o0);
         for (int tl = cw; tl < ntiles; tl += 4) {
@@ -418,48 +460,45 @@ __global__ __launch_bounds__(512, 2) void k_conv32_x3(ConvX3Args a)
             for (int i = 0; i < 18; ++i) {
                 Ops &cur = (i & 1) ? o1 : o0;
                 Ops &nxt = (i & 1) ? o0 : o1;
-                if (i < 17) rd(off, i + 1, nxt); // the next operand's reads run one 6-MFMA group (192 cycles) ahead
-                else rd(off2, 0, nxt);           // ... across the tile boundary
-                __builtin_amdgcn_sched_barrier(0);
-                // smallest products first: wm xm, wl xh, wh xl, wm xh, wh xm, wh xh
-                if (i & 1) {
-                    X3_MM(accn, wm[i], cur.xm);
-                    X3_MM(accn, __builtin_bit_cast(bf16x8, cur.wl), cur.xh);
-                    X3_MM(accn, wh[i], cur.xl);
-                    X3_MM(accn, wm[i], cur.xh);
-                    X3_MM(accn, wh[i], cur.xm);
-                    X3_MM(accn, wh[i], cur.xh);
-                } else {
-                    X3_MM(acc, wm[i], cur.xm);
-                    X3_MM(acc, __builtin_bit_cast(bf16x8, cur.wl), cur.xh);
-                    X3_MM(acc, wh[i], cur.xl);
-                    X3_MM(acc, wm[i], cur.xh);
-                    X3_MM(acc, wh[i], cur.xm);
-                    X3_MM(acc, wh[i], cur.xh);
-                }
-                __builtin_amdgcn_sched_barrier(0);
+                const int noff = i < 17 ? off : off2, ni = i < 17 ? i + 1 : 0; // the next operand (across the tile boundary)
+                // One LDS read of the NEXT operand after each of the first four MFMAs (four reads bunched in front of a group
+                // held the issue port when the next MFMA was due); every read is >= 4 MFMAs (128 cycles) ahead of its use.
+                // Smallest products first: wm xm, wl xh, wh xl, wm xh, wh xm, wh xh.
+#define X3_STEP(A_, B_, PART_)                       \
+    do {                                             \
+        if (i & 1) X3_MM(accn, A_, B_);              \
+        else X3_MM(acc, A_, B_);                     \
+        __builtin_amdgcn_sched_barrier(0);           \
+        if (PART_ >= 0) rd1(noff, ni, nxt, PART_);   \
+        if (MODE == 0 && PART_ == 1 && i < 16) store_row(i);                                  \
+        if (MODE == 1 && (PART_ == 1 || PART_ == 3) && i < 8) side_row(2 * i + (PART_ == 3)); \
+        __builtin_amdgcn_sched_barrier(0);           \
+    } while (0)
+                X3_STEP(wm[i], cur.xm, 1); // (xm is the first operand the next group uses)
+                X3_STEP(__builtin_bit_cast(bf16x8, cur.wl), cur.xh, 3);
+                X3_STEP(wh[i], cur.xl, 0);
+                X3_STEP(wm[i], cur.xh, 2);
+                X3_STEP(wh[i], cur.xm, -1);
+                X3_STEP(wh[i], cur.xh, -1);
+#undef X3_STEP
             }
 #undef X3_MM
+            // rows in accumulator order: co = 0,1,2,3, 8,9,10,11, ... (+4 h in the lane offset).  Forward ReLU on the bit pattern
+            // is one v_max_i32 (negative floats are negative integers; floor INT_MIN = no ReLU); backward-data gates with the
+            // layer input's sign.
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] -= accn[r];
-            X3_STAMP(acc[0] == 12345.678f ? 99 : 12); // (reads acc: after the MFMA chain has drained)
-            // 18 is even: the next tile's operand 0 sits in o0 again
-            if (MODE == 1 && a.mask != nullptr) { // gate in place, request the NEXT tile's gates, then store
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = gv[r] > 0.0f ? acc[r] : 0.0f;
-                if (tl + 4 < ntiles) gates(boff2, gv);
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[r] - accn[r];
+                if (MODE == 0) v = __int_as_float(max(__float_as_int(v), relu_floor));
+                else if (a.mask != nullptr) v = gv[r] > 0.0f ? v : 0.0f;
+                res[r] = v;
             }
-            if (valid) {
-                // rows in accumulator order: co = 0,1,2,3, 8,9,10,11, ... (+4 h in the lane offset).  Forward ReLU on the bit
-                // pattern is one v_max_i32 (negative floats are negative integers; floor INT_MIN = no ReLU).
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float v = acc[r];
-                    if (MODE == 0) v = __int_as_float(max(__float_as_int(v), relu_floor));
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_out, boff,
-                                                          (unsigned)(((r & 3) + 8 * (r >> 2)) * chw) * 4u, 0);
-                }
-            }
+            X3_STAMP(res[0] == 12345.678f ? 99 : 12); // (reads the results: after the MFMA chain has drained)
+            pboff = valid ? boff : kNoStore;
+#ifdef AUGCL_TUNING
+            if ((a.abl & 128) && res[0] != 12345.678f) pboff = kNoStore; // ablation: no output stores
+#endif
+            // (18 is even: the next tile's operand 0 sits in o0 again)
             X3_STAMP(13);
             valid = valid2; off = off2; boff = boff2;
         }
@@ -477,6 +516,8 @@ __global__ __launch_bounds__(512, 2) void k_conv32_x3(ConvX3Args a)
         __syncthreads();
         X3_STAMP(15);
     }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) store_row(r); // the last tile's results
 #ifdef AUGCL_TUNING
     if (dbgp && wave == 0 && lane == 0) {
         a.dbg[8191] = __builtin_amdgcn_s_memrealtime();
@@ -774,6 +815,7 @@ int launch_conv_x3(ConvX3Args &a, const char *name, hipStream_t s)
     a.n_items = a.B * a.S;
     a.magic_wo = (uint32_t)(0x100000000ull / (unsigned)a.Wo) + 1u;
     a.magic_qw = (uint32_t)(0x100000000ull / (unsigned)QW) + 1u;
+    a.magic_s = (uint32_t)(0x100000000ull / (unsigned)a.S) + 1u; // S == 1 wraps to 1: handled in the kernel
     const int tilepix = (a.RT + 2) * Wl + (MODE ? 2 : 0);
     const int bufbytes = std::max(tilepix * X3_SLOT, X3_WST);
     const size_t lds = (size_t)X3_WLF + 128 + 2 * (size_t)bufbytes;
@@ -808,7 +850,7 @@ static int x3_forward_impl(const float *in, const float *w, const float *bias, c
     AUGCL_REQUIRE(aligned16(w) && aligned16(w2), "%s: weights must be 16-byte aligned", name);
     AUGCL_REQUIRE(aligned4(in) && aligned4(out), "%s: tensors must be 4-byte aligned", name);
     AUGCL_REQUIRE(w2 == nullptr || (B & 1) == 0, "%s: a two-weight-set batch must be even", name);
-    AUGCL_REQUIRE((size_t)B * 32 * Hi * Wi < ((size_t)1 << 30), "%s: tensor too large for 32-bit byte offsets (2^30 elements)", name);
+    AUGCL_REQUIRE((size_t)B * 32 * Hi * Wi < ((size_t)1 << 30) - 8, "%s: tensor too large for 32-bit byte offsets (2^30 elements)", name);
     ConvX3Args a{};
     a.in = in; a.w = w; a.bias = bias; a.mask = nullptr; a.out = out;
     a.w2 = w2; a.bias2 = bias2; a.dual = w2 != nullptr;
@@ -858,7 +900,7 @@ int augcl_enc_x3_conv32_backward_data(const float *dz, const float *w, const flo
     AUGCL_REQUIRE(dz && w && dact, "%s: null tensor", name);
     AUGCL_REQUIRE(aligned16(w), "%s: weights must be 16-byte aligned", name);
     AUGCL_REQUIRE(aligned4(dz) && aligned4(dact) && aligned4(act_prev), "%s: tensors must be 4-byte aligned", name);
-    AUGCL_REQUIRE((size_t)B * 32 * (Ho + 2) * (Wo + 2) < ((size_t)1 << 30), "%s: tensor too large for 32-bit byte offsets (2^30 elements)", name);
+    AUGCL_REQUIRE((size_t)B * 32 * (Ho + 2) * (Wo + 2) < ((size_t)1 << 30) - 8, "%s: tensor too large for 32-bit byte offsets (2^30 elements)", name);
     ConvX3Args a{};
     a.in = dz; a.w = w; a.bias = nullptr; a.mask = act_prev; a.out = dact;
     a.B = B; a.Hi = Ho; a.Wi = Wo; a.Ho = Ho + 2; a.Wo = Wo + 2; a.relu = 0;
