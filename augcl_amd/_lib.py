@@ -103,9 +103,10 @@ _SIGS = {
     "augcl_enc_bf16_conv32_backward_weights_mfma": [_P, _P, _P, _P, _P, _SZ, _I, _I, _I, _P],
     "augcl_enc_bf16_conv_first_backward_weights": [_P, _P, _P, _P, _P, _SZ, _I, _I, _I, _I, _I, _F, _P],
     "augcl_enc_nchw_f32_to_nhwc_bf16": [_P, _P, _I, _I, _I, _P],
-    "augcl_enc_stack_forward": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P],
-    "augcl_enc_stack_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P, _SZ, _I, _I, _I, _I, _I, _I, _F, _I, _I, _P],
-    "augcl_enc_stack_forward_dual": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P],
+    "augcl_enc_stack_forward": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P, _SZ, _P],
+    "augcl_enc_frag_workspace_bytes": [_I, _I],
+    "augcl_enc_stack_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P, _SZ, _I, _I, _I, _I, _I, _I, _F, _I, _I, _P, _SZ, _P],
+    "augcl_enc_stack_forward_dual": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P, _SZ, _P],
     "augcl_replay_gather": [_P, _P, _P, _I, _I, _I, _I, _P],
     "augcl_enc_conv_first_forward": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
     "augcl_enc_conv32_forward": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
@@ -117,7 +118,7 @@ _SIGS = {
     "augcl_enc_conv32_backward_weights": [_P, _P, _P, _P, _P, _SZ, _I, _I, _I, _P],
     "augcl_enc_conv_first_backward_weights": [_P, _P, _P, _P, _P, _SZ, _I, _I, _I, _I, _I, _F, _P],
 }
-_RESTYPE = {"augcl_last_error": _c.c_char_p, "augcl_enc_wgrad_workspace_bytes": _SZ}
+_RESTYPE = {"augcl_last_error": _c.c_char_p, "augcl_enc_wgrad_workspace_bytes": _SZ, "augcl_enc_frag_workspace_bytes": _SZ}
 
 _lib = None
 
@@ -140,8 +141,8 @@ def load():
         fn.argtypes = argtypes
         fn.restype = _RESTYPE.get(name, _I)
     ver = lib.augcl_abi_version()
-    if ver != 1:
-        raise AugclError(f"libaugcl_hip.so ABI version {ver} != 1")
+    if ver != 2:
+        raise AugclError(f"libaugcl_hip.so ABI version {ver} != 2 (stale build: run `make -C augcl_amd/csrc`)")
     _lib = lib
     return lib
 

@@ -31,6 +31,9 @@ class AugCL(RAD):
         self.critic_weak = pretrained_agent.critic
         self._weak_group = pretrained_agent.critic_group
         self.critic_weak_optimizer = pretrained_agent.critic_optimizer
+        own = self.critic.encoder.shared_cnn.precision  # the aliased critic now computes inside THIS agent's update()
+        for m in self._cnn_modules():
+            m.precision = own
         if self._graph is not None:  # graphs captured before the hand-off reference the old weak critic
             self.critic_weak_optimizer.make_capturable()
             self._graph.update(graphs={}, static=None, pool=None, seen=0)

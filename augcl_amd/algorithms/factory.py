@@ -21,10 +21,9 @@ def make_agent(obs_shape, action_shape, args):
         except (AttributeError, KeyError):
             return default
 
-    if opt("precision") is not None:  # "f32" (parity path) / "bf16" (performance mode of the conv stack), process-wide
-        from .. import encoder_ops
-        encoder_ops.set_precision(opt("precision"))
     agent = cls(obs_shape, action_shape, args)
+    if opt("precision") is not None:  # "f32" (parity path) / "f32_mfma" / "bf16" (performance mode): THIS agent's conv stacks
+        agent.set_precision(opt("precision"))
     if opt("hip_graph"):    # replay update() as captured hipGraphs
         agent.enable_hip_graphs()
     if opt("action_graph"):  # replay batch-1 select_action / sample_action as captured hipGraphs

@@ -95,6 +95,8 @@ class SharedCNN(nn.Module):
         self.out_shape = torch.Size((num_filters, hw, hw))
         self.apply(weight_init)
 
+    precision = None  # None = encoder_ops' process default; SAC.set_precision sets it per agent
+
     def convs(self):
         return [m for m in self.layers if isinstance(m, nn.Conv2d)]
 
@@ -102,17 +104,17 @@ class SharedCNN(nn.Module):
         x = self.layers[0](x)
         cs = self.convs()
         return encoder_ops.conv_stack(x, [c.weight for c in cs], [c.bias for c in cs], first_stride=2,
-                                      input_scale=255.0, relu_first=False)
+                                      input_scale=255.0, relu_first=False, precision=self.precision)
 
     def forward_with(self, other, x):
         """No-grad forward of this CNN and of `other` (same architecture, other weights) over the same x in one launch
         per layer.  Returns (self(x), other(x)) or None when the fused path does not apply."""
-        if torch.is_grad_enabled() or self.num_layers != other.num_layers:
+        if torch.is_grad_enabled() or self.num_layers != other.num_layers or self.precision != other.precision:
             return None
         x = self.layers[0](x)
         a, b = self.convs(), other.convs()
         return encoder_ops.conv_stack_dual(x, [c.weight for c in a], [c.bias for c in a], [c.weight for c in b],
-                                           [c.bias for c in b], first_stride=2, input_scale=255.0)
+                                           [c.bias for c in b], first_stride=2, input_scale=255.0, precision=self.precision)
 
 
 class HeadCNN(nn.Module):
@@ -129,11 +131,13 @@ class HeadCNN(nn.Module):
         self.out_shape = torch.Size((num_filters * hw * hw,))
         self.apply(weight_init)
 
+    precision = None
+
     def forward(self, x):
         cs = [m for m in self.layers if isinstance(m, nn.Conv2d)]
         if cs:
             x = encoder_ops.conv_stack(x, [c.weight for c in cs], [c.bias for c in cs], first_stride=1,
-                                       input_scale=1.0, relu_first=True)
+                                       input_scale=1.0, relu_first=True, precision=self.precision)
         return x.reshape(x.size(0), -1)
 
 

@@ -285,6 +285,24 @@ class SAC(object):
     def _optimizers(self):
         return [self.critic_optimizer, self.actor_optimizer]
 
+    def _cnn_modules(self):
+        from .modules import HeadCNN, SharedCNN
+        nets = [getattr(self, n, None) for n in ("actor", "critic", "critic_target", "critic_weak")]
+        return [m for net in nets if net is not None for m in net.modules() if isinstance(m, (SharedCNN, HeadCNN))]
+
+    def set_precision(self, name):
+        """Arithmetic of THIS agent's conv stacks (not in the reference): "f32" = parity path, "f32_mfma" = the same tensors
+        on the native f32 MFMA pipe, "bf16" = performance mode, None = follow encoder_ops' process default.  Captured
+        hipGraphs bake the kernels in, so they are dropped and recaptured."""
+        from .. import encoder_ops
+        if name is not None:
+            encoder_ops._check(name)
+        for m in self._cnn_modules():
+            m.precision = name
+        if getattr(self, "_graph", None) is not None:
+            self._graph["graphs"].clear()
+        return self
+
     def enable_hip_graphs(self, warmup=3):
         """Capture `_learn` (every network pass, backward, the all-reduce, Adam and the target EMA) in hipGraphs --
         one per (actor step?, target step?, logging?) variant -- and replay them: one launch per update() instead

@@ -7,18 +7,43 @@ extern "C" {
 
 static inline int out_hw(int h, int stride) { return (h - 3) / stride + 1; }
 
+int augcl_internal_x3_conv32_forward(const float *in, const float *w, const float *bias, const float *w2, const float *bias2,
+                                     float *out, int B, int Hi, int Wi, int relu, const void *wfrag, const void *wfrag2,
+                                     augcl_stream_t stream);
+int augcl_internal_x3_conv32_backward_data(const float *dz, const float *w, const float *act_prev, float *dact, int B, int Ho,
+                                           int Wo, const void *wfrag, augcl_stream_t stream);
+int augcl_internal_x3_prep_weights(const float *const *w, int n, int mode, void *out, augcl_stream_t stream);
+
+// precision 2: the weight fragments of every 32 -> 32 layer are prepared by ONE small launch per pass into frag_ws (>=
+// augcl_enc_frag_workspace_bytes(n_layers - 1, sets) bytes; null / too small: every layer launch prepares its own in its
+// prologue -- ~6 us of a 20-90 us launch).  Returns the per-layer block size in bytes, or 0 when not used.
+static size_t x3_prepare(const float *const *w, int n_layers, int mode, char *ws, size_t ws_bytes, size_t at, augcl_stream_t stream,
+                         int *rc)
+{
+    *rc = AUGCL_OK;
+    const size_t block = augcl_enc_frag_workspace_bytes(1, 1), need = at + (size_t)(n_layers - 1) * block;
+    if (ws == nullptr || n_layers < 2 || n_layers > 33 || ws_bytes < need) return 0;
+    *rc = augcl_internal_x3_prep_weights(w + 1, n_layers - 1, mode, ws + at, stream);
+    return *rc == AUGCL_OK ? block : 0;
+}
+
 // precision: 0 = f32 NCHW activations, f32 MFMA; 1 = bf16 NHWC activations (performance mode); 2 = f32 NCHW activations
 // with the 32 -> 32 layers on the split-bf16 kernels (float32-accurate products on the bf16 pipe: the parity path).
 // acts_out[i] = output buffer of layer i; the last layer always writes f32 NCHW.
 int augcl_enc_stack_forward(const float *x, const float *const *w, const float *const *b, void *const *acts_out,
                             int n_layers, int B, int C, int H, int W, int first_stride, float scale, int precision,
-                            augcl_stream_t stream)
+                            void *frag_ws, size_t frag_ws_bytes, augcl_stream_t stream)
 {
     AUGCL_REQUIRE(x && w && b && acts_out && n_layers >= 1, "augcl_enc_stack_forward: bad argument");
     AUGCL_REQUIRE(precision >= 0 && precision <= 2, "augcl_enc_stack_forward: precision must be 0, 1 or 2");
     AUGCL_REQUIRE(precision != 1 || n_layers >= 2, "augcl_enc_stack_forward: bf16 mode needs >= 2 layers");
     int h = H, ww = W, rc;
     const void *cur = x;
+    size_t fblock = 0;
+    if (precision == 2) {
+        fblock = x3_prepare(w, n_layers, 0, (char *)frag_ws, frag_ws_bytes, 0, stream, &rc);
+        if (rc != AUGCL_OK) return rc;
+    }
     for (int i = 0; i < n_layers; ++i) {
         const int relu = i < n_layers - 1;
         const bool last = i == n_layers - 1;
@@ -35,7 +60,8 @@ int augcl_enc_stack_forward(const float *x, const float *const *w, const float *
             if (precision == 0)
                 rc = augcl_enc_conv32_forward((const float *)cur, w[i], b[i], (float *)acts_out[i], B, h, ww, relu, stream);
             else if (precision == 2)
-                rc = augcl_enc_x3_conv32_forward((const float *)cur, w[i], b[i], (float *)acts_out[i], B, h, ww, relu, stream);
+                rc = augcl_internal_x3_conv32_forward((const float *)cur, w[i], b[i], nullptr, nullptr, (float *)acts_out[i], B, h, ww,
+                                                      relu, fblock ? (char *)frag_ws + (size_t)(i - 1) * fblock : nullptr, nullptr, stream);
             else
                 rc = augcl_enc_bf16_conv32_forward(cur, w[i], b[i], acts_out[i], B, h, ww, relu, last ? 1 : 0, stream);
             h -= 2;
@@ -50,9 +76,6 @@ int augcl_enc_stack_forward(const float *x, const float *const *w, const float *
 int augcl_internal_conv32_forward_dual(const float *in, const float *w, const float *bias, const float *w2,
                                        const float *bias2, float *out, int B2, int Hi, int Wi, int relu,
                                        augcl_stream_t stream);
-int augcl_internal_x3_conv32_forward_dual(const float *in, const float *w, const float *bias, const float *w2,
-                                          const float *bias2, float *out, int B2, int Hi, int Wi, int relu,
-                                          augcl_stream_t stream);
 int augcl_internal_bf16_conv32_forward_dual(const void *in_bf16_nhwc, const float *w, const float *bias, const float *w2,
                                             const float *bias2, void *out, int B2, int Hi, int Wi, int relu,
                                             int out_f32_nchw, augcl_stream_t stream);
@@ -63,7 +86,8 @@ int augcl_internal_bf16_conv32_forward_dual(const void *in_bf16_nhwc, const floa
 // Returns AUGCL_E_UNSUPPORTED for shapes without a pipelined first-layer kernel: the caller then runs two passes.
 int augcl_enc_stack_forward_dual(const float *x, const float *const *wA, const float *const *bA, const float *const *wB,
                                  const float *const *bB, void *const *acts_out, int n_layers, int B, int C, int H, int W,
-                                 int first_stride, float scale, int precision, augcl_stream_t stream)
+                                 int first_stride, float scale, int precision, void *frag_ws, size_t frag_ws_bytes,
+                                 augcl_stream_t stream)
 {
     const char *name = "augcl_enc_stack_forward_dual";
     AUGCL_REQUIRE(x && wA && bA && wB && bB && acts_out && n_layers >= 2 && B >= 1, "%s: bad argument", name);
@@ -73,14 +97,25 @@ int augcl_enc_stack_forward_dual(const float *x, const float *const *wA, const f
     if (rc > 0) return augcl::fail(AUGCL_E_UNSUPPORTED, "%s: first-layer shape (%d,%d,%d) stride %d not covered", name, C, H, W, first_stride);
     if (rc != AUGCL_OK) return rc;
     int h = out_hw(H, first_stride), ww = out_hw(W, first_stride);
+    size_t fblock = 0;
+    const size_t setB = (size_t)(n_layers - 1) * augcl_enc_frag_workspace_bytes(1, 1); // set B's blocks follow set A's
+    if (precision == 2 && frag_ws_bytes >= 2 * setB) {
+        fblock = x3_prepare(wA, n_layers, 0, (char *)frag_ws, frag_ws_bytes, 0, stream, &rc);
+        if (rc != AUGCL_OK) return rc;
+        if (fblock) {
+            x3_prepare(wB, n_layers, 0, (char *)frag_ws, frag_ws_bytes, setB, stream, &rc);
+            if (rc != AUGCL_OK) return rc;
+        }
+    }
     for (int i = 1; i < n_layers; ++i) {
         const int relu = i < n_layers - 1;
         if (precision == 0)
             rc = augcl_internal_conv32_forward_dual((const float *)acts_out[i - 1], wA[i], bA[i], wB[i], bB[i],
                                                     (float *)acts_out[i], B2, h, ww, relu, stream);
         else if (precision == 2)
-            rc = augcl_internal_x3_conv32_forward_dual((const float *)acts_out[i - 1], wA[i], bA[i], wB[i], bB[i],
-                                                       (float *)acts_out[i], B2, h, ww, relu, stream);
+            rc = augcl_internal_x3_conv32_forward((const float *)acts_out[i - 1], wA[i], bA[i], wB[i], bB[i], (float *)acts_out[i], B2,
+                                                  h, ww, relu, fblock ? (char *)frag_ws + (size_t)(i - 1) * fblock : nullptr,
+                                                  fblock ? (char *)frag_ws + setB + (size_t)(i - 1) * fblock : nullptr, stream);
         else
             rc = augcl_internal_bf16_conv32_forward_dual(acts_out[i - 1], wA[i], bA[i], wB[i], bB[i], acts_out[i], B2, h, ww,
                                                          relu, i == n_layers - 1 ? 1 : 0, stream);
@@ -97,7 +132,8 @@ int augcl_enc_stack_forward_dual(const float *x, const float *const *wA, const f
 int augcl_enc_stack_backward(const void *const *acts_in, const float *const *w, const float *grad_out, float *const *dw,
                              float *const *db, void *dz_a, void *dz_b, float *ws32, size_t ws32_bytes, float *ws_first,
                              size_t ws_first_bytes, int n_layers, int B, int C, int H, int W, int first_stride,
-                             float scale, int precision, int bf16_wgrad_mfma, augcl_stream_t stream)
+                             float scale, int precision, int bf16_wgrad_mfma, void *frag_ws, size_t frag_ws_bytes,
+                             augcl_stream_t stream)
 {
     AUGCL_REQUIRE(acts_in && w && grad_out && dw && db && dz_a && dz_b && n_layers >= 1, "augcl_enc_stack_backward: bad argument");
     int hs[64], wsz[64]; // input size of every layer
@@ -115,6 +151,11 @@ int augcl_enc_stack_backward(const void *const *acts_in, const float *const *w, 
         ~Scope() { if (on) augcl::reduce_defer_abort(); }
     } scope{batched};
     if (batched) augcl::reduce_defer_begin();
+    size_t fblock = 0;
+    if (precision == 2) { // backward-data fragments (transposed weights, flipped taps) of every 32 -> 32 layer: one launch
+        fblock = x3_prepare(w, n_layers, 1, (char *)frag_ws, frag_ws_bytes, 0, stream, &rc);
+        if (rc != AUGCL_OK) return rc;
+    }
     const void *dz = grad_out; // f32 NCHW (B,32,hs[n],ws[n])
     if (precision == 1) {
         rc = augcl_enc_nchw_f32_to_nhwc_bf16(grad_out, dz_a, B, hs[n_layers], wsz[n_layers], stream);
@@ -141,8 +182,8 @@ int augcl_enc_stack_backward(const void *const *acts_in, const float *const *w, 
             rc = augcl_enc_conv32_backward_data((const float *)dz, w[i], (const float *)acts_in[i], (float *)nxt, B, hs[i + 1],
                                                 wsz[i + 1], stream);
         else if (precision == 2)
-            rc = augcl_enc_x3_conv32_backward_data((const float *)dz, w[i], (const float *)acts_in[i], (float *)nxt, B, hs[i + 1],
-                                                   wsz[i + 1], stream);
+            rc = augcl_internal_x3_conv32_backward_data((const float *)dz, w[i], (const float *)acts_in[i], (float *)nxt, B, hs[i + 1],
+                                                        wsz[i + 1], fblock ? (char *)frag_ws + (size_t)(i - 1) * fblock : nullptr, stream);
         else
             rc = augcl_enc_bf16_conv32_backward_data(dz, w[i], acts_in[i], nxt, B, hs[i + 1], wsz[i + 1], stream);
         if (rc != AUGCL_OK) return rc;

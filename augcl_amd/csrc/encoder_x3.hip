@@ -75,6 +75,9 @@ struct ConvX3Args {
     uint32_t magic_qw;   // MODE 1: floor(2^32 / QW) + 1, QW = quads per dZ row
     const float *w2, *bias2; // two-weight-set forward: images [B/2, B) use w2 / bias2 (odd workgroups)
     int dual;
+    // weight fragments prepared by k_x3_prep (whole-stack entry points: one small launch per pass instead of a 36 KB staging +
+    // 144-value split in every layer launch's prologue), or null: [3 components][18 operands][64 lanes] x 16 B
+    const vu4 *wfrag, *wfrag2;
     int abl;                 // tuning builds only: ablation bits (1: no MFMA loop, 2: loaders skip the LDS stores, 4: ... the split)
     unsigned long long *dbg; // tuning builds only (-DAUGCL_TUNING): (shader clock << 8 | event id) records of workgroup 0
 };
@@ -126,7 +129,13 @@ __global__ __launch_bounds__(512, 2) void k_conv32_x3(ConvX3Args a)
     // ---- weights: the 4 compute waves copy the 36 KB of f32 masters into LDS with coalesced 16-byte loads (into the region
     // of tile buffer 1, which the loaders first write after the second barrier) WHILE the loaders already have the first
     // strip's loads in flight: the two memory latencies of the prologue overlap
-    if (!loader) {
+    const vu4 *const wfrag = grp ? a.wfrag2 : a.wfrag; // prepared fragments (wave-uniform choice) or null
+    if (!loader && wfrag != nullptr) {
+        const float *bsrc = grp ? a.bias2 : a.bias;
+        if (tid < 32) lbias[tid] = (MODE == 0 && bsrc) ? bsrc[tid] : 0.0f;
+        __syncthreads();
+        X3_STAMP(1);
+    } else if (!loader) {
         float *wst = reinterpret_cast<float *>(tiles + bufbytes);
         const vf4 *w4 = reinterpret_cast<const vf4 *>(grp ? a.w2 : a.w);
         const float *bsrc = grp ? a.bias2 : a.bias;
@@ -323,7 +332,14 @@ __global__ __launch_bounds__(512, 2) void k_conv32_x3(ConvX3Args a)
     // (measured: db 1.2e-5 off float64 ten layers down at B = 8).  Two accumulators of opposite sign carry the same bias, so
     // it cancels in the difference (mean error -1.4e-9 -> -2e-12, rel-L2 2.6e-7 -> 1.8e-7: two shorter chains).
     bf16x8 wh[18], wm[18];
-    {
+    if (wfrag != nullptr) { // 36 coalesced 16-byte loads per lane; the lo fragments go to LDS (each wave a quarter)
+#pragma unroll
+        for (int i = 0; i < 18; ++i) {
+            wh[i] = __builtin_bit_cast(bf16x8, wfrag[i * 64 + lane]);
+            wm[i] = __builtin_bit_cast(bf16x8, wfrag[(18 + i) * 64 + lane]);
+            if ((i & 3) == cw) *reinterpret_cast<vu4 *>(wlf + (i * 64 + lane) * 16) = wfrag[(36 + i) * 64 + lane];
+        }
+    } else {
         const float *wst = reinterpret_cast<const float *>(tiles + bufbytes);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -774,6 +790,44 @@ __global__ __launch_bounds__(512, 2) void k_wgrad32_x3(WgX3Args a)
     }
 }
 
+
+// Weight fragments of a whole stack in one small launch: block (operand i, layer): lane l computes the fragment
+// W_eff[row l & 31][k = 16 s + 8 (l >> 5) + j][tap t] of operand i = 2 t + s exactly as k_conv32_x3's prologue does (odd operands
+// negated) and stores its hi / mid / lo parts into that layer's block [3][18][64] x 16 B.
+constexpr int X3_FRAG_VU4 = 3 * 18 * 64; // 16-byte entries per layer block (55296 bytes)
+struct PrepX3Args {
+    const float *w[32]; // (32,32,3,3) weights of the layers to prepare
+    vu4 *out;           // [n][X3_FRAG_VU4]
+    int mode;           // 0: forward fragments, 1: backward-data (transposed, flipped taps)
+};
+
+__global__ __launch_bounds__(64) void k_x3_prep(PrepX3Args a)
+{
+    const int lane = threadIdx.x, l31 = lane & 31, h = lane >> 5;
+    const int i = blockIdx.x, t = i >> 1, s = i & 1;
+    const float *w = a.w[blockIdx.y];
+    vu4 fh, fm, fl;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float v0, v1;
+        if (a.mode == 0) { // W[co = l31][ci = k][t]
+            v0 = w[l31 * 288 + (16 * s + 8 * h + 2 * e) * 9 + t];
+            v1 = w[l31 * 288 + (16 * s + 8 * h + 2 * e + 1) * 9 + t];
+        } else {           // W'[ci = l31][co = k][t] = W[co][ci][8 - t]
+            v0 = w[(16 * s + 8 * h + 2 * e) * 288 + l31 * 9 + (8 - t)];
+            v1 = w[(16 * s + 8 * h + 2 * e + 1) * 288 + l31 * 9 + (8 - t)];
+        }
+        if (s) { v0 = -v0; v1 = -v1; }
+        uint32_t th, tm, tl;
+        split2(v0, v1, th, tm, tl);
+        fh[e] = th; fm[e] = tm; fl[e] = tl;
+    }
+    vu4 *o = a.out + (size_t)blockIdx.y * X3_FRAG_VU4;
+    o[i * 64 + lane] = fh;
+    o[(18 + i) * 64 + lane] = fm;
+    o[(36 + i) * 64 + lane] = fl;
+}
+
 } // namespace augcl
 
 using namespace augcl;
@@ -842,7 +896,8 @@ int augcl_internal_conv32_forward_dual(const float *in, const float *w, const fl
                                        augcl_stream_t stream);
 
 static int x3_forward_impl(const float *in, const float *w, const float *bias, const float *w2, const float *bias2, float *out,
-                           int B, int Hi, int Wi, int relu, augcl_stream_t stream, const char *name)
+                           int B, int Hi, int Wi, int relu, augcl_stream_t stream, const char *name,
+                           const void *wfrag = nullptr, const void *wfrag2 = nullptr)
 {
     AUGCL_REQUIRE(B >= 0 && Hi >= 3 && Wi >= 3, "%s: bad shape", name);
     if (B == 0) return AUGCL_OK;
@@ -854,6 +909,9 @@ static int x3_forward_impl(const float *in, const float *w, const float *bias, c
     ConvX3Args a{};
     a.in = in; a.w = w; a.bias = bias; a.mask = nullptr; a.out = out;
     a.w2 = w2; a.bias2 = bias2; a.dual = w2 != nullptr;
+    a.wfrag = reinterpret_cast<const vu4 *>(wfrag);
+    a.wfrag2 = reinterpret_cast<const vu4 *>(w2 ? wfrag2 : nullptr);
+    if (w2 && (wfrag == nullptr) != (wfrag2 == nullptr)) a.wfrag = a.wfrag2 = nullptr; // both sets prepared, or neither
     a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ho = Hi - 2; a.Wo = Wi - 2; a.relu = relu;
     const int rc = launch_conv_x3<0>(a, name, as_stream(stream));
     if (rc <= 0) return rc;
@@ -883,16 +941,56 @@ int augcl_enc_x3_conv32_forward(const float *in, const float *w, const float *bi
     return x3_forward_impl(in, w, bias, nullptr, nullptr, out, B, Hi, Wi, relu, stream, "augcl_enc_x3_conv32_forward");
 }
 
-// internal (encoder_stack.cpp): B2 images, the first half with (w, bias), the second with (w2, bias2)
-int augcl_internal_x3_conv32_forward_dual(const float *in, const float *w, const float *bias, const float *w2,
-                                          const float *bias2, float *out, int B2, int Hi, int Wi, int relu,
-                                          augcl_stream_t stream)
+// internal (encoder_stack.cpp): one layer with PREPARED weight fragments (augcl_internal_x3_prep_weights; null = the kernel
+// prepares its own); w2 != null: B images, the first half with (w, bias), the second with (w2, bias2)
+int augcl_internal_x3_conv32_forward(const float *in, const float *w, const float *bias, const float *w2, const float *bias2,
+                                     float *out, int B, int Hi, int Wi, int relu, const void *wfrag, const void *wfrag2,
+                                     augcl_stream_t stream)
 {
-    return x3_forward_impl(in, w, bias, w2, bias2, out, B2, Hi, Wi, relu, stream, "augcl_enc_stack_forward_dual");
+    return x3_forward_impl(in, w, bias, w2, bias2, out, B, Hi, Wi, relu, stream,
+                           w2 ? "augcl_enc_stack_forward_dual" : "augcl_enc_stack_forward", wfrag, wfrag2);
 }
+
+size_t augcl_enc_frag_workspace_bytes(int n_layers, int weight_sets)
+{
+    if (n_layers < 1 || weight_sets < 1) return 0;
+    return (size_t)n_layers * (size_t)weight_sets * X3_FRAG_VU4 * 16;
+}
+
+// internal: fragments of n (<= 32) 32 -> 32 layers into out[n][X3_FRAG_VU4] (mode 0 forward, 1 backward-data): ONE launch
+int augcl_internal_x3_prep_weights(const float *const *w, int n, int mode, void *out, augcl_stream_t stream)
+{
+    const char *name = "augcl_internal_x3_prep_weights";
+    AUGCL_REQUIRE(w && out && n >= 1 && n <= 32 && (mode == 0 || mode == 1) && aligned16(out), "%s: bad argument", name);
+    PrepX3Args a{};
+    for (int i = 0; i < n; ++i) {
+        AUGCL_REQUIRE(w[i] != nullptr, "%s: null weight tensor", name);
+        a.w[i] = w[i];
+    }
+    a.out = reinterpret_cast<vu4 *>(out);
+    a.mode = mode;
+    hipLaunchKernelGGL(k_x3_prep, dim3(18, n), dim3(64), 0, as_stream(stream), a);
+    return augcl::check_launch(name);
+}
+
+static int x3_backward_data_impl(const float *dz, const float *w, const float *act_prev, float *dact, int B, int Ho, int Wo,
+                                 const void *wfrag, augcl_stream_t stream);
 
 int augcl_enc_x3_conv32_backward_data(const float *dz, const float *w, const float *act_prev, float *dact, int B, int Ho,
                                       int Wo, augcl_stream_t stream)
+{
+    return x3_backward_data_impl(dz, w, act_prev, dact, B, Ho, Wo, nullptr, stream);
+}
+
+// internal (encoder_stack.cpp): with prepared mode-1 fragments
+int augcl_internal_x3_conv32_backward_data(const float *dz, const float *w, const float *act_prev, float *dact, int B, int Ho,
+                                           int Wo, const void *wfrag, augcl_stream_t stream)
+{
+    return x3_backward_data_impl(dz, w, act_prev, dact, B, Ho, Wo, wfrag, stream);
+}
+
+static int x3_backward_data_impl(const float *dz, const float *w, const float *act_prev, float *dact, int B, int Ho, int Wo,
+                                 const void *wfrag, augcl_stream_t stream)
 {
     const char *name = "augcl_enc_x3_conv32_backward_data";
     AUGCL_REQUIRE(B >= 0 && Ho >= 1 && Wo >= 1, "%s: bad shape", name);
@@ -903,6 +1001,7 @@ int augcl_enc_x3_conv32_backward_data(const float *dz, const float *w, const flo
     AUGCL_REQUIRE((size_t)B * 32 * (Ho + 2) * (Wo + 2) < ((size_t)1 << 30) - 8, "%s: tensor too large for 32-bit byte offsets (2^30 elements)", name);
     ConvX3Args a{};
     a.in = dz; a.w = w; a.bias = nullptr; a.mask = act_prev; a.out = dact;
+    a.wfrag = reinterpret_cast<const vu4 *>(wfrag);
     a.B = B; a.Hi = Ho; a.Wi = Wo; a.Ho = Ho + 2; a.Wo = Wo + 2; a.relu = 0;
     const int rc = launch_conv_x3<1>(a, name, as_stream(stream));
     if (rc <= 0) return rc;

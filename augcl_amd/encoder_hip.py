@@ -22,6 +22,22 @@ def _workspace(dev, c_in, count=1):
     return _ws[key]
 
 
+_fws = {}
+
+
+def _frag_ws(dev, n_layers32, sets=1):
+    """scratch for the prepared weight fragments of the split-bf16 layers (augcl_enc_stack_*'s frag_ws): one buffer per
+    device, sized for the largest request; its contents only live inside one stack call"""
+    need = _lib.load().augcl_enc_frag_workspace_bytes(int(n_layers32), int(sets))
+    t = _fws.get(dev)
+    if t is None or t.numel() < need:
+        if dev.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            raise _lib.AugclError("weight-fragment workspace requested for the first time inside a hipGraph capture; run one "
+                                  "eager update first (SAC.enable_hip_graphs keeps warmup >= 1)")
+        t = _fws[dev] = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
+    return t
+
+
 def _out_hw(h, stride):
     return (h - 3) // stride + 1
 
@@ -144,9 +160,10 @@ def conv_stack_dual(x, weights_a, biases_a, weights_b, biases_b, first_stride, i
     arena = torch.empty(2 * big, dtype=adt, device=dev)  # two ping-pong buffers
     ptrs = [arena.data_ptr() + (i & 1) * big * arena.element_size() for i in range(n_layers - 1)] + [out.data_ptr()]
     d = lambda ts: _ptr_array([t.detach().data_ptr() for t in ts])  # noqa: E731
+    fws = _frag_ws(dev, n_layers - 1, 2) if precision == "f32" else None
     _lib.call("augcl_enc_stack_forward_dual", x.data_ptr(), d(weights_a), d(biases_a), d(weights_b), d(biases_b),
               _ptr_array(ptrs), n_layers, B, C, H, W, first_stride, input_scale, PRECISION_CODE[precision],
-              _lib.current_stream(dev))
+              _lib.ptr(fws), fws.numel() if fws is not None else 0, _lib.current_stream(dev))
     return out
 
 
@@ -186,9 +203,11 @@ class ConvStackFn(torch.autograd.Function):
             arena = torch.empty(2 * big, dtype=adt, device=dev)
             ptrs = [arena.data_ptr() + (i & 1) * big * arena.element_size() for i in range(n_layers - 1)]
         ptrs.append(out.data_ptr())
+        fws = _frag_ws(dev, n_layers - 1) if precision == "f32" and n_layers > 1 else None
         _lib.call("augcl_enc_stack_forward", x.data_ptr(), _ptr_array([t.data_ptr() for t in weights]),
                   _ptr_array([t.data_ptr() for t in biases]), _ptr_array(ptrs), n_layers, B, C, H, W, first_stride,
-                  input_scale, PRECISION_CODE[precision], _lib.current_stream(dev))
+                  input_scale, PRECISION_CODE[precision], _lib.ptr(fws), fws.numel() if fws is not None else 0,
+                  _lib.current_stream(dev))
         if need_grad:
             ctx.save_for_backward(x, arena, *weights)
             ctx.meta = (first_stride, input_scale, precision, n_layers, ptrs[:-1], max(numel))
@@ -208,9 +227,11 @@ class ConvStackFn(torch.autograd.Function):
         dz = torch.empty(2 * ((max_numel + 7) // 8 * 8), dtype=torch.bfloat16 if bf16 else torch.float32, device=dev)
         half = dz.numel() // 2 * dz.element_size()
         ws32, wsf = _workspace(dev, 32, max(1, n_layers - 1)), _workspace(dev, C)
+        fws = _frag_ws(dev, n_layers - 1) if precision == "f32" and n_layers > 1 else None
         _lib.call("augcl_enc_stack_backward", _ptr_array([x.data_ptr()] + list(act_ptrs)),
                   _ptr_array([w.data_ptr() for w in weights]), g.data_ptr(), _ptr_array([t.data_ptr() for t in dws]),
                   _ptr_array([dbs[i].data_ptr() for i in range(n_layers)]), dz.data_ptr(), dz.data_ptr() + half,
                   ws32.data_ptr(), ws32.numel() * 4, wsf.data_ptr(), wsf.numel() * 4, n_layers, B, C, H, W, first_stride,
-                  input_scale, PRECISION_CODE[precision], 1 if _BF16_WGRAD.endswith("_mfma") else 0, _lib.current_stream(dev))
+                  input_scale, PRECISION_CODE[precision], 1 if _BF16_WGRAD.endswith("_mfma") else 0, _lib.ptr(fws),
+                  fws.numel() if fws is not None else 0, _lib.current_stream(dev))
         return (None, None, None, None, None, *dws, *[dbs[i] for i in range(n_layers)])

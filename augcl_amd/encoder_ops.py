@@ -8,7 +8,9 @@ Precision: "f32" = parity path (f32 NCHW activations; the 32 -> 32 layers split 
 parts and run the six significant cross products on the bf16 MFMA pipe with f32 accumulation -- float32 accuracy at
 2.67x the f32 MFMA rate, csrc/encoder_x3.hip); "f32_mfma" = the same tensors on the native f32 MFMA pipe (kept for
 A/B); "bf16" = performance mode of BASELINE config 2 (bf16 NHWC activations, bf16 MFMA, f32 accumulation / master
-weights / weight gradients).  One precision per process, selected with `set_precision` (`args.precision` calls it).
+weights / weight gradients).  `set_precision` sets the process default; an agent built with `args.precision` (or
+`agent.set_precision(name)`) carries its own choice on its CNN modules, so a bf16 agent and an f32 agent (the pretrained
+agent AugCL loads, an evaluation copy) can live in one process.
 """
 import torch
 
@@ -19,12 +21,16 @@ PRECISION = "f32"
 
 def set_precision(name):
     global PRECISION
+    PRECISION = _check(name)
+
+
+def _check(name):
     if name not in ("f32", "f32_mfma", "bf16"):
         raise ValueError(f"precision must be 'f32', 'f32_mfma' or 'bf16', got {name!r}")
-    PRECISION = name
+    return name
 
 
-def conv_stack_dual(x, weights_a, biases_a, weights_b, biases_b, first_stride=2, input_scale=255.0):
+def conv_stack_dual(x, weights_a, biases_a, weights_b, biases_b, first_stride=2, input_scale=255.0, precision=None):
     """No-grad forward of TWO stacks with identical shapes over the same input in one launch per layer; returns the two
     outputs, or None when the fused path does not cover the case (it needs a 9 x H x 84 input and stride 2)."""
     if not x.is_cuda or len(weights_a) != len(weights_b) or len(weights_a) < 2:
@@ -32,21 +38,25 @@ def conv_stack_dual(x, weights_a, biases_a, weights_b, biases_b, first_stride=2,
     if any(a.shape != b.shape for a, b in zip(weights_a, weights_b)) or x.dtype != torch.float32:
         return None
     from . import encoder_hip
-    out = encoder_hip.conv_stack_dual(x, weights_a, biases_a, weights_b, biases_b, first_stride, float(input_scale), PRECISION)
+    out = encoder_hip.conv_stack_dual(x, weights_a, biases_a, weights_b, biases_b, first_stride, float(input_scale),
+                                      _check(precision or PRECISION))
     if out is None:
         return None
     B = x.shape[0]
     return out[:B], out[B:]
 
 
-def conv_stack(x, weights, biases, first_stride=2, input_scale=255.0, relu_first=False):
-    """x: (B,C,H,W) f32 (0..255 when input_scale=255).  Returns the last conv's output (no final ReLU)."""
+def conv_stack(x, weights, biases, first_stride=2, input_scale=255.0, relu_first=False, precision=None):
+    """x: (B,C,H,W) f32 (0..255 when input_scale=255).  Returns the last conv's output (no final ReLU).
+    precision: None = the process default (`set_precision`)."""
     _lib.require_cuda(x, "conv_stack input")
     from . import encoder_hip
+    prec = _check(precision or PRECISION)
     if relu_first:  # HeadCNN stacks (num_head_layers > 0): per-layer path, f32
         return encoder_hip.ConvStackLayerwiseFn.apply(x, first_stride, float(input_scale), True, len(weights),
-                                                      "f32_mfma" if PRECISION == "f32_mfma" else "f32", *weights, *biases)
+                                                      "f32_mfma" if prec == "f32_mfma" else "f32", *weights, *biases)
     for w in weights:
         assert w.shape[0] == 32 and w.is_contiguous(), "encoder kernels are built for 32 contiguous filters"
-    precision = PRECISION if len(weights) > 1 else "f32"
-    return encoder_hip.ConvStackFn.apply(x, first_stride, float(input_scale), precision, len(weights), *weights, *biases)
+    if len(weights) == 1 and prec == "bf16":
+        prec = "f32"  # a lone first layer has no bf16 activation to hand on
+    return encoder_hip.ConvStackFn.apply(x, first_stride, float(input_scale), prec, len(weights), *weights, *biases)

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define AUGCL_ABI_VERSION 1
+#define AUGCL_ABI_VERSION 2 /* 2: the whole-stack entry points take a weight-fragment workspace */
 
 #define AUGCL_OK 0
 #define AUGCL_E_INVALID (-1)   /* bad argument (null pointer, bad shape, misalignment) */
@@ -337,14 +337,20 @@ int augcl_enc_nchw_f32_to_nhwc_bf16(const float *in, void *out_bf16_nhwc, int B,
  * with the 32 -> 32 layers on the split-bf16 kernels (augcl_enc_x3_*: float32-accurate, the default parity path).
  * forward: acts_out[i] = output buffer of layer i (the last layer always writes f32 NCHW).
  * backward: acts_in[i] = input of layer i (acts_in[0] = the raw f32 image batch); dz_a / dz_b = two scratch buffers
- * of the largest activation's size; dw[i] / db[i] receive the weight / bias gradients. */
+ * of the largest activation's size; dw[i] / db[i] receive the weight / bias gradients.
+ * frag_ws (precision 2 only; may be NULL): device scratch of augcl_enc_frag_workspace_bytes(n_layers - 1, sets) bytes
+ * (sets = 1, 2 for the dual forward), 16-byte aligned.  With it the bf16 hi / mid / lo fragments of every 32 -> 32
+ * layer's weights are made by ONE small launch per pass; without it every layer launch splits its own weights in its
+ * prologue (same values, ~6 us per launch more).  The contents are scratch: valid only inside the call. */
+size_t augcl_enc_frag_workspace_bytes(int n_layers32, int weight_sets);
 int augcl_enc_stack_forward(const float *x, const float *const *w, const float *const *b, void *const *acts_out,
                             int n_layers, int B, int C, int H, int W, int first_stride, float scale, int precision,
-                            augcl_stream_t stream);
+                            void *frag_ws, size_t frag_ws_bytes, augcl_stream_t stream);
 int augcl_enc_stack_backward(const void *const *acts_in, const float *const *w, const float *grad_out, float *const *dw,
                              float *const *db, void *dz_a, void *dz_b, float *ws32, size_t ws32_bytes, float *ws_first,
                              size_t ws_first_bytes, int n_layers, int B, int C, int H, int W, int first_stride,
-                             float scale, int precision, int bf16_wgrad_mfma, augcl_stream_t stream);
+                             float scale, int precision, int bf16_wgrad_mfma, void *frag_ws, size_t frag_ws_bytes,
+                             augcl_stream_t stream);
 
 /* Two encoders with identical shapes over the SAME input batch in one launch per layer (no-grad passes: the actor's CNN
  * and the target critic's CNN over next_obs, src/algorithms/sac.py:94-101).  acts_out[i] holds 2B images: [0,B) from
@@ -352,7 +358,8 @@ int augcl_enc_stack_backward(const void *const *acts_in, const float *const *w, 
  * shape has no pipelined kernel (9 x H x 84, stride 2): run two augcl_enc_stack_forward passes instead. */
 int augcl_enc_stack_forward_dual(const float *x, const float *const *wA, const float *const *bA, const float *const *wB,
                                  const float *const *bB, void *const *acts_out, int n_layers, int B, int C, int H, int W,
-                                 int first_stride, float scale, int precision, augcl_stream_t stream);
+                                 int first_stride, float scale, int precision, void *frag_ws, size_t frag_ws_bytes,
+                                 augcl_stream_t stream);
 
 /* ---- device-resident replay sampling: ReplayBuffer.sample -> tensor_buffer_samples / _encode_obses /
  * LazyFrames._force (src/utils.py:206-214, 234-240, 272-280, 293-299).  `frames` is a uint8 ring of RGB frames
