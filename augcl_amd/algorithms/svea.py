@@ -48,7 +48,10 @@ class SVEA(RAD):
         the uint8 frame ring (ReplayBuffer.sample_shift_conv): the first tensor of the batch is then already the
         (2B,C,H,W) stack `_front_end` would build."""
         fused = getattr(replay_buffer, "sample_shift_conv", None)
-        if fused is None or not self._fused_front_end(None):
+        # the fused kernel exists for square 84 / 100 frames (augcl_replay_shift_conv_u8_f32); any other ring geometry takes
+        # sample() + the un-fused front end, as it did before the fused path existed
+        hw = (getattr(replay_buffer, "h", None), getattr(replay_buffer, "w", None))
+        if fused is None or not self._fused_front_end(None, hw=hw):
             return replay_buffer.sample()
         static = self._graph["static"] if self._graph is not None and self._graph["seen"] >= self._graph["warmup"] else None
         if static is not None and static[0].shape[0] != 2 * replay_buffer.batch_size:
@@ -79,8 +82,10 @@ class SVEA(RAD):
         if do_target:
             self.soft_update_critic_target()
 
-    def _fused_front_end(self, obs):
+    def _fused_front_end(self, obs, hw=None):
         a = self.aug_funcs
+        if hw is None and obs is not None:
+            hw = (obs.shape[-2], obs.shape[-1])
         return (list(a) == ["conv"] and a["conv"]["func"] is augmentations.random_conv and not a["conv"]["params"]
-                and (obs is None or (obs.shape[-1] in (84, 100) and obs.shape[-2] == obs.shape[-1]))
+                and hw is not None and hw[1] in (84, 100) and hw[0] == hw[1]
                 and getattr(self, "fuse_front_end", True))

@@ -38,6 +38,32 @@ def set_sample_base(sample0):
     _rng["sample0"] = int(sample0)
 
 
+def set_conv_weight_stream(name):
+    """Where random_conv's per-sample weights come from when none are passed: "philox" (default: drawn inside the kernel,
+    keyed by (seed, call, global sample index) -- no host step, invariant to sharding) or "reference": the reference's own
+    stream, one CPU `torch.randn(3, 3, 3, 3)` per sample in order on torch's default generator
+    (src/augmentations.py:268-269), uploaded once per batch -- a run seeded like a reference run then sees the SAME
+    augmented batches (graph capture needs the device stream: hipGraph replay keeps "philox")."""
+    if name not in ("philox", "reference"):
+        raise ValueError(f"conv weight stream must be 'philox' or 'reference', got {name!r}")
+    _rng["conv_stream"] = name
+
+
+def _conv_weights(weights, B, device):
+    """explicit (B,3,3,3,3) weights, the string "reference" / the module's reference-stream mode, or None (in-kernel draw)"""
+    if weights is None and _rng.get("conv_stream", "philox") == "reference":
+        weights = "reference"
+    if isinstance(weights, str):
+        if weights != "reference":
+            raise ValueError("random_conv: weights must be a tensor, 'reference' or None")
+        weights = torch.stack([torch.randn(3, 3, 3, 3) for _ in range(B)])  # the reference's draw order, CPU generator
+    if weights is not None:
+        weights = torch.as_tensor(weights, device=device, dtype=torch.float32).contiguous()
+        if weights.numel() != B * 81:
+            raise ValueError("random_conv: weights must hold B*81 values")
+    return weights
+
+
 def _next_call():
     off = _rng["offset"]
     _rng["offset"] = off + 1
@@ -91,17 +117,15 @@ def random_shift(imgs, pad=4, *, oy=None, ox=None, out=None):
 def random_conv(x, *, weights=None, out=None):
     """src/augmentations.py:265-274: per-sample random 3x3 conv (3->3 channels, shared by the
     sample's frames) on x/255 with replicate padding, sigmoid, *255.
-    weights: optional (B,3,3,3,3) tensor replacing the per-sample N(0,1) draw."""
+    weights: optional (B,3,3,3,3) tensor replacing the per-sample N(0,1) draw, or "reference" = draw them like the
+    reference does (one CPU torch.randn(3,3,3,3) per sample, in order: see set_conv_weight_stream)."""
     _check_bchw(x, "random_conv")
     if x.dtype != torch.float32:
         raise TypeError("random_conv: float32 input expected")
     B, C, H, W = x.shape
     if C % 3:
         raise ValueError("random_conv: channel count must be a multiple of 3")
-    if weights is not None:
-        weights = torch.as_tensor(weights, device=x.device, dtype=torch.float32).contiguous()
-        if weights.numel() != B * 81:
-            raise ValueError("random_conv: weights must hold B*81 values")
+    weights = _conv_weights(weights, B, x.device)
     seed, off, s0 = _next_call()
     if out is None:
         out = torch.empty_like(x)
@@ -118,8 +142,7 @@ def shift_conv(obs, pad=4, *, oy=None, ox=None, weights=None, want_shift=True, w
     B, C, H, W = obs.shape
     oy = _i32(oy, B, obs.device, "oy")
     ox = _i32(ox, B, obs.device, "ox")
-    if weights is not None:
-        weights = torch.as_tensor(weights, device=obs.device, dtype=torch.float32).contiguous()
+    weights = _conv_weights(weights, B, obs.device)
     seed, off, s0 = _next_call()
     if stacked:
         both = out if out is not None else torch.empty((2 * B, C, H, W), dtype=torch.float32, device=obs.device)

@@ -213,8 +213,7 @@ class ReplayBuffer(object):
         assert both.shape == (2 * B, C, self.h, self.w) and both.dtype == torch.float32 and both.is_contiguous()
         oy = augmentations._i32(oy, B, self.device, "oy")
         ox = augmentations._i32(ox, B, self.device, "ox")
-        if weights is not None:
-            weights = torch.as_tensor(weights, device=self.device, dtype=torch.float32).contiguous()
+        weights = augmentations._conv_weights(weights, B, self.device)
         seed, off, s0 = augmentations._next_call()
         st = _lib.current_stream(self.device)
         _lib.call("augcl_replay_shift_conv_u8_f32", self.frames.data_ptr(), self.slot_tab.data_ptr(), it.data_ptr(),

@@ -120,6 +120,31 @@ def test_conv_golden(cuda, golden_aug):
     assert err <= CONV_ATOL_VS_ORACLE, err
 
 
+def test_conv_reference_weight_stream_reproduces_the_reference_run(cuda, golden_aug):
+    """src/augmentations.py:268-269 draws one CPU torch.randn(3,3,3,3) per sample, in order, on the default generator.
+    Seeded as tests/golden/make_golden.py seeds the reference (torch.manual_seed(202)), the reference-stream mode reproduces
+    the reference's OWN output without being handed its weights -- per call (weights="reference"), as the module default
+    (set_conv_weight_stream), and through the fused shift + conv front end."""
+    x = gi.obs_u8(11, 2).astype(np.float32)
+    torch.manual_seed(202)
+    got = host(aug.random_conv(dev(x, cuda), weights="reference"))
+    assert np.abs(got - golden_aug["conv_out"]).max() <= CONV_ATOL
+    aug.set_conv_weight_stream("reference")
+    try:
+        torch.manual_seed(202)
+        got2 = host(aug.random_conv(dev(x, cuda)))
+        assert np.array_equal(got, got2)
+        # fused front end: random_conv(random_shift(x)) with a zero shift = pad 4 / offset 4 = the identity crop
+        torch.manual_seed(202)
+        z = np.full(2, 4, np.int32)
+        _, o_a = aug.shift_conv(dev(x, cuda), oy=z, ox=z)
+        assert np.abs(host(o_a) - golden_aug["conv_out"]).max() <= CONV_ATOL
+    finally:
+        aug.set_conv_weight_stream("philox")
+    torch.manual_seed(202)
+    assert not np.array_equal(host(aug.random_conv(dev(x, cuda))), got)  # back on the in-kernel Philox stream
+
+
 @pytest.mark.parametrize("shape", [(16, 9, 84, 84), (3, 3, 84, 84), (2, 9, 100, 100), (2, 6, 40, 52)])
 def test_conv_vs_oracle(cuda, shape):
     B = shape[0]

@@ -158,3 +158,48 @@ def test_networks_match_reference(G):
     mu, pi, log_pi, log_std = so.actor_forward(as_, x.detach(), hp, noise)
     for k, v in (("mu", mu), ("pi", pi), ("log_pi", log_pi), ("log_std", log_std)):
         np.testing.assert_allclose(v.detach().numpy(), G[f"nets/{k}"], rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ head layers
+def head_case():
+    """The scenario of tests/golden/make_golden_head.py (num_shared_layers = 8, num_head_layers = 2, A = 6, B = 3)."""
+    sys_path_golden = os.path.join(ROOT, "tests", "golden")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden_head", os.path.join(sys_path_golden, "make_golden_head.py"))
+    mh = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mh)  # (defines the scenario; the reference is only imported inside its main())
+    as_, cs = mh.states()
+    return mh, as_, cs, mh.batch(), mh.noises()
+
+
+def test_head_layers_match_reference():
+    """src/algorithms/modules.py:168-181 (HeadCNN with layers, shared by actor and critic: sac.py:20-33): the oracle's
+    networks and one SAC update() against vectors minted from the reference."""
+    G = np.load(os.path.join(ROOT, "tests", "golden", "head_golden.npz"))
+    mh, as_, cs, batch, nz = head_case()
+    hp, A = mh.HP, mh.A
+    obs, act = batch[0], batch[1]
+    p = {k: v.clone().requires_grad_(True) for k, v in cs.items()}
+    feat = so.cnn_forward(p, obs, hp)
+    np.testing.assert_allclose(feat.detach().numpy().reshape(G["head/features"].shape), G["head/features"], rtol=1e-5, atol=1e-6)
+    q1, q2 = so.critic_forward(p, obs, act, hp)
+    (q1.sum() + 2.0 * q2.sum()).backward()
+    np.testing.assert_allclose(q1.detach().numpy(), G["head/q1"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(q2.detach().numpy(), G["head/q2"], rtol=1e-5, atol=1e-6)
+    names = list(so.critic_shapes(OBS, A, hp).keys())
+    got = so.checksum({n: p[n].grad for n in names}, names)
+    np.testing.assert_allclose(got[:, 1], G["head/critic_grad_ck"][:, 1], rtol=1e-5)
+    mu, pi, log_pi, _ = so.actor_forward(as_, obs, hp, nz[0])
+    for k, v in (("mu", mu), ("pi", pi), ("log_pi", log_pi)):
+        np.testing.assert_allclose(v.detach().numpy(), G[f"head/{k}"], rtol=1e-5, atol=1e-6)
+    agent = so.OracleAgent("sac", OBS, A, as_, cs, hp=hp)
+    log = agent.update(batch, 0, nz[1], nz[2])
+    for k, want in zip([str(k) for k in G["head/log_keys"]], G["head/logs"]):
+        atol = RTOL * (ENT_CONST(A) + abs(want)) if k.endswith("mean_entropy") else RTOL
+        assert log[k] == pytest.approx(want, rel=RTOL, abs=atol), k
+    for ck, params, nm in (("critic_ck", agent.critic, agent.critic_names), ("actor_ck", agent.actor, agent.actor_names),
+                           ("target_ck", agent.critic_target, agent.critic_names)):
+        got = so.checksum(params, nm)
+        np.testing.assert_allclose(got[:, 1], G[f"head/{ck}"][:, 1], rtol=1e-5)
+        np.testing.assert_allclose(got[:, 2:], G[f"head/{ck}"][:, 2:], rtol=1e-4, atol=2e-6)
+    assert float(agent.log_alpha) == pytest.approx(float(G["head/log_alpha"][0]), rel=1e-9)

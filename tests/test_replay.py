@@ -217,3 +217,44 @@ def test_fused_sample_shift_conv_equals_sample_then_front_end(cuda):
         torch.cuda.synchronize()
         snaps.append((agent.critic_group.param.clone(), agent.actor_group.param.clone()))
     assert torch.equal(snaps[0][0], snaps[1][0]) and torch.equal(snaps[0][1], snaps[1][1])
+
+
+@pytest.mark.gpu
+def test_svea_hip_graph_update_on_the_device_ring_and_other_frame_sizes(cuda):
+    """SVEA.update() against a REAL ReplayBuffer with hipGraphs enabled: the fused sample -> shift -> conv launch writes
+    straight into the captured graph's static input (SVEA._sample, out=static[0]); the trajectory equals the eager one.
+    A ring whose frames are not 84 x 84 / 100 x 100 (no fused kernel) takes sample() + the un-fused front end instead of
+    raising inside update()."""
+    import torch
+
+    from augcl_amd import augmentations as aug
+    from augcl_amd import utils as au
+    from augcl_amd.algorithms import make_agent
+    from augcl_amd.replay import LazyFrames, ReplayBuffer
+    from oracle import sac_oracle as so
+    rb = ReplayBuffer((9, 84, 84), (A,), capacity=96, batch_size=B, device=cuda)
+    for of, a, r, nf, d in gi.replay_stream(seed=43, n=80, A=A):
+        rb.add(LazyFrames(of), a, r, LazyFrames(nf), d)
+    snaps = []
+    for graph in (False, True):
+        torch.manual_seed(3)
+        aug.manual_seed(9)
+        np.random.seed(9)
+        agent = make_agent((9, 84, 84), (A,), au.dotdict(algorithm="svea", data_aug="conv", aug_params=None, **so.DEFAULTS))
+        if graph:
+            agent.enable_hip_graphs(warmup=2)
+        for step in range(8):
+            agent.update(rb, None, step)
+        torch.cuda.synchronize()
+        if graph:
+            assert len(agent._graph["graphs"]) >= 2 and agent._graph["static"][0].shape[0] == 2 * B
+        snaps.append((agent.critic_group.param.clone(), agent.actor_group.param.clone(), agent.log_alpha.detach().clone()))
+    for x, y in zip(*snaps):
+        assert float((x.double() - y.double()).abs().max()) <= 1e-5 * max(1.0, float(x.abs().max()))
+    # another geometry: the gate looks at the ring's own frame size
+    odd = ReplayBuffer((9, 64, 64), (A,), capacity=32, batch_size=4, device=cuda)
+    for of, a, r, nf, d in gi.replay_stream(seed=44, n=20, A=A, H=64, W=64):
+        odd.add(LazyFrames(of), a, r, LazyFrames(nf), d)
+    assert not agent._fused_front_end(None, hw=(odd.h, odd.w)) and agent._fused_front_end(None, hw=(rb.h, rb.w))
+    got = agent._sample(odd)
+    assert len(got) == 5 and got[0].shape == (4, 9, 64, 64)  # plain sample(), not the (2B, ...) fused stack

@@ -637,3 +637,89 @@ def test_bf16_update_tracks_f32_update(cuda, monkeypatch):
     c0 = build_agent("svea", "conv", A, as_, cs, cuda, hp=hp).critic_group.param
     d32, d16 = (c32 - c0).double(), (c16 - c0).double()
     assert float(d32 @ d16 / (d32.norm() * d16.norm())) > 0.9
+
+
+def test_head_layers_match_reference_golden(cuda, monkeypatch):
+    """Agents WITH head layers (num_head_layers = 2: HeadCNN = [ReLU, Conv]* on the shared CNN's un-activated output, shared
+    by actor and critic -- src/algorithms/modules.py:168-181, sac.py:20-33) against vectors minted from the reference
+    (tests/golden/make_golden_head.py): the relu_first per-layer conv path forward and backward (its input gradient feeds the
+    shared stack's backward), Q values, the critic's parameter gradients, the policy head, and one full update()."""
+    import test_oracle_golden_sac as TO
+    G = np.load(os.path.join(ROOT, "tests", "golden", "head_golden.npz"))
+    mh, as_, cs, batch, nz = TO.head_case()
+    hp, A = mh.HP, mh.A
+    agent = build_agent("sac", "identity", A, as_, cs, cuda, hp=hp)
+    obs, act = batch[0].to(cuda), batch[1].to(cuda)
+    enc = agent.critic.encoder
+    assert agent.actor.encoder.head_cnn is enc.head_cnn and len(list(enc.head_cnn.parameters())) == 4
+    with torch.no_grad():
+        feat = enc.head_cnn(enc.shared_cnn(obs))
+    np.testing.assert_allclose(feat.cpu().numpy().reshape(G["head/features"].shape), G["head/features"], rtol=1e-5, atol=1e-6)
+    q1, q2 = agent.critic(obs, act)
+    (q1.sum() + 2.0 * q2.sum()).backward()
+    np.testing.assert_allclose(q1.detach().cpu().numpy(), G["head/q1"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(q2.detach().cpu().numpy(), G["head/q2"], rtol=1e-5, atol=1e-6)
+    names = list(so.critic_shapes(T.OBS, A, hp).keys())
+    got = so.checksum({n: p.grad.cpu() for n, p in agent.critic.named_parameters()}, names)
+    want = G["head/critic_grad_ck"]
+    np.testing.assert_allclose(got[:, 1], want[:, 1], rtol=1e-5)
+    shapes = so.critic_shapes(T.OBS, A, hp)
+    for n, g_row, w_row in zip(names, got, want):
+        scale = max(np.abs(w_row[2:]).max(), w_row[1] / int(np.prod(shapes[n])))
+        np.testing.assert_allclose(g_row[2:], w_row[2:], rtol=1e-4, atol=1e-4 * scale, err_msg=n)
+    monkeypatch.setattr(torch, "randn_like", lambda t, *a_, **k: nz[0].to(cuda))
+    with torch.no_grad():
+        mu, pi, log_pi, _ = agent.actor(obs)
+    for k, v in (("mu", mu), ("pi", pi), ("log_pi", log_pi)):
+        np.testing.assert_allclose(v.cpu().numpy(), G[f"head/{k}"], rtol=1e-5, atol=1e-6, err_msg=k)
+    # one update() from the golden state (critic, actor + alpha, target EMA at step 0)
+    agent = build_agent("sac", "identity", A, as_, cs, cuda, hp=hp)
+    queue = [nz[1].to(cuda), nz[2].to(cuda)]
+    monkeypatch.setattr(torch, "randn_like", lambda t, *a_, **k: queue.pop(0))
+    L = RecLogger()
+    agent.update(FakeBuffer(tuple(t.to(cuda) for t in batch)), L, 0)
+    torch.cuda.synchronize()
+    for k, want in zip([str(k) for k in G["head/log_keys"]], G["head/logs"]):
+        atol = RTOL0 * (T.ENT_CONST(A) + abs(want)) if k.endswith("mean_entropy") else RTOL0
+        assert L.rows[(0, k)] == pytest.approx(want, rel=RTOL0, abs=atol), k
+    cn, an = list(so.critic_shapes(T.OBS, A, hp).keys()), list(so.actor_shapes(T.OBS, A, hp).keys())
+    for ck, mod, nm in (("critic_ck", agent.critic, cn), ("actor_ck", agent.actor, an), ("target_ck", agent.critic_target, cn)):
+        got = so.checksum({n: p.detach().cpu() for n, p in mod.named_parameters()}, nm)
+        np.testing.assert_allclose(got[:, 1], G[f"head/{ck}"][:, 1], rtol=1e-5, err_msg=ck)
+        np.testing.assert_allclose(got[:, 2:], G[f"head/{ck}"][:, 2:], rtol=1e-4, atol=2e-6, err_msg=ck)
+    assert float(agent.log_alpha) == pytest.approx(float(G["head/log_alpha"][0]), rel=1e-7)
+
+
+def test_head_layers_hip_graph_update_matches_eager(cuda):
+    """The same architecture through captured hipGraphs: 8 SVEA updates, every (actor step?, target step?) variant, equal to
+    the eager trajectory (the head CNN's parameters get no gradient in the actor step: the device-step Adam must cope)."""
+    import test_oracle_golden_sac as TO
+    mh, as_, cs, _, _ = TO.head_case()
+    hp, A, B = mh.HP, mh.A, 8
+    batches = _svea_batches(cuda, B, A, seed=5)
+
+    class Ring:
+        def __init__(self):
+            self.i = 0
+
+        def sample(self, n=None, idxs=None):
+            self.i += 1
+            return tuple(t.clone() for t in batches[self.i % 3])
+
+    snaps = []
+    for graph in (False, True):
+        torch.manual_seed(21)
+        aug.manual_seed(22)
+        agent = build_agent("svea", "conv", A, as_, cs, cuda, hp=hp)
+        if graph:
+            agent.enable_hip_graphs(warmup=2)
+        buf = Ring()
+        for step in range(8):
+            agent.update(buf, None, step)
+        torch.cuda.synchronize()
+        if graph:
+            assert len(agent._graph["graphs"]) >= 2
+        snaps.append((agent.critic_group.param.clone(), agent.actor_group.param.clone(), agent.target_group.param.clone()))
+    for x, y in zip(*snaps):
+        assert bool(torch.isfinite(x).all())
+        assert float((x.double() - y.double()).abs().max()) <= 1e-5 * max(1.0, float(x.abs().max()))
