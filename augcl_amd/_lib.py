@@ -57,6 +57,7 @@ _SIGS = {
     "augcl_philox_shift_offsets": [_U64, _U64, _I, _I, _I, _P, _P, _P],
     "augcl_philox_conv_weights": [_U64, _U64, _I, _I, _P, _P],
     "augcl_philox_normal": [_U64, _U64, _SZ, _P, _P],
+    "augcl_philox_replay_indices": [_U64, _U64, _I, _I, _P, _I, _P],
     "augcl_random_shift_f32": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _U64, _U64, _I, _P],
     "augcl_random_shift_u8": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _U64, _U64, _I, _P],
     "augcl_random_shift_u8_f32": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _U64, _U64, _I, _P],

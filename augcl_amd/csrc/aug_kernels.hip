@@ -729,6 +729,15 @@ __global__ void k_philox_conv_w(uint64_t seed, uint64_t offset, int sample0, int
     }
 }
 
+__global__ void k_philox_replay_idx(uint64_t seed, uint64_t offset, int sample0, uint32_t n_valid, int64_t *idx, int B)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) {
+        const u32x4 r = philox_sample(seed, offset, (uint32_t)(sample0 + b), 32u);
+        idx[b] = (int64_t)(((uint64_t)r.x * n_valid) >> 32);
+    }
+}
+
 __global__ void k_philox_normal(uint64_t seed, uint64_t offset, size_t n, float *out)
 {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; // one Philox call = 4 normals
@@ -996,6 +1005,16 @@ int augcl_philox_conv_weights(uint64_t seed, uint64_t offset, int sample0, int B
     hipLaunchKernelGGL(k_philox_conv_w, dim3((B * 21 + 255) / 256), dim3(256), 0, as_stream(stream), seed, offset,
                        sample0, B, weights);
     LAUNCH_CHECK("augcl_philox_conv_weights");
+}
+
+int augcl_philox_replay_indices(uint64_t seed, uint64_t offset, int sample0, int n_valid, int64_t *idx, int B,
+                                augcl_stream_t stream)
+{
+    AUGCL_REQUIRE(B >= 0 && (B == 0 || (idx && n_valid >= 1)), "augcl_philox_replay_indices: bad argument (empty buffer?)");
+    if (B == 0) return AUGCL_OK;
+    hipLaunchKernelGGL(k_philox_replay_idx, dim3((B + 255) / 256), dim3(256), 0, as_stream(stream), seed, offset, sample0,
+                       (uint32_t)n_valid, idx, B);
+    LAUNCH_CHECK("augcl_philox_replay_indices");
 }
 
 int augcl_philox_normal(uint64_t seed, uint64_t offset, size_t n, float *out, augcl_stream_t stream)

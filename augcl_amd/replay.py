@@ -46,7 +46,7 @@ class LazyFrames(object):
 
 class ReplayBuffer(object):
     def __init__(self, obs_shape, action_shape, capacity, batch_size, prefill=True, device=None, frame_slack=None,
-                 sample_dtype=torch.float32):
+                 sample_dtype=torch.float32, index_stream="numpy"):
         c, h, w = obs_shape
         assert c % 3 == 0, "observations are stacks of RGB frames"
         if device is None:
@@ -78,6 +78,13 @@ class ReplayBuffer(object):
         self._scal = pin(torch.empty((A + 2,), dtype=torch.float32))
         self._slots = pin(torch.empty((2 * self.stack,), dtype=torch.int32))
         self.sample_dtype = sample_dtype
+        # where sample()'s transition indices come from: "numpy" = np.random.randint on the GLOBAL generator like the
+        # reference (src/utils.py:229-232; one H2D copy of the indices per call), "device" = drawn by a Philox launch keyed
+        # like the augmentations (augcl_philox_replay_indices): sample() / sample_shift_conv() are then launches only
+        if index_stream not in ("numpy", "device"):
+            raise ValueError("index_stream must be 'numpy' or 'device'")
+        self.index_stream = index_stream
+        self._idx_dev = None
         self.idx = 0
         self._adds = 0
         self.full = False
@@ -153,6 +160,20 @@ class ReplayBuffer(object):
             n = self.batch_size
         return np.random.randint(0, self.capacity if self.full else self.idx, size=n)
 
+    def _device_idxs(self, n=None):
+        """B transition indices drawn on the device (no host step; the ring invariant add() maintains makes every live
+        transition valid, so nothing needs checking on the host)."""
+        from . import augmentations
+        B = self.batch_size if n is None else int(n)
+        n_valid = self.capacity if self.full else self.idx
+        if n_valid < 1:
+            raise IndexError("replay sample: the buffer is empty")
+        if self._idx_dev is None or self._idx_dev.numel() != B:
+            self._idx_dev = torch.empty(B, dtype=torch.int64, device=self.device)
+        seed, off, s0 = augmentations._next_call()
+        _lib.call("augcl_philox_replay_indices", seed, off, s0, n_valid, self._idx_dev.data_ptr(), B, _lib.current_stream(self.device))
+        return self._idx_dev
+
     def _gather(self, seqs, dtype):
         live = self.frame_seq - self.n_slots
         if seqs.min() < live:
@@ -183,12 +204,15 @@ class ReplayBuffer(object):
     def sample(self, n=None, idxs=None, dtype=None):
         """src/utils.py:272-280: returns (obs, actions, rewards, next_obs, not_dones) on the device -- one H2D copy
         of the drawn indices and one launch (augcl_replay_sample) for all five tensors."""
-        if idxs is None:
-            idxs = self._get_idxs(n)
-        idxs = self._checked_idxs(idxs)
+        if idxs is None and self.index_stream == "device":
+            it = self._device_idxs(n)
+        else:
+            if idxs is None:
+                idxs = self._get_idxs(n)
+            idxs = self._checked_idxs(idxs)
+            it = torch.from_numpy(idxs).to(self.device, non_blocking=True)
         dtype = dtype or self.sample_dtype
-        B, A = idxs.shape[0], self.A
-        it = torch.from_numpy(idxs).to(self.device, non_blocking=True)
+        B, A = it.shape[0], self.A
         obs = torch.empty((B, 3 * self.stack, self.h, self.w), dtype=dtype, device=self.device)
         next_obs = torch.empty_like(obs)
         sc = torch.empty(B * (A + 2), dtype=torch.float32, device=self.device)
@@ -204,11 +228,14 @@ class ReplayBuffer(object):
         (63.5 KB read per observation instead of 63.5 KB read + 254 KB written + 254 KB read again).  Bit-identical to
         `sample()` followed by `augmentations.shift_conv(obs, stacked=True)` with the same parameters / Philox call."""
         from . import augmentations
-        if idxs is None:
-            idxs = self._get_idxs(n)
-        idxs = self._checked_idxs(idxs)
-        B, A, C = idxs.shape[0], self.A, 3 * self.stack
-        it = torch.from_numpy(idxs).to(self.device, non_blocking=True)
+        if idxs is None and self.index_stream == "device":
+            it = self._device_idxs(n)
+        else:
+            if idxs is None:
+                idxs = self._get_idxs(n)
+            idxs = self._checked_idxs(idxs)
+            it = torch.from_numpy(idxs).to(self.device, non_blocking=True)
+        B, A, C = it.shape[0], self.A, 3 * self.stack
         both = out if out is not None else torch.empty((2 * B, C, self.h, self.w), dtype=torch.float32, device=self.device)
         assert both.shape == (2 * B, C, self.h, self.w) and both.dtype == torch.float32 and both.is_contiguous()
         oy = augmentations._i32(oy, B, self.device, "oy")

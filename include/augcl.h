@@ -57,6 +57,10 @@ int augcl_philox_shift_offsets(uint64_t seed, uint64_t offset, int sample0, int 
 int augcl_philox_conv_weights(uint64_t seed, uint64_t offset, int sample0, int B,
                               float *weights /* B x 81 */, augcl_stream_t stream);
 int augcl_philox_normal(uint64_t seed, uint64_t offset, size_t n, float *out, augcl_stream_t stream);
+/* replay sampling indices drawn ON the device (ReplayBuffer.sample's np.random.randint(0, n_valid, B), src/utils.py:229-232,
+ * without the host draw and its H2D copy): idx[b] = floor(u32 * n_valid / 2^32), u32 from slot 32 of sample (sample0 + b). */
+int augcl_philox_replay_indices(uint64_t seed, uint64_t offset, int sample0, int n_valid, int64_t *idx, int B,
+                                augcl_stream_t stream);
 
 /* ---- random_shift: src/augmentations.py:378-382 (F.pad replicate + kornia RandomCrop((h,w)))
  * out[b,c,y,x] = in[b,c,clamp(y+oy[b]-pad,0,H-1),clamp(x+ox[b]-pad,0,W-1)], oy/ox in [0,2*pad].

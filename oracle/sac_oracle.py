@@ -186,7 +186,14 @@ def _relu(h, gates, key, i):
     implementation under test, so that what is left to compare is arithmetic (tests/test_referee_gpu.py)."""
     if gates is None or key not in gates:
         return torch.relu(h)
-    return _GatedReLU.apply(h, gates[key][i].to(device=h.device, dtype=h.dtype))
+    g = gates[key][i].to(device=h.device, dtype=h.dtype)
+    if "audit" in gates:  # how the imposed gates sit on THIS evaluation's pre-activations: (key, i, #differing, #gates,
+        with torch.no_grad():  # max |pre-activation| / rms at a differing gate) -- a wrong gate far from 0 would show here
+            diff = (g > 0) != (h > 0)
+            n = int(diff.sum())
+            worst = float(h[diff].abs().max() / h.square().mean().sqrt().clamp_min(1e-300)) if n else 0.0
+            gates["audit"].append((key, i, n, h.numel(), worst))
+    return _GatedReLU.apply(h, g)
 
 
 def cnn_forward(p, x, hp, gates=None):

@@ -483,13 +483,36 @@ def test_update_against_f64_referee(cuda, monkeypatch, algo, data_aug, A, B, hpo
 
     ref_free, log_free = oracle_run(torch.float64)
     o32, log32 = oracle_run(torch.float32)
+    # AUDIT of every gate set handed to the referee (round 2 only audited the CNN's, in test_encoder_against_f64_referee): the
+    # forced float64 run records, per ReLU, how many imposed gates differ from the sign of ITS OWN float64 pre-activation
+    # (computed under the same upstream gates) and how far from zero the worst of them sits.  A wrong-but-consistent gate
+    # in the fused MLP heads (head_ops._TwinQ / _Mlp3) would be inherited by a referee that just takes the gates; here it
+    # would show as a differing gate with |z| / rms far above rounding.
+    audits = []
+    for gset in forced["critic"] + forced.get("weak", []) + [forced["actor"], forced["actor_q"]]:
+        gset["audit"] = []
+        audits.append(gset["audit"])
     ref, log64 = oracle_run(torch.float64, forced=forced, after_critic=take_hip_critic)
+    audit_rows = [r for a in audits for r in a]
+    for gset in forced["critic"] + forced.get("weak", []) + [forced["actor"], forced["actor_q"]]:
+        del gset["audit"]
+    head_rows = [r for r in audit_rows if r[0] != "cnn"]
+    assert head_rows and any(r[0] == "mlp" for r in head_rows) and any(r[0] == "Q1" for r in head_rows)
+    n_head = sum(r[3] for r in head_rows)
+    flips_head = sum(r[2] for r in head_rows)
+    worst_head = max(r[4] for r in head_rows)
+    worst_cnn = max([r[4] for r in audit_rows if r[0] == "cnn"], default=0.0)
+    gate_audit = {"head_gates": n_head, "head_gates_differ": flips_head, "head_max_|z|/rms_at_differing": worst_head,
+                  "cnn_gates_differ": sum(r[2] for r in audit_rows if r[0] == "cnn"), "cnn_max_|z|/rms_at_differing": worst_cnn}
+    assert worst_head <= 1e-5 and flips_head <= 5e-6 * n_head + 10, gate_audit
+    assert worst_cnn <= 1e-5, gate_audit
     # the float32 oracle under the SAME forced gates: what float32 arithmetic alone costs on this batch (a loss made of
     # cancelling differences, a tanh that saturates to exactly 1 in float32 but not in float64, ...) -- the yardstick
     # wherever that exceeds 1e-5
     y32, ylog32 = oracle_run(torch.float32, forced=forced, after_critic=take_hip_critic)
 
-    rep = {"algo": algo, "B": B, "init": init, "hp": hpo, "referee_device": str(rdev), "logs": {}, "tensors": {}, "groups": {}}
+    rep = {"algo": algo, "B": B, "init": init, "hp": hpo, "referee_device": str(rdev), "logs": {}, "tensors": {}, "groups": {},
+           "gate_audit": gate_audit}
     # ---- every logged quantity against the gate-forced referee
     for k, want in log64.items():
         got_v = L.rows[k]

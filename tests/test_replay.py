@@ -258,3 +258,44 @@ def test_svea_hip_graph_update_on_the_device_ring_and_other_frame_sizes(cuda):
     assert not agent._fused_front_end(None, hw=(odd.h, odd.w)) and agent._fused_front_end(None, hw=(rb.h, rb.w))
     got = agent._sample(odd)
     assert len(got) == 5 and got[0].shape == (4, 9, 64, 64)  # plain sample(), not the (2B, ...) fused stack
+
+
+@pytest.mark.gpu
+def test_device_index_stream_is_launch_only_and_equals_explicit_indices(cuda):
+    """index_stream="device": the transition indices of sample() / sample_shift_conv() are drawn by a Philox launch
+    (augcl_philox_replay_indices, keyed like the augmentations) instead of np.random.randint + an H2D copy
+    (src/utils.py:229-232).  RNG-internal == explicit: the batch equals sample(idxs=<the exported indices>) bit for bit;
+    numpy's generator is not consumed; the indices are in range and spread over the filled part."""
+    import torch
+
+    from augcl_amd import _lib
+    from augcl_amd import augmentations as aug
+    from augcl_amd.replay import LazyFrames, ReplayBuffer
+    rb = ReplayBuffer((9, 84, 84), (A,), capacity=96, batch_size=B, device=cuda, index_stream="device")
+    for of, a, r, nf, d in gi.replay_stream(seed=45, n=70, A=A):  # not full: n_valid = 70
+        rb.add(LazyFrames(of), a, r, LazyFrames(nf), d)
+    aug.manual_seed(123)
+    np.random.seed(7)
+    state = np.random.get_state()[1].copy()
+    got = rb.sample()
+    used_idx = rb._idx_dev.clone()
+    assert np.array_equal(np.random.get_state()[1], state), "the device index stream must not consume numpy's generator"
+    idx = torch.empty(B, dtype=torch.int64, device=cuda)
+    _lib.call("augcl_philox_replay_indices", 123, 0, 0, 70, idx.data_ptr(), B, _lib.current_stream(cuda))
+    assert torch.equal(idx, used_idx) and int(idx.min()) >= 0 and int(idx.max()) < 70
+    want = rb.sample(idxs=idx.cpu().numpy())
+    for x, y in zip(got, want):
+        assert torch.equal(x, y)
+    # the fused front end draws its indices the same way (call 1 of the stream: the index draw; call 2: shift + conv)
+    aug.manual_seed(123)
+    both, act, rew, nobs, nd = rb.sample_shift_conv()
+    aug.manual_seed(123)
+    aug._next_call()
+    want2 = rb.sample_shift_conv(idxs=idx.cpu().numpy())
+    for x, y in zip((both, act, rew, nobs, nd), want2):
+        assert torch.equal(x, y)
+    # spread: 4096 draws over 70 transitions hit every one of them, none twice as often as uniform allows by chance
+    big = torch.empty(4096, dtype=torch.int64, device=cuda)
+    _lib.call("augcl_philox_replay_indices", 5, 9, 0, 70, big.data_ptr(), 4096, _lib.current_stream(cuda))
+    cnt = torch.bincount(big, minlength=70)
+    assert int(cnt.min()) > 20 and int(cnt.max()) < 110 and cnt.numel() == 70
