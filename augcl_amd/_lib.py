@@ -33,6 +33,20 @@ def build(force=False, verbose=False):
     return LIB_PATH
 
 
+def source_hash():
+    """16 hex digits over every source the shared object is built from (csrc/*, include/augcl.h): profiles/*.json carry
+    the hash of the tree whose binary produced their counters, and bench.py only quotes counters whose hash is this one."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(_PKG, "csrc")
+    files = sorted(f for f in glob.glob(os.path.join(csrc, "*")) if f.endswith((".hip", ".cpp", ".h", "Makefile")))
+    for f in files + [HEADER_PATH]:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def declared_symbols():
     """Every function name include/augcl.h declares (used by the symbol-export test)."""
     txt = open(HEADER_PATH).read()

@@ -82,14 +82,40 @@ def run(dev, dist, world, rank, steps=20, warmup=4, B=256, A=6, algo="svea", dat
             break
     wall = sorted(walls)[len(walls) // 2]
     encoder_ops.set_precision("f32")
-    flops = 432e9 * (B / 256)  # ~1.69 GFLOP per sample per (average) step
+    flops = 432e9 * (B / 256)  # ALGORITHMIC: ~1.69 GFLOP per sample per average step of the reference's update
+    flops_exec = executed_flops_per_update(B, A)  # what the build actually runs
     return {"grad_steps_per_s": steps / wall, "ms_per_update": wall / steps * 1e3, "samples_per_s": world * B * steps / wall,
             "ms_per_update_min": min(walls) / steps * 1e3, "ms_per_update_max": max(walls) / steps * 1e3,
             "repeats": len(walls), "timed_s": sum(walls),
             "algo": f"{algo}+{data_aug}", "batch_per_gpu": B, "steps": steps,
             "dtype": "f32" if precision == "f32" else "bf16 conv stack (f32 accumulate, f32 heads/optimizer)",
-            "approx_TFLOP/s_per_gpu": flops * steps / wall / 1e12, "encoder_backend": "hip",
+            "approx_TFLOP/s_per_gpu": flops * steps / wall / 1e12, "algorithmic_TFLOP/s": flops * steps / wall / 1e12,
+            "executed_TFLOP/s": flops_exec["total"] * steps / wall / 1e12, "executed_GFLOP_per_update": flops_exec["total"] / 1e9,
+            "executed_conv32_GFLOP_per_update": flops_exec["conv32"] / 1e9, "encoder_backend": "hip",
             "hip_graph": bool(graph), "world": world}
+
+
+def executed_flops_per_update(B, A, n_layers=11, hidden=1024, proj=100):
+    """Multiply-add flops (x2) one average SVEA update() of THIS build executes at batch B: the reference's count (SURVEY 8d:
+    8 encoder-forward equivalents per critic step + 2 per actor step) minus what the build does not run -- the actor step
+    reuses ONE CNN pass for the actor and the critic (the reference runs two), and nothing differentiates with respect to
+    the pixels (no first-layer backward-data).  Returns {"total", "conv32" (the 32 -> 32 layers only), "first", "heads"}."""
+    hw = [41 - 2 * i for i in range(n_layers)]                      # output size of layer i
+    first = 2.0 * 81 * 32 * hw[0] * hw[0]                           # 9 -> 32, 3x3, stride 2: 84 -> 41
+    c32 = sum(2.0 * 288 * 32 * h * h for h in hw[1:])               # ten 32 -> 32 layers, 39 .. 21
+    feat = 32 * hw[-1] * hw[-1]
+    head_fwd = 2.0 * (feat * proj + (proj + A) * hidden * 2 + hidden * hidden * 2 + hidden * 2)  # projection + twin Q
+    actor_fwd = 2.0 * (feat * proj + proj * hidden + hidden * hidden + hidden * 2 * A)
+    # critic step: 2 no-grad passes over next_obs (actor's + target's CNN), forward over 2B (obs, obs_aug), backward over
+    # 2B = backward-data + backward-weights of the 32 -> 32 layers, backward-weights only of the first layer
+    conv32 = B * c32 * (2 + 2 + 2 * 2)
+    firstl = B * first * (2 + 2 + 2 * 1)
+    heads = B * (2 * (head_fwd + actor_fwd) + 2 * 3 * head_fwd)
+    # actor + alpha step every second update: ONE CNN pass (no gradient), actor MLP fwd + bwd, critic heads fwd + bwd (dx only)
+    conv32 += 0.5 * B * c32
+    firstl += 0.5 * B * first
+    heads += 0.5 * B * (3 * actor_fwd + 2 * head_fwd)
+    return {"total": conv32 + firstl + heads, "conv32": conv32, "first": firstl, "heads": heads}
 
 
 def action_latency(dev, A=6, calls=300):

@@ -553,7 +553,7 @@ struct WgX3Args {
     const float *dz;  // f32 NCHW (B,32,Ho,Wo)
     float *partial;   // [gridDim.x][32*288 + 32]
     int B, Hi, Wi, Ho, Wo, RT, S, n_items;
-    uint32_t magic_wo;
+    uint32_t magic_wo, magic_s; // floor(2^32 / Wo) + 1, floor(2^32 / S) + 1
 };
 
 constexpr int WGX_SLAB = 32 * 288 + 32;
@@ -594,9 +594,9 @@ __global__ __launch_bounds__(512, 2) void k_wgrad32_x3(WgX3Args a)
         struct Geo {
             int b, y0, rows, na, nz, nqa, nqz;
         };
-        auto geom = [&](int item) {
+        auto geom = [&](int item) { // item is wave-uniform: scalar arithmetic, the division a multiplication
             Geo g;
-            g.b = item / a.S;
+            g.b = a.S == 1 ? item : (int)__umulhi((uint32_t)item, a.magic_s);
             const int s = item - g.b * a.S;
             g.y0 = s * a.RT;
             g.rows = min(a.RT, a.Ho - g.y0);
@@ -698,57 +698,78 @@ __global__ __launch_bounds__(512, 2) void k_wgrad32_x3(WgX3Args a)
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
     float dbacc = 0.0f;
     auto compute = [&](int item, int bi) {
-        const int s = item % a.S;
+        const int s = item - (a.S == 1 ? item : (int)__umulhi((uint32_t)item, a.magic_s)) * a.S;
         const int rows = min(a.RT, a.Ho - s * a.RT);
         const int npix = rows * Wo;
         const char *At = ldsw + bi * bufbytes;
         const char *Zt = At + 3 * abytes;
         const int nsteps = (npix + 15) >> 4;
-        for (int k = cw; k < nsteps; k += 4) { // 16 strip pixels per step; all 64 lanes stay active (tr reads)
-            bf16x8 zf[3];
-            const char *pa[2];
-            {
-                s16x4 zr[3][2];
+        if (cw >= nsteps) return; // wave-uniform
+        // Software pipeline at tap granularity: the six transposed reads of tap t + 1 (three planes x two row groups) are issued
+        // before the six MFMAs of tap t, the NEXT step's dZ fragments during tap 7 and its tap 0 during tap 8 -- no MFMA waits
+        // for a read issued less than six MFMAs (192 cycles) earlier.  (Reading a whole kernel row's 18 fragments in front of
+        // its 18 MFMAs stalled every row on the LDS latency: ~130 of 576 cycles, tools/kisa.sh.)
+        typedef s16x4 Frag[3][2]; // [plane][row group]
+        auto locate = [&](int k, const char *(&pz)[2], const char *(&pa)[2]) {
 #pragma unroll
-                for (int rd = 0; rd < 2; ++rd) {
-                    const int m = 16 * k + 8 * h + 4 * rd + q; // the pixel whose row this lane supplies
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) zr[pl][rd] = lds_tr_x(Zt + pl * zbytes + m * 64 + colbyte);
-                    const int mc = min(m, npix - 1);            // padded pixels: dZ is zero, read any real activation
-                    const int yy = (int)__umulhi((uint32_t)mc, a.magic_wo), xx = mc - yy * Wo;
-                    pa[rd] = At + (yy * Wi + xx) * 64 + colbyte;
-                }
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    zf[pl] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(zr[pl][0], zr[pl][1], 0, 1, 2, 3, 4, 5, 6, 7));
+            for (int rd = 0; rd < 2; ++rd) {
+                const int m = 16 * k + 8 * h + 4 * rd + q; // the pixel whose row this lane supplies
+                pz[rd] = Zt + m * 64 + colbyte;
+                const int mc = min(m, npix - 1);            // padded pixels: dZ is zero, read any real activation
+                const int yy = (int)__umulhi((uint32_t)mc, a.magic_wo), xx = mc - yy * Wo;
+                pa[rd] = At + (yy * Wi + xx) * 64 + colbyte;
             }
+        };
+        auto rdz = [&](const char *const (&pz)[2], Frag &f) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int rd = 0; rd < 2; ++rd) f[pl][rd] = lds_tr_x(pz[rd] + pl * zbytes);
+        };
+        auto rdx = [&](const char *const (&pa)[2], int t, Frag &f) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int rd = 0; rd < 2; ++rd) f[pl][rd] = lds_tr_x(pa[rd] + pl * abytes + ((t / 3) * Wi + (t % 3)) * 64);
+        };
+        auto cat = [&](const Frag &f, int pl) {
+            return __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(f[pl][0], f[pl][1], 0, 1, 2, 3, 4, 5, 6, 7));
+        };
+        const char *pz[2], *pa[2];
+        Frag zr, x0, x1;
+        locate(cw, pz, pa);
+        rdz(pz, zr);
+        rdx(pa, 0, x0);
+        for (int k = cw; k < nsteps; k += 4) { // 16 strip pixels per step; all 64 lanes stay active (tr reads)
+            const bf16x8 zf[3] = {cat(zr, 0), cat(zr, 1), cat(zr, 2)};
 #pragma unroll
             for (int j = 0; j < 8; ++j) dbacc += ((float)zf[0][j] + (float)zf[1][j]) + (float)zf[2][j];
+            const char *pzn[2], *pan[2];
+            locate(k + 4 < nsteps ? k + 4 : k, pzn, pan); // no next step: re-read this one
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) { // one kernel row at a time keeps 9 operand fragments live
-                s16x4 xr[3][3][2];
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-                        for (int rd = 0; rd < 2; ++rd) xr[kx][pl][rd] = lds_tr_x(pa[rd] + pl * abytes + (ky * Wi + kx) * 64);
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    bf16x8 xf[3];
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl)
-                        xf[pl] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(xr[kx][pl][0], xr[kx][pl][1], 0, 1, 2, 3, 4, 5, 6, 7));
-                    f32x16 &c = acc[ky * 3 + kx];
-                    // smallest products first: zm xm, zl xh, zh xl, zm xh, zh xm, zh xh
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zf[1], xf[1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zf[2], xf[0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zf[0], xf[2], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zf[1], xf[0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zf[0], xf[1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zf[0], xf[0], c, 0, 0, 0);
-                }
+            for (int t = 0; t < 9; ++t) {
+                Frag &cur = (t & 1) ? x1 : x0;
+                Frag &nxt = (t & 1) ? x0 : x1;
+                if (t < 8) rdx(pa, t + 1, nxt);
+                else rdx(pan, 0, nxt);      // (9 is odd: the next step's tap 0 lands in x1 -- swapped back below)
+                if (t == 7) rdz(pzn, zr);   // zf holds this step's fragments by value
+                __builtin_amdgcn_sched_barrier(0);
+                const bf16x8 xf[3] = {cat(cur, 0), cat(cur, 1), cat(cur, 2)};
+                f32x16 &c = acc[t];
+                // smallest products first: zm xm, zl xh, zh xl, zm xh, zh xm, zh xh
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zf[1], xf[1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zf[2], xf[0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zf[0], xf[2], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zf[1], xf[0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zf[0], xf[1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zf[0], xf[0], c, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int rd = 0; rd < 2; ++rd) x0[pl][rd] = x1[pl][rd];
+            pa[0] = pan[0]; pa[1] = pan[1];
         }
     };
     __syncthreads();
@@ -861,10 +882,31 @@ int launch_conv_x3(ConvX3Args &a, const char *name, hipStream_t s)
     rt = std::min(rt, (MODE ? 64 * X3_NU / QW : 256 * X3_NU / Wi) - 2); // quads of the tile's RT + 2 input rows <= 64 * X3_NU
     if (rt < 1) return 1;
     if (rt > a.Ho) rt = a.Ho;
-    a.S = (a.Ho + rt - 1) / rt;
     const int cus = cu_count_x3();
-    while ((long)a.B * a.S < 2L * cus && a.S < a.Ho) ++a.S; // small batches: enough strips to go around
-    a.RT = (a.Ho + a.S - 1) / a.S;
+    {   // Strip height: a strip's 32-pixel tiles are dealt to 4 compute waves, so it costs ceil(tiles / 4) rounds of 108 MFMAs
+        // whatever its size.  Among the heights that fit, take the one with the fewest rounds per image (+ a little per strip
+        // for its barrier and halo rows); small batches additionally need enough strips to go around the CUs.
+        const int rt_max = rt;
+        double best_cost = 1e30;
+        int best = rt_max;
+#ifdef AUGCL_TUNING
+        const bool even_split = getenv("AUGCL_X3_EVEN") != nullptr; // tuning: the plain even split, for A/B
+#else
+        const bool even_split = false;
+#endif
+        for (int r = 1; r <= rt_max && !even_split; ++r) {
+            const int S = (a.Ho + r - 1) / r, last = a.Ho - (S - 1) * r;
+            if ((long)a.B * S < 2L * cus && r > 1) continue; // too few strips for this batch
+            const double cost = (S - 1) * (double)(((r * a.Wo + 31) / 32 + 3) / 4) + (double)(((last * a.Wo + 31) / 32 + 3) / 4) + 0.12 * S;
+            if (cost <= best_cost) { best_cost = cost; best = r; }
+        }
+        if (even_split) {
+            a.S = (a.Ho + rt_max - 1) / rt_max;
+            while ((long)a.B * a.S < 2L * cus && a.S < a.Ho) ++a.S;
+            best = (a.Ho + a.S - 1) / a.S;
+        }
+        a.RT = best;
+    }
     a.S = (a.Ho + a.RT - 1) / a.RT;
     a.n_items = a.B * a.S;
     a.magic_wo = (uint32_t)(0x100000000ull / (unsigned)a.Wo) + 1u;
@@ -1025,13 +1067,17 @@ int augcl_enc_x3_conv32_backward_weights(const float *act_prev, const float *dz,
     if (rt < 1 || a.Wo < 4) // rows too wide (or too narrow) for the split tiles: the native f32 MFMA kernel
         return augcl_enc_conv32_backward_weights(act_prev, dz, dw, db, workspace, workspace_bytes, B, Hi, Wi, stream);
     if (rt > a.Ho) rt = a.Ho;
-    a.S = (a.Ho + rt - 1) / rt;
     const int cus = cu_count_x3();
+    // Strip height: the fewest strips that fit, split evenly.  (Choosing the height by rounds of 4-wave steps as launch_conv_x3
+    // does measured 4 % SLOWER over the ten layer sizes -- 717 vs 691 us at B = 512, tools/x3_wg_sweep.py: this kernel is bound by
+    // its loaders, which split BOTH operands, and shorter strips stage more halo rows.)
+    a.S = (a.Ho + rt - 1) / rt;
     while ((long)B * a.S < 2L * cus && a.S < a.Ho) ++a.S;
     a.RT = (a.Ho + a.S - 1) / a.S;
     a.S = (a.Ho + a.RT - 1) / a.RT;
     a.n_items = B * a.S;
     a.magic_wo = (uint32_t)(0x100000000ull / (unsigned)a.Wo) + 1u;
+    a.magic_s = (uint32_t)(0x100000000ull / (unsigned)a.S) + 1u; // (S == 1 is tested for in the kernel)
     const int apix = (a.RT + 2) * Wi, zpix = (a.RT * a.Wo + 15) & ~15;
     size_t lds = (size_t)2 * 3 * (apix + zpix) * 64;
     const size_t red = (size_t)(145 * 64) * 4;

@@ -265,10 +265,17 @@ def graph_collectives_ok(dist, dev, torch):
 
 
 def load_profile_json(name):
+    """A counter summary under profiles/ -- only if it was measured on THIS source tree: every summary carries the hash of
+    csrc/ + include/ (augcl_amd._lib.source_hash) of the binary that produced it.  Otherwise {} and the caller reports null
+    with "stale_profile": true (round 2 quoted counters of a slightly older binary, silently)."""
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", name)))
+        d = json.load(open(os.path.join(ROOT, "profiles", name)))
     except Exception:  # noqa: BLE001
         return {}
+    from augcl_amd import _lib
+    if d.get("source_hash") != _lib.source_hash():
+        return {"stale_profile": True, "profile_source_hash": d.get("source_hash")}
+    return d
 
 
 def main():
@@ -362,10 +369,13 @@ def main():
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         res["per_rank_obs_per_s_device"] = [float(v.item()) for v in allr]
-    tr = load_profile_json("pmc_traffic.json").get("k_random_conv", {})
-    if tr.get("batch") == B:  # measured offline with rocprofv3 --pmc (profiles/, tools/summarize_profiles.py)
+    prof = load_profile_json("pmc_traffic.json")
+    tr = prof.get("k_random_conv", {})
+    if tr.get("batch") == B:  # measured offline with rocprofv3 --pmc (profiles/, tools/summarize_profiles.py) on THIS tree
         res["roofline"]["traffic"] = tr.get("hbm_bytes_per_launch")
         res["roofline"]["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+    elif prof.get("stale_profile"):
+        res["roofline"]["stale_profile"] = True  # counters on file belong to another source tree: not quoted
 
     if not args.no_extras:
         extras = {}
@@ -429,7 +439,8 @@ def main():
         # update() replayed from captured hipGraphs (SAC.enable_hip_graphs); the eager figure beside it.
         # With several ranks the graphs contain the gradient all-reduce: checked by a pre-flight first.
         use_graph = dist is None or (args.dp_graph and not args.rehearse_one_gpu and graph_collectives_ok(dist, dev, torch))
-        busy = load_profile_json("r02_mfma_busy.json")
+        busy = load_profile_json("r03_mfma_busy.json")
+        hbm16 = load_profile_json("r03_bf16_conv_hbm.json")
 
         def leg(precision):
             """Both execution modes of update(); the faster one is the reported figure, the other sits beside it
@@ -440,12 +451,31 @@ def main():
             for r in runs:
                 if r is not best:
                     best["hip_graph_ms_per_update" if r["hip_graph"] else "eager_ms_per_update"] = r["ms_per_update"]
-            peak = MFMA_F32_PEAK_TFLOPS if precision == "f32" else MFMA_BF16_PEAK_TFLOPS
-            tf = best["approx_TFLOP/s_per_gpu"]
-            best["roofline"] = {"bound": "mfma_f32" if precision == "f32" else "mfma_bf16 (conv stack; heads and optimiser stay f32)",
-                                "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
-                                "mfma_busy": busy.get(precision), "mfma_busy_source": "profiles/r02_mfma_busy.json (rocprofv3 --pmc "
-                                "SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES per conv kernel, time-weighted)" if busy.get(precision) else None}
+            # The f32 parity path runs its 32 -> 32 layers as SIX bf16 MFMAs per product group (csrc/encoder_x3.hip): its roof
+            # is the bf16 matrix pipe.  achieved = the bf16-MFMA flops those layers ISSUE (6 x their executed f32-equivalent
+            # flops) per second, whole update in the denominator; the f32-equivalent rates sit beside it.  The bf16 mode's conv
+            # kernels are HBM-paced: its roofline is the time-weighted HBM fraction of those kernels,
+            # from the rocprofv3 stats of the same tree (null when the profile on file is stale).
+            if precision == "f32":
+                issued = 6.0 * best["executed_conv32_GFLOP_per_update"] * 1e9 / (best["ms_per_update"] * 1e-3) / 1e12
+                best["roofline"] = {"bound": "mfma_bf16 (f32-accurate products: 6 bf16 MFMAs per product group)", "achieved": issued,
+                                    "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": issued / MFMA_BF16_PEAK_TFLOPS,
+                                    "f32_equivalent_executed_TFLOP/s": best["executed_TFLOP/s"],
+                                    "f32_equivalent_algorithmic_TFLOP/s": best["algorithmic_TFLOP/s"],
+                                    "native_f32_mfma_peak_TFLOP/s": MFMA_F32_PEAK_TFLOPS}
+            else:
+                h = hbm16 if not hbm16.get("stale_profile") else {}
+                best["roofline"] = {"bound": "hbm (conv kernels; heads and optimiser stay f32)", "achieved": h.get("conv_GBps_time_weighted"),
+                                    "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": (h.get("conv_GBps_time_weighted") / HBM_PEAK_GBS) if h.get("conv_GBps_time_weighted") else None,
+                                    "source": "profiles/r03_bf16_conv_hbm.json (algorithmic bytes of every conv launch / its rocprofv3 "
+                                              "duration, time-weighted)" if h else None}
+            b_ = busy.get(precision) if not busy.get("stale_profile") else None
+            best["roofline"]["mfma_busy"] = b_
+            best["roofline"]["mfma_busy_source"] = ("profiles/r03_mfma_busy.json (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES per conv "
+                                                    "kernel / launch duration x 2.4 GHz x 1024 SIMDs, time-weighted)") if b_ else None
+            if busy.get("stale_profile") or hbm16.get("stale_profile"):
+                best["roofline"]["stale_profile"] = True
             return best
 
         try:

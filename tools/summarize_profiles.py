@@ -12,10 +12,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = lambda n: os.path.join(ROOT, "gpurun_out", f"{rnd}_{n}")  # noqa: E731
 tag = "r%02d" % int(rnd[1:])
 out = os.path.join(ROOT, "profiles")
+# hash of the source tree whose binary produced these counters (written on the box by tools/profile_round.sh)
+SRC_HASH = open(G("source_hash.txt")).read().strip() if os.path.exists(G("source_hash.txt")) else None
+sys.path.insert(0, ROOT)
+try:
+    from augcl_amd import _lib
+    if SRC_HASH and SRC_HASH != _lib.source_hash():
+        print("NOTE: the profiled tree (%s) is not the tree checked out here (%s): bench.py will report these counters as stale"
+              % (SRC_HASH, _lib.source_hash()))
+except Exception as e:  # noqa: BLE001
+    print("source hash check skipped:", e)
 CLK_HZ, SIMDS = 2.4e9, 256 * 4  # MI355X engine clock (peak), 256 CUs x 4 SIMDs
 
 for src, dst in (("bench.csv", f"{tag}_bench_kernel_stats.csv"), ("update_f32.csv", f"{tag}_update_kernel_stats.csv"),
-                 ("update_bf16.csv", f"{tag}_update_bf16_kernel_stats.csv")):
+                 ("update_bf16.csv", f"{tag}_update_bf16_kernel_stats.csv"), ("update_f32_mfma.csv", f"{tag}_update_f32_mfma_kernel_stats.csv")):
     if os.path.exists(G(src)):
         shutil.copy(G(src), os.path.join(out, dst))
 
@@ -60,7 +70,8 @@ if os.path.exists(G("fetch.json")) and os.path.exists(G("write.json")):
                 ent["algorithmic_bytes_per_launch"] = a[0]
                 ent["traffic_over_algorithmic"] = round(ent["hbm_bytes_per_launch"] / a[0], 3)
         kernels[k] = ent
-    res = {"round": tag, "batch": 256, "note": "FETCH_SIZE doubled (gfx950 correction), separate --pmc passes", "kernels": kernels}
+    res = {"round": tag, "source_hash": SRC_HASH, "batch": 256, "note": "FETCH_SIZE doubled (gfx950 correction), separate --pmc passes",
+           "kernels": kernels}
     key = [k for k in kernels if "k_conv<84, 84, 12, 256, float, false" in k]
     if key:
         res["k_random_conv"] = {"batch": 256, **kernels[key[0]]}
@@ -68,7 +79,7 @@ if os.path.exists(G("fetch.json")) and os.path.exists(G("write.json")):
     print("pmc_traffic.json:", {k[:60]: v.get("traffic_over_algorithmic") for k, v in kernels.items()})
 
 # ---- MFMA-busy of the encoder kernels inside update()
-busy = {"round": tag, "formula": "whole_launch = SQ_VALU_MFMA_BUSY_CYCLES / (launch duration x 2.4 GHz x 1024 SIMDs); "
+busy = {"round": tag, "source_hash": SRC_HASH, "formula": "whole_launch = SQ_VALU_MFMA_BUSY_CYCLES / (launch duration x 2.4 GHz x 1024 SIMDs); "
         "while_cu_busy = SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES).  SQ_VALU_MFMA_BUSY_CYCLES sums every SIMD's busy "
         "cycles (checked on k_proj_partial: 16 x 63 x 4 x 7 x 16 MFMAs x 64 cycles = the counter to 0.3 %); durations from the "
         "rocprofv3 --kernel-trace --stats run of the same command; f32 / bf16 = time-weighted over the kernels listed."}
@@ -108,6 +119,95 @@ for prec in ("f32", "bf16"):
 if "f32" in busy or "bf16" in busy:
     json.dump(busy, open(os.path.join(out, f"{tag}_mfma_busy.json"), "w"), indent=1)
     print("mfma_busy:", busy.get("f32"), busy.get("bf16"))
+
+# ---- the conv encoder's kernels inside update(): algorithmic bytes per launch (launch mix of one average SVEA update at
+# B = 256: two no-grad passes as ONE dual launch per layer over 2 x 256 images, the critic's forward / backward over 2B = 512,
+# the actor step's forward over 256 every second update) against the PMC traffic, and -- bf16 mode -- the time-weighted HBM rate
+HS = [41 - 2 * i for i in range(11)]  # output size of layer i (input of layer i + 1)
+
+
+def conv_mix(elem):
+    """{kernel-name fragment: (launches per update, algorithmic bytes per update)} for activations of `elem` bytes"""
+    px = lambda n: 32 * n * n  # noqa: E731
+    fwd = bwd = wg = 0.0
+    for i in range(1, 11):
+        hi, ho = HS[i - 1], HS[i]
+        o_el = 4 if (i == 10) else elem  # the last layer always writes f32
+        fwd += (512 + 512 + 0.5 * 256) * (px(hi) * elem + px(ho) * o_el)
+        bwd += 512 * (px(ho) * elem + 2 * px(hi) * elem)       # dZ in, gate (layer input) in, dX out
+        wg += 512 * (px(hi) * elem + px(ho) * elem)
+    first = (256 + 512 + 0.5 * 256) * (9 * 84 * 84 * 4) + (512 + 512 + 0.5 * 256) * px(41) * elem  # dual launch reads x once
+    wfirst = 512 * (9 * 84 * 84 * 4 + px(41) * elem)
+    return {"fwd": (25, fwd), "bwd": (10, bwd), "wgrad": (10, wg), "first": (2.5, first), "wfirst": (1, wfirst)}
+
+
+KERNEL_ROLE = [("k_conv32_x3<0", "fwd"), ("k_conv32_x3<1", "bwd"), ("k_wgrad32_x3", "wgrad"), ("k_conv32_bf16<0", "fwd"),
+               ("k_conv32_bf16<1", "bwd"), ("k_wgrad32_bf16", "wgrad"), ("k_conv_first9", "first"), ("k_wgrad_first", "wfirst"),
+               ("k_conv32<0", "fwd"), ("k_conv32<1", "bwd"), ("k_wgrad32<", "wgrad")]
+
+
+def role_of(name):
+    for frag, role in KERNEL_ROLE:
+        if frag in name:
+            return role
+    return None
+
+
+def kernel_times(csv_path):
+    """{kernel name: (calls, total_us)} merged over launch grids"""
+    tot = {}
+    for r in csv.reader(l for l in open(csv_path) if not l.startswith("#")):
+        if r and r[0] != "name":
+            t = tot.setdefault(r[0], [0, 0.0])
+            t[0] += int(r[2])
+            t[1] += float(r[3])
+    return tot
+
+
+upd = {"round": tag, "source_hash": SRC_HASH, "note": "conv encoder kernels inside SVEA update() B=256; algorithmic bytes = the f32 / bf16 "
+       "activations each launch must read and write (launch mix of an average update); hbm = 2 x FETCH_SIZE + WRITE_SIZE (KiB, separate "
+       "--pmc passes, gfx950 correction)"}
+for prec, elem in (("f32", 4), ("bf16", 2)):
+    if not os.path.exists(G(f"update_{prec}.csv")):
+        continue
+    mix = conv_mix(elem)
+    times = kernel_times(G(f"update_{prec}.csv"))
+    fetch = json.load(open(G(f"ufetch_{prec}.json"))) if os.path.exists(G(f"ufetch_{prec}.json")) else {}
+    write = json.load(open(G(f"uwrite_{prec}.json"))) if os.path.exists(G(f"uwrite_{prec}.json")) else {}
+
+    def pmc_avg(d, name, counter):
+        num = den = 0.0
+        for k, v in d.items():
+            if k.partition(" [grid ")[0][:60] == name.split("(")[0].strip()[:60] and counter in v:
+                num += v[counter]["avg"] * v[counter]["n"]
+                den += v[counter]["n"]
+        return num / den if den else None
+
+    rows, tot_b, tot_t = {}, 0.0, 0.0
+    for name, (calls, total_us) in times.items():
+        role = role_of(name)
+        if role is None or "augcl::" not in name:
+            continue
+        launches, bytes_upd = mix[role]
+        avg_us = total_us / calls
+        ent = {"role": role, "avg_us": round(avg_us, 2), "launches_per_update": launches,
+               "algorithmic_bytes_per_launch": int(bytes_upd / launches), "algorithmic_GBps": round(bytes_upd / launches / avg_us / 1e3, 1)}
+        f_kb, w_kb = pmc_avg(fetch, name, "FETCH_SIZE"), pmc_avg(write, name, "WRITE_SIZE")
+        if f_kb is not None and w_kb is not None:
+            ent["hbm_bytes_per_launch"] = int(2 * f_kb * 1024 + w_kb * 1024)
+            ent["traffic_over_algorithmic"] = round(ent["hbm_bytes_per_launch"] / ent["algorithmic_bytes_per_launch"], 3)
+        rows[name.split("(")[0][:70]] = ent
+        tot_b += bytes_upd
+        tot_t += avg_us * launches
+    upd[prec] = {"kernels": rows, "conv_us_per_update": round(tot_t, 1), "conv_algorithmic_MB_per_update": round(tot_b / 1e6, 1),
+                 "conv_GBps_time_weighted": round(tot_b / tot_t / 1e3, 1) if tot_t else None}
+if "f32" in upd or "bf16" in upd:
+    json.dump(upd, open(os.path.join(out, f"{tag}_update_conv_traffic.json"), "w"), indent=1)
+    if "bf16" in upd:
+        json.dump({"round": tag, "source_hash": SRC_HASH, "conv_GBps_time_weighted": upd["bf16"]["conv_GBps_time_weighted"],
+                   "conv_us_per_update": upd["bf16"]["conv_us_per_update"], "frac_of_8TBps": round(upd["bf16"]["conv_GBps_time_weighted"] / 8000.0, 3),
+                   "source": f"profiles/{tag}_update_conv_traffic.json"}, open(os.path.join(out, f"{tag}_bf16_conv_hbm.json"), "w"), indent=1)
+    print("update conv traffic:", {p: upd[p]["conv_GBps_time_weighted"] for p in ("f32", "bf16") if p in upd})
 
 # ---- the launch sequence of graph-replayed updates: launches per update() with and without the actor step
 if os.path.exists(G("seq_f32_sequence.txt")):
