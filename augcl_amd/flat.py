@@ -81,7 +81,7 @@ class FlatGroup:
         parameters that have NO gradient (torch.optim.Adam skips those: no moment decay, no step)."""
         return self.scatter_into_bucket([p.grad for p in self.params], step_prep=step_prep)
 
-    def scatter_into_bucket(self, grads, names=None, step_prep=None):
+    def scatter_into_bucket(self, grads, names=None, step_prep=None, zero_missing=False):
         """grads[i] -> the bucket slot of names[i] (default: all of the group's tensors, in order).  On the GPU one
         augcl_gather_f32 launch (the pointer table rides in the kernel arguments); step_prep = (device step state, lr,
         beta1, beta2) lets that launch also advance the optimiser's device-side step count -- `self.prepped` then tells
@@ -90,7 +90,10 @@ class FlatGroup:
         dsts, srcs, missing = [], [], []
         names = g.names if names is None else names
         if all(t is None for t in grads):
-            return list(names)  # nothing to copy; the caller skips these tensors (no zero-fill launches either)
+            if zero_missing and names:  # the caller all-reduces this slice of the bucket regardless: keep it well defined
+                a0, b0 = g.slices[names[0]][0], g.slices[names[-1]][1]
+                g.grad[a0:b0].zero_()
+            return list(names)  # nothing to copy; the caller skips these tensors
         base = g.grad.data_ptr()
         on_gpu = g.grad.is_cuda
         for n, t in zip(names, grads):
@@ -211,7 +214,9 @@ class FlatAdam:
         k = g.cut_index
         split = g.slices[g.names[k]][0]
         grads = torch.autograd.grad(loss, g.params[k:] + cut, grad_outputs=one, allow_unused=True)
-        missing = g.scatter_into_bucket(grads[:len(g.params) - k], g.names[k:], step_prep=self._step_prep())
+        # (the device-side step is advanced by the LAST scatter, and only if nothing was missing above the cut either: a
+        # partial step must not find the count already moved)
+        missing = g.scatter_into_bucket(grads[:len(g.params) - k], g.names[k:], zero_missing=True)
         pending = [r.allreduce_sum_async(g.grad[split:])]
         d_cut = grads[len(g.params) - k:]
         live = [(t, d) for t, d in zip(cut, d_cut) if d is not None]
@@ -219,7 +224,7 @@ class FlatAdam:
             below = torch.autograd.grad([t for t, _ in live], g.params[:k], grad_outputs=[d for _, d in live], allow_unused=True)
         else:
             below = [None] * k
-        missing += g.scatter_into_bucket(below, g.names[:k])
+        missing += g.scatter_into_bucket(below, g.names[:k], step_prep=None if missing else self._step_prep(), zero_missing=True)
         pending.append(r.allreduce_sum_async(g.grad[:split]))
         return missing, pending
 
@@ -244,8 +249,11 @@ class FlatAdam:
         if len(missing) == len(g.names):
             return  # nothing received a gradient (AugCL's orphan weak optimiser before the hand-off, augcl.py:13-14): no-op
         if self.step_state is not None:
-            raise _lib.AugclError("FlatAdam: parameters without a gradient cannot be skipped inside a captured hipGraph "
-                                  f"(no gradient for {missing[:3]}...)")
+            if missing:
+                raise _lib.AugclError("FlatAdam: parameters without a gradient cannot be skipped inside a captured hipGraph "
+                                      f"(no gradient for {missing[:3]}...)")
+            self._tensor_steps = None  # per-tensor counts left over from a resume, nothing missing now: the plain path
+            return self._apply((), reduced=True, scale=scale)
         if self._tensor_steps is None:
             self._tensor_steps = {n: self._step_count for n in g.names}
         skip = set(missing)
@@ -263,14 +271,17 @@ class FlatAdam:
         self._step_count = max(self._tensor_steps.values())
         for a, b, k in runs:
             self._launch_adam(a, b, k, scale)
+        if len(set(self._tensor_steps.values())) == 1:
+            self._tensor_steps = None  # every tensor is at the same count again: back to one launch per step
 
-    def _apply(self, missing=(), reduced=False):
+    def _apply(self, missing=(), reduced=False, scale=None):
         g = self.group
         if len(missing) == len(g.names):
             return  # no tensor of the group received a gradient (the same on every rank): nothing to exchange or step
-        scale = 1.0
-        if self.reducer is not None:  # reduced: backward_begin already exchanged the bucket (in two overlapped pieces)
-            scale = 1.0 / self.reducer.world if reduced else self.reducer.allreduce_sum_(g.grad)  # 1/world_size
+        if scale is None:
+            scale = 1.0
+            if self.reducer is not None:  # reduced: backward_begin already exchanged the bucket (in two overlapped pieces)
+                scale = 1.0 / self.reducer.world if reduced else self.reducer.allreduce_sum_(g.grad)  # 1/world_size
         if missing or self._tensor_steps is not None:
             return self._apply_partial(list(missing), scale)
         if self.step_state is not None:

@@ -6,6 +6,8 @@ with the reference's operation order inside.  Callers keep the literal ATen chai
 cover (another dtype, e.g. a float64 check of the same module)."""
 import ctypes
 
+import weakref
+
 import torch
 
 from . import _lib
@@ -296,8 +298,8 @@ def _twin_views(*ps):
     rebuilt every call: they go stale with the next optimiser step.)"""
     key = tuple(p.data_ptr() for p in ps)
     hit = _twin_cache.get(key)
-    if hit is not None:
-        return hit
+    if hit is not None and hit[0]() is ps[0]:  # (same addresses AND the same live parameter object: a freed agent's buffer
+        return hit[1]                          # may be handed out again at the same address)
     a, b = ps[:6], ps[6:]
     out = [_stacked(p, q) for p, q in zip(a, b)]
     views = all(t.data_ptr() == p.data_ptr() for t, p in zip(out, a))
@@ -306,9 +308,14 @@ def _twin_views(*ps):
         views = False
     out = tuple(out)
     if views:
-        if len(_twin_cache) >= 16:
-            _twin_cache.clear()
-        _twin_cache[key] = out
+        # the cached views keep their flat buffer alive: entries of agents that are gone (their parameter objects have been
+        # collected) are dropped here, so a discarded agent's device memory is released by the next agent's first forward
+        for k in [k for k, (ref, _) in _twin_cache.items() if ref() is None]:
+            del _twin_cache[k]
+        try:
+            _twin_cache[key] = (weakref.ref(ps[0]), out)
+        except TypeError:  # a plain tensor that cannot be weakly referenced: not cached
+            pass
     return out
 
 

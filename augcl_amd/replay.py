@@ -146,7 +146,11 @@ class ReplayBuffer(object):
         self._adds += 1
         oldest = self.idx if self.full else 0
         if min(self.obs_seq[oldest].min(), self.next_seq[oldest].min()) < self.frame_seq - self.n_slots:
-            per = self.frame_seq / self._adds
+            # frames stored per transition over the LIVE window (add counters do not survive load()): the oldest and newest
+            # live transitions' first frames bracket the frames their episode stream consumed
+            newest = (self.idx - 1) % self.capacity
+            span = max(1, (self.capacity if self.full else max(self.idx, 1)))
+            per = max(1.0, float(self.obs_seq[newest].max() - self.obs_seq[oldest].min() + 1) / span)
             need = int(np.ceil((per - 1.0) * self.capacity)) + 4 * self.stack + 16
             raise _lib.AugclError(
                 f"replay frame ring too small: this stream stores {per:.2f} new frames per transition, so {self.capacity} "
