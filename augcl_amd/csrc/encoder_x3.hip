@@ -587,74 +587,61 @@ __global__ __launch_bounds__(512, 2) void k_wgrad32_x3(WgX3Args a)
     const bool wg_neg = (blockIdx.x & 1) != 0;
 
     if (loader) {
+        // Round 0 of a lane's two units covers the activation rows, round 1 the dZ rows (the host keeps either within 256
+        // units): which tensor a load reads is then known at compile time and the loads are BUFFER loads -- resource base +
+        // this lane's 32-bit byte offset + a scalar offset carrying image, first row and channel -- with the item's geometry
+        // in SGPRs (as in k_conv32_x3; 64-bit vector addresses and a runtime division cost this loader-bound kernel ~8 %).
         const int lt = cw * 64 + lane;
         struct Regs {
-            vf4ua d[WGX_NU][8];
+            vu4 d[WGX_NU][8];
         };
         struct Geo {
-            int b, y0, rows, na, nz, nqa, nqz;
+            int na, nz;
+            unsigned base_a, base_z; // byte offsets of (image b, channel 0, first row)
         };
+        const int cg = lt & 3, q0 = lt >> 2;
+        const unsigned csA4 = (unsigned)(a.Hi * Wi) * 4u, csZ4 = (unsigned)(a.Ho * Wo) * 4u;
+        const unsigned lane_a = (unsigned)cg * 8u * csA4, lane_z = (unsigned)cg * 8u * csZ4;
+        const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.act), 0, -1, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.dz), 0, -1, 0x00020000);
         auto geom = [&](int item) { // item is wave-uniform: scalar arithmetic, the division a multiplication
             Geo g;
-            g.b = a.S == 1 ? item : (int)__umulhi((uint32_t)item, a.magic_s);
-            const int s = item - g.b * a.S;
-            g.y0 = s * a.RT;
-            g.rows = min(a.RT, a.Ho - g.y0);
-            g.na = (g.rows + 2) * Wi;
-            g.nz = g.rows * Wo;
-            g.nqa = (g.na + 3) >> 2;
-            g.nqz = (g.nz + 3) >> 2;
+            const int b = a.S == 1 ? item : (int)__umulhi((uint32_t)item, a.magic_s);
+            const int y0 = (item - b * a.S) * a.RT;
+            const int rows = min(a.RT, a.Ho - y0);
+            g.na = (rows + 2) * Wi;
+            g.nz = rows * Wo;
+            g.base_a = (unsigned)((b * 32 * a.Hi + y0) * Wi) * 4u;
+            g.base_z = (unsigned)((b * 32 * a.Ho + y0) * Wo) * 4u;
             return g;
-        };
-        // unit -> (channel group, source pointer of its 4 pixels, LDS byte of the first pixel's row in plane 0)
-        auto locate = [&](const Geo &g, int u, const float *&src, size_t &cs, int &lo) {
-            const int unit = u * 256 + lt;
-            const int cg = unit & 3;
-            const int qd = min(unit >> 2, g.nqa + g.nqz - 1); // units past the item repeat its last quad (idempotent)
-            if (qd < g.nqa) {
-                const int p0 = min(4 * qd, g.na - 4);
-                cs = (size_t)a.Hi * Wi;
-                src = a.act + ((size_t)g.b * 32 + 8 * cg) * cs + (size_t)g.y0 * Wi + p0;
-                lo = p0 * 64 + cg * 16;
-            } else {
-                const int p0 = min(4 * (qd - g.nqa), g.nz - 4);
-                cs = (size_t)a.Ho * Wo;
-                src = a.dz + ((size_t)g.b * 32 + 8 * cg) * cs + (size_t)g.y0 * Wo + p0;
-                lo = 3 * abytes + p0 * 64 + cg * 16;
-            }
         };
         auto issue = [&](int item, Regs &R) {
             const Geo g = geom(item);
+            const int pa0 = min(4 * q0, g.na - 4), pz0 = min(4 * q0, g.nz - 4); // lanes past a run repeat its last quad
 #pragma unroll
-            for (int u = 0; u < WGX_NU; ++u) {
-                const float *src;
-                size_t cs;
-                int lo;
-                locate(g, u, src, cs, lo);
-#pragma unroll
-                for (int c = 0; c < 8; ++c) R.d[u][c] = *reinterpret_cast<const vf4ua *>(src + c * cs);
+            for (int c = 0; c < 8; ++c) {
+                R.d[0][c] = __builtin_bit_cast(vu4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, lane_a + 4u * (unsigned)pa0, g.base_a + (unsigned)c * csA4, 0));
+                R.d[1][c] = __builtin_bit_cast(vu4, __builtin_amdgcn_raw_buffer_load_b128(rs_z, lane_z + 4u * (unsigned)pz0, g.base_z + (unsigned)c * csZ4, 0));
             }
         };
         auto commit = [&](int item, int bi, const Regs &R) {
             const Geo g = geom(item);
             char *dst = ldsw + bi * bufbytes;
+            const int pa0 = min(4 * q0, g.na - 4), pz0 = min(4 * q0, g.nz - 4);
 #pragma unroll
             for (int u = 0; u < WGX_NU; ++u) {
-                const float *src;
-                size_t cs;
-                int lo;
-                locate(g, u, src, cs, lo);
-                const bool isz = lo >= 3 * abytes;
+                const bool isz = u == 1;
                 const int pstride = isz ? zbytes : abytes; // bytes between the hi / mid / lo planes
-                const float sg = (isz && wg_neg) ? -1.0f : 1.0f; // odd workgroups accumulate -dW (see the slab write)
-                char *o = dst + lo;
+                char *o = dst + (isz ? 3 * abytes + pz0 * 64 : pa0 * 64) + cg * 16;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     vu4 hi, mid, lw;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
+                        float v0 = __uint_as_float(R.d[u][2 * e][j]), v1 = __uint_as_float(R.d[u][2 * e + 1][j]);
+                        if (isz && wg_neg) { v0 = -v0; v1 = -v1; } // odd workgroups accumulate -dW (see the slab write)
                         uint32_t th, tm, tl;
-                        split2(sg * R.d[u][2 * e][j], sg * R.d[u][2 * e + 1][j], th, tm, tl);
+                        split2(v0, v1, th, tm, tl);
                         hi[e] = th; mid[e] = tm; lw[e] = tl;
                     }
                     *reinterpret_cast<vu4 *>(o + j * 64) = hi;
@@ -1057,13 +1044,15 @@ int augcl_enc_x3_conv32_backward_weights(const float *act_prev, const float *dz,
     AUGCL_REQUIRE(B >= 1 && Hi >= 3 && Wi >= 3, "%s: bad shape", name);
     AUGCL_REQUIRE(act_prev && dz && dw && db && workspace, "%s: null tensor", name);
     AUGCL_REQUIRE(aligned4(act_prev) && aligned4(dz), "%s: tensors must be 4-byte aligned", name);
+    if ((size_t)B * 32 * Hi * Wi >= ((size_t)1 << 30)) // beyond 32-bit byte offsets: the native f32 MFMA kernel
+        return augcl_enc_conv32_backward_weights(act_prev, dz, dw, db, workspace, workspace_bytes, B, Hi, Wi, stream);
     WgX3Args a{};
     a.act = act_prev; a.dz = dz; a.partial = workspace;
     a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ho = Hi - 2; a.Wo = Wi - 2;
     // per buffer: 3 planes x ((RT+2)*Wi + roundup16(RT*Wo)) pixels of 64 bytes; one item = WGX_NU rounds of loader units
     const int budget_pix = 80 * 1024 / 192;
     int rt = (budget_pix - 2 * Wi - 16) / (Wi + a.Wo);
-    rt = std::min(rt, (256 * WGX_NU - 2 * Wi - 8) / (Wi + a.Wo)); // quads of A + quads of dZ <= 64 * WGX_NU
+    rt = std::min(rt, std::min(256 / Wi - 2, 256 / a.Wo)); // one loader round (64 quads) per operand: (RT+2)*Wi, RT*Wo <= 256
     if (rt < 1 || a.Wo < 4) // rows too wide (or too narrow) for the split tiles: the native f32 MFMA kernel
         return augcl_enc_conv32_backward_weights(act_prev, dz, dw, db, workspace, workspace_bytes, B, Hi, Wi, stream);
     if (rt > a.Ho) rt = a.Ho;

@@ -30,9 +30,10 @@ __global__ __launch_bounds__(256) void k_replay_gather(const uint8_t *__restrict
 
 // The whole ReplayBuffer.sample() in one launch: transition indices idx[B] pick rows of the device-resident tables
 // (slot_tab[cap][2*stack] = ring slots of the obs / next_obs frame stacks, scal[cap][S] = action | reward | not_done)
-// and both stacked batches plus the scalars are written.  A lane moves 16 pixels: ONE dwordx4 of uint8 in, FOUR float4 (or
-// one dwordx4) out -- with one dword per lane (round 2) a wave's load instruction fetched 256 B and the kernel sat at 0.57
-// of the HBM peak with four times the instructions per byte.  fq = 16-byte chunks per frame (frame sizes are multiples of 16).
+// and both stacked batches plus the scalars are written.  Work item q < 2*B*stack*fq: one dword (4 pixels) in, one float4 out
+// per lane: both sides of a wave's access are contiguous (256 B in, 1 KB out).  (Round 3 tried 16 pixels per lane -- one
+// dwordx4 in, four float4 out: the four stores of a lane are then 64 B apart ACROSS lanes, every store instruction touches 64
+// partial lines, WRITE_SIZE doubled and the launch took 111 instead of 28 us: profiles/r03_bench_kernel_stats.csv history.)
 template <typename TOut>
 __global__ __launch_bounds__(256) void k_replay_sample(const uint8_t *__restrict__ frames,
                                                        const int32_t *__restrict__ slot_tab,
@@ -49,22 +50,16 @@ __global__ __launch_bounds__(256) void k_replay_sample(const uint8_t *__restrict
     const int fi = f - which * per; // = b*stack + k
     const int b = fi / stack, k = fi - b * stack;
     const int slot = slot_tab[idx[b] * (2 * stack) + which * stack + k];
-    typedef uint32_t u4v __attribute__((ext_vector_type(4)));
-    const u4v *__restrict__ src = reinterpret_cast<const u4v *>(frames) + (size_t)slot * fq;
+    const uint32_t *__restrict__ src = reinterpret_cast<const uint32_t *>(frames) + (size_t)slot * fq;
     TOut *out = which ? next_obs : obs;
     for (int off = blockIdx.x * 256 + threadIdx.x; off < fq; off += gridDim.x * 256) {
-        const u4v v4 = __builtin_nontemporal_load(src + off);
+        const uint32_t v = src[off];
         const size_t r = (size_t)fi * fq + off;
-        if constexpr (sizeof(TOut) == 1) {
-            __builtin_nontemporal_store(v4, reinterpret_cast<u4v *>(out) + r);
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const uint32_t v = v4[e];
-                store_nt(reinterpret_cast<float *>(out) + 16 * r + 4 * e,
-                         make_float4((float)(v & 0xffu), (float)((v >> 8) & 0xffu), (float)((v >> 16) & 0xffu), (float)(v >> 24)));
-            }
-        }
+        if constexpr (sizeof(TOut) == 1)
+            store_nt(reinterpret_cast<uint32_t *>(out) + r, v);
+        else
+            store_nt(reinterpret_cast<float *>(out) + 4 * r,
+                     make_float4((float)(v & 0xffu), (float)((v >> 8) & 0xffu), (float)((v >> 16) & 0xffu), (float)(v >> 24)));
     }
     if (blockIdx.x == 0 && which == first && k == 0) { // one workgroup per sample copies its scalars
         const int A = S - 2; // outputs as three contiguous blocks: actions [B][S-2], rewards [B], not_dones [B]
@@ -82,12 +77,11 @@ extern "C" int augcl_replay_sample(const uint8_t *frames, const int32_t *slot_ta
                                    int out_f32, augcl_stream_t stream)
 {
     const char *name = "augcl_replay_sample";
-    AUGCL_REQUIRE(B >= 0 && stack > 0 && frame_bytes > 0 && (frame_bytes & 15) == 0 && S >= 0,
-                  "%s: bad shape (frame_bytes must be a multiple of 16)", name);
+    AUGCL_REQUIRE(B >= 0 && stack > 0 && frame_bytes > 0 && (frame_bytes & 3) == 0 && S >= 0, "%s: bad shape", name);
     if (B == 0) return AUGCL_OK;
     AUGCL_REQUIRE(frames && slot_tab && idx && next_obs && (S == 0 || (scal && scal_out)), "%s: null buffer", name);
     AUGCL_REQUIRE(aligned16(frames) && aligned16(obs) && aligned16(next_obs), "%s: buffers must be 16-byte aligned", name);
-    const int fq = frame_bytes / 16;
+    const int fq = frame_bytes / 4;
     AUGCL_REQUIRE((size_t)2 * B * stack <= 65535, "%s: batch too large for one launch", name);
     const dim3 grid((fq + 255) / 256 < 8 ? (fq + 255) / 256 : 8, (obs ? 2 : 1) * B * stack);
     hipStream_t s = as_stream(stream);
