@@ -118,10 +118,14 @@ _SIGS = {
     "augcl_enc_bf16_conv32_backward_weights_mfma": [_P, _P, _P, _P, _P, _SZ, _I, _I, _I, _P],
     "augcl_enc_bf16_conv_first_backward_weights": [_P, _P, _P, _P, _P, _SZ, _I, _I, _I, _I, _I, _F, _P],
     "augcl_enc_nchw_f32_to_nhwc_bf16": [_P, _P, _I, _I, _I, _P],
-    "augcl_enc_stack_forward": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P, _SZ, _P],
+    "augcl_enc_amax_f32": [_P, _SZ, _P, _P],
+    "augcl_enc_x2_conv32_forward": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _SZ, _P, _P, _P],
+    "augcl_enc_x2_conv32_backward_data": [_P, _P, _P, _P, _I, _I, _I, _P, _SZ, _P, _P, _P],
+    "augcl_enc_x2_conv32_backward_weights": [_P, _P, _P, _P, _P, _SZ, _I, _I, _I, _P, _P, _P],
+    "augcl_enc_stack_forward": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P, _SZ, _P, _P],
     "augcl_enc_frag_workspace_bytes": [_I, _I],
-    "augcl_enc_stack_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P, _SZ, _I, _I, _I, _I, _I, _I, _F, _I, _I, _P, _SZ, _P],
-    "augcl_enc_stack_forward_dual": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P, _SZ, _P],
+    "augcl_enc_stack_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P, _SZ, _I, _I, _I, _I, _I, _I, _F, _I, _I, _P, _SZ, _P, _P, _P],
+    "augcl_enc_stack_forward_dual": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P, _SZ, _P, _P],
     "augcl_replay_gather": [_P, _P, _P, _I, _I, _I, _I, _P],
     "augcl_enc_conv_first_forward": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
     "augcl_enc_conv32_forward": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
@@ -156,8 +160,8 @@ def load():
         fn.argtypes = argtypes
         fn.restype = _RESTYPE.get(name, _I)
     ver = lib.augcl_abi_version()
-    if ver != 2:
-        raise AugclError(f"libaugcl_hip.so ABI version {ver} != 2 (stale build: run `make -C augcl_amd/csrc`)")
+    if ver != 3:
+        raise AugclError(f"libaugcl_hip.so ABI version {ver} != 3 (stale build: run `make -C augcl_amd/csrc`)")
     _lib = lib
     return lib
 

@@ -43,6 +43,9 @@ struct First9Args {
     // two-weight-set forward over ONE input batch: image b >= B/2 reads input b - B/2 and uses w2 / bias2
     const float *w2, *bias2;
     int dual;
+    // f32 output only: max |out| is atomically max-ed into it (float bits, zeroed by the caller; dual: [0] / [1] per half), or
+    // null -- the f16-pair kernels of the next layer derive their operand scale from it (encoder_x2.hip)
+    uint32_t *amax_out;
 };
 
 constexpr int F9_U = 12;  // 16-byte chunks per loader lane per strip
@@ -80,6 +83,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_first9(First9Args a)
         const float *wsrc = grp ? a.w2 : a.w, *bsrc = grp ? a.bias2 : a.bias;
         for (int i = tid; i < 32 * 81; i += 512) wst[(i / 81) * 85 + (i % 81)] = wsrc[i];
         if (tid < 32) lbias[tid] = bsrc ? bsrc[tid] : 0.0f;
+        if (tid < 2) reinterpret_cast<uint32_t *>(lbias)[32 + tid] = 0u; // the workgroup's max |out| and its ticket counter
     }
     __syncthreads();
 
@@ -176,6 +180,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_first9(First9Args a)
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, -1, 0x00020000);
     // bf16 mode: the products run on v_mfma_f32_32x32x16_bf16 -- K = 81 padded to 96 = 6 MFMAs instead of 41.  A fragment
     // of MFMA i: W[co = l31][k = 16 i + 8 h + j], j = 0..7, rounded to bf16 (RNE); k >= 81 carries a zero weight.
+    float vmax = 0.0f; // max |output| of this lane (f32 output)
     bf16x8 wfrag[F9B_NM];
     if (OUT_BF16) {
         const float *wst = ldsf + bufwords + l31 * 85;
@@ -336,6 +341,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_first9(First9Args a)
                     for (int r = 0; r < 16; ++r) {
                         float v = acc[r];
                         if (RELU) v = __int_as_float(max(__float_as_int(v), 0)); // one v_max_i32: negative floats are negative ints
+                        vmax = fmaxf(vmax, fabsf(v));
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_out, boff,
                                                               (unsigned)(((r & 3) + 8 * (r >> 2)) * chw) * 4u, 0);
                     }
@@ -352,6 +358,15 @@ __global__ __launch_bounds__(512, 2) void k_conv_first9(First9Args a)
         compute(item + NG, 1);
         __syncthreads();
     }
+    if (!OUT_BF16 && a.amax_out != nullptr) { // one global atomic per workgroup: the last of the 4 compute waves sends the maximum on
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+        uint32_t *lred = reinterpret_cast<uint32_t *>(lbias) + 32;
+        if (lane == 0) {
+            atomicMax(lred, __float_as_uint(vmax));
+            if (atomicAdd(lred + 1, 1u) == 3u) atomicMax(a.amax_out + grp, lred[0]);
+        }
+    }
 }
 
 template <int WI, bool OUT_BF16, bool RELU>
@@ -359,7 +374,7 @@ static int launch_first9_t(First9Args &a, int cus, hipStream_t s, const char *na
 {
     constexpr int ROWF = 9 * WI;
     const int bufwords = (2 * a.RT + 2) * ROWF;
-    const size_t lds = (size_t)2 * bufwords * 4 + 32 * 4;
+    const size_t lds = (size_t)2 * bufwords * 4 + 34 * 4;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_first9<WI, OUT_BF16, RELU>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return fail(AUGCL_E_LAUNCH, "%s: cannot set dynamic LDS %zu: %s", name, lds, hipGetErrorString(e));
@@ -373,7 +388,7 @@ static int launch_first9_t(First9Args &a, int cus, hipStream_t s, const char *na
 // to the generic kernel)
 int conv_first9_try(const float *in, const float *w, const float *bias, void *out, int B, int C, int Hi, int Wi, int stride,
                     float scale, int relu, bool out_bf16, hipStream_t s, const char *name, const float *w2,
-                    const float *bias2)
+                    const float *bias2, float *amax_out)
 {
     if (C != 9 || Wi != 84 || stride != 2 || Hi < 3) return 1;
     if (w2 != nullptr && (B & 1)) return 1;
@@ -382,6 +397,7 @@ int conv_first9_try(const float *in, const float *w, const float *bias, void *ou
     First9Args a{};
     a.in = in; a.w = w; a.bias = bias; a.out = out;
     a.w2 = w2; a.bias2 = bias2; a.dual = w2 != nullptr;
+    a.amax_out = reinterpret_cast<uint32_t *>(amax_out);
     a.B = B; a.Hi = Hi; a.Ho = (Hi - 3) / 2 + 1; a.Wo = (Wi - 3) / 2 + 1; a.scale = scale;
     // one strip = one round of loads: 9 * (2RT+1) * WI/4 chunks <= 256 * F9_U
     int rt = ((256 * F9_U) / (9 * (Wi / 4)) - 1) / 2;

@@ -13,42 +13,151 @@ int augcl_internal_x3_conv32_forward(const float *in, const float *w, const floa
 int augcl_internal_x3_conv32_backward_data(const float *dz, const float *w, const float *act_prev, float *dact, int B, int Ho,
                                            int Wo, const void *wfrag, augcl_stream_t stream);
 int augcl_internal_x3_prep_weights(const float *const *w, int n, int mode, void *out, augcl_stream_t stream);
+// encoder_x2.hip (f16-pair kernels, precision 3); the layer calls return +1 for a shape they do not cover
+int augcl_internal_x2_prep_weights(const float *const *w, int n, int mode, void *out, augcl_stream_t stream);
+int augcl_internal_amax_f32(const float *x, size_t n, float *out, augcl_stream_t stream);
+int augcl_internal_x2_conv32_forward(const float *in, const float *bias, const float *bias2, float *out, int B, int Hi, int Wi,
+                                     int relu, const void *wfrag, const void *wfrag2, const float *amax_in, float *amax_out,
+                                     augcl_stream_t stream);
+int augcl_internal_x2_conv32_backward_data(const float *dz, const float *act_prev, float *dact, int B, int Ho, int Wo,
+                                           const void *wfrag, const float *amax_in, float *amax_out, augcl_stream_t stream);
+int augcl_internal_x2_conv32_backward_weights(const float *act_prev, const float *dz, float *dw, float *db, float *workspace,
+                                              size_t workspace_bytes, int B, int Hi, int Wi, const float *amax_act,
+                                              const float *amax_dz, augcl_stream_t stream);
 
 // precision 2: the weight fragments of every 32 -> 32 layer are prepared by ONE small launch per pass into frag_ws (>=
 // augcl_enc_frag_workspace_bytes(n_layers - 1, sets) bytes; null / too small: every layer launch prepares its own in its
 // prologue -- ~6 us of a 20-90 us launch).  Returns the per-layer block size in bytes, or 0 when not used.
 static size_t x3_prepare(const float *const *w, int n_layers, int mode, char *ws, size_t ws_bytes, size_t at, augcl_stream_t stream,
-                         int *rc)
+                         int *rc, bool f16_pairs = false)
 {
     *rc = AUGCL_OK;
     const size_t block = augcl_enc_frag_workspace_bytes(1, 1), need = at + (size_t)(n_layers - 1) * block;
     if (ws == nullptr || n_layers < 2 || n_layers > 33 || ws_bytes < need) return 0;
-    *rc = augcl_internal_x3_prep_weights(w + 1, n_layers - 1, mode, ws + at, stream);
+    *rc = f16_pairs ? augcl_internal_x2_prep_weights(w + 1, n_layers - 1, mode, ws + at, stream)
+                    : augcl_internal_x3_prep_weights(w + 1, n_layers - 1, mode, ws + at, stream);
     return *rc == AUGCL_OK ? block : 0;
 }
 
+// precision 3 needs both of its side buffers: the prepared fragments and the per-tensor maxima
+static int x2_require(const char *name, int n_layers, const void *frag_ws, size_t frag_ws_bytes, int sets, const float *amax)
+{
+    if (n_layers < 2) return AUGCL_OK;
+    AUGCL_REQUIRE(n_layers <= 33, "%s: precision 3 covers at most 33 layers", name);
+    AUGCL_REQUIRE(frag_ws != nullptr && frag_ws_bytes >= augcl_enc_frag_workspace_bytes(n_layers - 1, sets),
+                  "%s: precision 3 needs frag_ws of augcl_enc_frag_workspace_bytes(n_layers - 1, %d) bytes", name, sets);
+    AUGCL_REQUIRE(amax != nullptr, "%s: precision 3 needs the amax buffer", name);
+    return AUGCL_OK;
+}
+
+// ---- single 32 -> 32 layers on the f16-pair kernels (public: include/augcl.h).  A lone layer has no producer that left its
+// input's maximum, so the caller passes it (augcl_enc_amax_f32 computes one); the weight fragments are prepared per call.
+int augcl_enc_amax_f32(const float *x, size_t n, float *amax_out, augcl_stream_t stream)
+{
+    const char *name = "augcl_enc_amax_f32";
+    AUGCL_REQUIRE(x && amax_out, "%s: null tensor", name);
+    hipError_t e = hipMemsetAsync(amax_out, 0, sizeof(float), (hipStream_t)stream);
+    if (e != hipSuccess) return augcl::fail(AUGCL_E_LAUNCH, "%s: memset: %s", name, hipGetErrorString(e));
+    return n ? augcl_internal_amax_f32(x, n, amax_out, stream) : AUGCL_OK;
+}
+
+static int x2_layer_prep(const char *name, const float *w, int mode, void *frag_ws, size_t frag_ws_bytes, float *amax_out,
+                         augcl_stream_t stream)
+{
+    AUGCL_REQUIRE(frag_ws != nullptr && frag_ws_bytes >= augcl_enc_frag_workspace_bytes(1, 1),
+                  "%s: frag_ws must hold augcl_enc_frag_workspace_bytes(1, 1) bytes", name);
+    if (amax_out != nullptr) {
+        hipError_t e = hipMemsetAsync(amax_out, 0, sizeof(float), (hipStream_t)stream);
+        if (e != hipSuccess) return augcl::fail(AUGCL_E_LAUNCH, "%s: memset: %s", name, hipGetErrorString(e));
+    }
+    const float *wl[1] = {w};
+    return augcl_internal_x2_prep_weights(wl, 1, mode, frag_ws, stream);
+}
+
+int augcl_enc_x2_conv32_forward(const float *in, const float *w, const float *bias, float *out, int B, int Hi, int Wi, int relu,
+                                void *frag_ws, size_t frag_ws_bytes, const float *amax_in, float *amax_out,
+                                augcl_stream_t stream)
+{
+    const char *name = "augcl_enc_x2_conv32_forward";
+    AUGCL_REQUIRE(in && w && out && amax_in, "%s: null tensor", name);
+    if (B == 0) return AUGCL_OK;
+    int rc = x2_layer_prep(name, w, 0, frag_ws, frag_ws_bytes, amax_out, stream);
+    if (rc != AUGCL_OK) return rc;
+    rc = augcl_internal_x2_conv32_forward(in, bias, nullptr, out, B, Hi, Wi, relu, frag_ws, nullptr, amax_in, amax_out, stream);
+    if (rc <= 0) return rc;
+    rc = augcl_enc_x3_conv32_forward(in, w, bias, out, B, Hi, Wi, relu, stream); // shape not covered: the split-bf16 kernel
+    if (rc == AUGCL_OK && amax_out != nullptr) rc = augcl_internal_amax_f32(out, (size_t)B * 32 * (Hi - 2) * (Wi - 2), amax_out, stream);
+    return rc;
+}
+
+int augcl_enc_x2_conv32_backward_data(const float *dz, const float *w, const float *act_prev, float *dact, int B, int Ho, int Wo,
+                                      void *frag_ws, size_t frag_ws_bytes, const float *amax_dz, float *amax_out,
+                                      augcl_stream_t stream)
+{
+    const char *name = "augcl_enc_x2_conv32_backward_data";
+    AUGCL_REQUIRE(dz && w && dact && amax_dz, "%s: null tensor", name);
+    if (B == 0) return AUGCL_OK;
+    int rc = x2_layer_prep(name, w, 1, frag_ws, frag_ws_bytes, amax_out, stream);
+    if (rc != AUGCL_OK) return rc;
+    rc = augcl_internal_x2_conv32_backward_data(dz, act_prev, dact, B, Ho, Wo, frag_ws, amax_dz, amax_out, stream);
+    if (rc <= 0) return rc;
+    rc = augcl_enc_x3_conv32_backward_data(dz, w, act_prev, dact, B, Ho, Wo, stream);
+    if (rc == AUGCL_OK && amax_out != nullptr) rc = augcl_internal_amax_f32(dact, (size_t)B * 32 * (Ho + 2) * (Wo + 2), amax_out, stream);
+    return rc;
+}
+
+int augcl_enc_x2_conv32_backward_weights(const float *act_prev, const float *dz, float *dw, float *db, float *workspace,
+                                         size_t workspace_bytes, int B, int Hi, int Wi, const float *amax_act,
+                                         const float *amax_dz, augcl_stream_t stream)
+{
+    const char *name = "augcl_enc_x2_conv32_backward_weights";
+    AUGCL_REQUIRE(act_prev && dz && dw && db && workspace && amax_act && amax_dz, "%s: null tensor", name);
+    const int rc = augcl_internal_x2_conv32_backward_weights(act_prev, dz, dw, db, workspace, workspace_bytes, B, Hi, Wi, amax_act,
+                                                             amax_dz, stream);
+    if (rc <= 0) return rc;
+    return augcl_enc_x3_conv32_backward_weights(act_prev, dz, dw, db, workspace, workspace_bytes, B, Hi, Wi, stream);
+}
+
 // precision: 0 = f32 NCHW activations, f32 MFMA; 1 = bf16 NHWC activations (performance mode); 2 = f32 NCHW activations
-// with the 32 -> 32 layers on the split-bf16 kernels (float32-accurate products on the bf16 pipe: the parity path).
-// acts_out[i] = output buffer of layer i; the last layer always writes f32 NCHW.
+// with the 32 -> 32 layers on the split-bf16 kernels (float32-accurate products on the bf16 pipe); 3 = the same tensors with
+// the 32 -> 32 layers on the f16-pair kernels (float32-accurate, half the matrix instructions of 2: the parity path).
+// acts_out[i] = output buffer of layer i; the last layer always writes f32 NCHW.  amax (precision 3): n_layers floats,
+// amax[i] = max |output of layer i| on return (the backward pass reads them).
 int augcl_enc_stack_forward(const float *x, const float *const *w, const float *const *b, void *const *acts_out,
                             int n_layers, int B, int C, int H, int W, int first_stride, float scale, int precision,
-                            void *frag_ws, size_t frag_ws_bytes, augcl_stream_t stream)
+                            void *frag_ws, size_t frag_ws_bytes, float *amax, augcl_stream_t stream)
 {
-    AUGCL_REQUIRE(x && w && b && acts_out && n_layers >= 1, "augcl_enc_stack_forward: bad argument");
-    AUGCL_REQUIRE(precision >= 0 && precision <= 2, "augcl_enc_stack_forward: precision must be 0, 1 or 2");
-    AUGCL_REQUIRE(precision != 1 || n_layers >= 2, "augcl_enc_stack_forward: bf16 mode needs >= 2 layers");
+    const char *name = "augcl_enc_stack_forward";
+    AUGCL_REQUIRE(x && w && b && acts_out && n_layers >= 1, "%s: bad argument", name);
+    AUGCL_REQUIRE(precision >= 0 && precision <= 3, "%s: precision must be 0, 1, 2 or 3", name);
+    AUGCL_REQUIRE(precision != 1 || n_layers >= 2, "%s: bf16 mode needs >= 2 layers", name);
     int h = H, ww = W, rc;
     const void *cur = x;
     size_t fblock = 0;
-    if (precision == 2) {
-        fblock = x3_prepare(w, n_layers, 0, (char *)frag_ws, frag_ws_bytes, 0, stream, &rc);
+    const bool x2 = precision == 3 && n_layers >= 2;
+    if (precision == 3 && (rc = x2_require(name, n_layers, frag_ws, frag_ws_bytes, 1, amax)) != AUGCL_OK) return rc;
+    if (precision == 2 || x2) {
+        fblock = x3_prepare(w, n_layers, 0, (char *)frag_ws, frag_ws_bytes, 0, stream, &rc, x2);
         if (rc != AUGCL_OK) return rc;
+    }
+    if (x2) {
+        hipError_t e = hipMemsetAsync(amax, 0, (size_t)n_layers * sizeof(float), (hipStream_t)stream);
+        if (e != hipSuccess) return augcl::fail(AUGCL_E_LAUNCH, "%s: memset: %s", name, hipGetErrorString(e));
     }
     for (int i = 0; i < n_layers; ++i) {
         const int relu = i < n_layers - 1;
         const bool last = i == n_layers - 1;
         if (i == 0) {
-            if (precision != 1)
+            if (x2) { // the pipelined first-layer kernel leaves max |a_0| itself; any other shape: generic kernel + one reduction
+                rc = augcl::conv_first9_try(x, w[0], b[0], acts_out[0], B, C, h, ww, first_stride, scale, relu, false,
+                                            (hipStream_t)stream, name, nullptr, nullptr, amax);
+                if (rc > 0) {
+                    rc = augcl_enc_conv_first_forward(x, w[0], b[0], (float *)acts_out[0], B, C, h, ww, first_stride, scale, relu, stream);
+                    if (rc == AUGCL_OK)
+                        rc = augcl_internal_amax_f32((const float *)acts_out[0],
+                                                     (size_t)B * 32 * out_hw(h, first_stride) * out_hw(ww, first_stride), amax, stream);
+                }
+            } else if (precision != 1)
                 rc = augcl_enc_conv_first_forward(x, w[0], b[0], (float *)acts_out[0], B, C, h, ww, first_stride, scale, relu,
                                                   stream);
             else
@@ -62,7 +171,16 @@ int augcl_enc_stack_forward(const float *x, const float *const *w, const float *
             else if (precision == 2)
                 rc = augcl_internal_x3_conv32_forward((const float *)cur, w[i], b[i], nullptr, nullptr, (float *)acts_out[i], B, h, ww,
                                                       relu, fblock ? (char *)frag_ws + (size_t)(i - 1) * fblock : nullptr, nullptr, stream);
-            else
+            else if (precision == 3) {
+                rc = augcl_internal_x2_conv32_forward((const float *)cur, b[i], nullptr, (float *)acts_out[i], B, h, ww, relu,
+                                                      (char *)frag_ws + (size_t)(i - 1) * fblock, nullptr, amax + i - 1,
+                                                      last ? nullptr : amax + i, stream);
+                if (rc > 0) { // a shape the f16-pair kernel does not cover: the split-bf16 kernel (or its own fallback) + one reduction
+                    rc = augcl_enc_x3_conv32_forward((const float *)cur, w[i], b[i], (float *)acts_out[i], B, h, ww, relu, stream);
+                    if (rc == AUGCL_OK && !last)
+                        rc = augcl_internal_amax_f32((const float *)acts_out[i], (size_t)B * 32 * (h - 2) * (ww - 2), amax + i, stream);
+                }
+            } else
                 rc = augcl_enc_bf16_conv32_forward(cur, w[i], b[i], acts_out[i], B, h, ww, relu, last ? 1 : 0, stream);
             h -= 2;
             ww -= 2;
@@ -87,23 +205,31 @@ int augcl_internal_bf16_conv32_forward_dual(const void *in_bf16_nhwc, const floa
 int augcl_enc_stack_forward_dual(const float *x, const float *const *wA, const float *const *bA, const float *const *wB,
                                  const float *const *bB, void *const *acts_out, int n_layers, int B, int C, int H, int W,
                                  int first_stride, float scale, int precision, void *frag_ws, size_t frag_ws_bytes,
-                                 augcl_stream_t stream)
+                                 float *amax /* precision 3: 2 x n_layers floats of scratch */, augcl_stream_t stream)
 {
     const char *name = "augcl_enc_stack_forward_dual";
     AUGCL_REQUIRE(x && wA && bA && wB && bB && acts_out && n_layers >= 2 && B >= 1, "%s: bad argument", name);
+    AUGCL_REQUIRE(precision >= 0 && precision <= 3, "%s: precision must be 0, 1, 2 or 3", name);
     const int B2 = 2 * B;
-    int rc = augcl::conv_first9_try(x, wA[0], bA[0], acts_out[0], B2, C, H, W, first_stride, scale, 1, precision == 1,
-                                    (hipStream_t)stream, name, wB[0], bB[0]);
+    int rc;
+    const bool x2 = precision == 3;
+    if (x2) { // amax[2 i + set] = max |output of layer i| of that weight set's half
+        if ((rc = x2_require(name, n_layers, frag_ws, frag_ws_bytes, 2, amax)) != AUGCL_OK) return rc;
+        hipError_t e = hipMemsetAsync(amax, 0, (size_t)2 * n_layers * sizeof(float), (hipStream_t)stream);
+        if (e != hipSuccess) return augcl::fail(AUGCL_E_LAUNCH, "%s: memset: %s", name, hipGetErrorString(e));
+    }
+    rc = augcl::conv_first9_try(x, wA[0], bA[0], acts_out[0], B2, C, H, W, first_stride, scale, 1, precision == 1,
+                                (hipStream_t)stream, name, wB[0], bB[0], x2 ? amax : nullptr);
     if (rc > 0) return augcl::fail(AUGCL_E_UNSUPPORTED, "%s: first-layer shape (%d,%d,%d) stride %d not covered", name, C, H, W, first_stride);
     if (rc != AUGCL_OK) return rc;
     int h = out_hw(H, first_stride), ww = out_hw(W, first_stride);
     size_t fblock = 0;
     const size_t setB = (size_t)(n_layers - 1) * augcl_enc_frag_workspace_bytes(1, 1); // set B's blocks follow set A's
-    if (precision == 2 && frag_ws_bytes >= 2 * setB) {
-        fblock = x3_prepare(wA, n_layers, 0, (char *)frag_ws, frag_ws_bytes, 0, stream, &rc);
+    if ((precision == 2 || x2) && frag_ws_bytes >= 2 * setB) {
+        fblock = x3_prepare(wA, n_layers, 0, (char *)frag_ws, frag_ws_bytes, 0, stream, &rc, x2);
         if (rc != AUGCL_OK) return rc;
         if (fblock) {
-            x3_prepare(wB, n_layers, 0, (char *)frag_ws, frag_ws_bytes, setB, stream, &rc);
+            x3_prepare(wB, n_layers, 0, (char *)frag_ws, frag_ws_bytes, setB, stream, &rc, x2);
             if (rc != AUGCL_OK) return rc;
         }
     }
@@ -116,7 +242,21 @@ int augcl_enc_stack_forward_dual(const float *x, const float *const *wA, const f
             rc = augcl_internal_x3_conv32_forward((const float *)acts_out[i - 1], wA[i], bA[i], wB[i], bB[i], (float *)acts_out[i], B2,
                                                   h, ww, relu, fblock ? (char *)frag_ws + (size_t)(i - 1) * fblock : nullptr,
                                                   fblock ? (char *)frag_ws + setB + (size_t)(i - 1) * fblock : nullptr, stream);
-        else
+        else if (x2) {
+            const bool last = i == n_layers - 1;
+            rc = augcl_internal_x2_conv32_forward((const float *)acts_out[i - 1], bA[i], bB[i], (float *)acts_out[i], B2, h, ww, relu,
+                                                  (char *)frag_ws + (size_t)(i - 1) * fblock,
+                                                  (char *)frag_ws + setB + (size_t)(i - 1) * fblock, amax + 2 * (i - 1),
+                                                  last ? nullptr : amax + 2 * i, stream);
+            if (rc > 0) { // shape not covered: the split-bf16 kernel, then the two halves' maxima
+                rc = augcl_internal_x3_conv32_forward((const float *)acts_out[i - 1], wA[i], bA[i], wB[i], bB[i], (float *)acts_out[i],
+                                                      B2, h, ww, relu, nullptr, nullptr, stream);
+                const size_t half = (size_t)B * 32 * (h - 2) * (ww - 2);
+                if (rc == AUGCL_OK && !last) rc = augcl_internal_amax_f32((const float *)acts_out[i], half, amax + 2 * i, stream);
+                if (rc == AUGCL_OK && !last)
+                    rc = augcl_internal_amax_f32((const float *)acts_out[i] + half, half, amax + 2 * i + 1, stream);
+            }
+        } else
             rc = augcl_internal_bf16_conv32_forward_dual(acts_out[i - 1], wA[i], bA[i], wB[i], bB[i], acts_out[i], B2, h, ww,
                                                          relu, i == n_layers - 1 ? 1 : 0, stream);
         if (rc != AUGCL_OK) return rc;
@@ -133,9 +273,12 @@ int augcl_enc_stack_backward(const void *const *acts_in, const float *const *w, 
                              float *const *db, void *dz_a, void *dz_b, float *ws32, size_t ws32_bytes, float *ws_first,
                              size_t ws_first_bytes, int n_layers, int B, int C, int H, int W, int first_stride,
                              float scale, int precision, int bf16_wgrad_mfma, void *frag_ws, size_t frag_ws_bytes,
-                             augcl_stream_t stream)
+                             const float *amax_acts /* precision 3: the forward pass's amax */,
+                             float *amax_dz /* precision 3: n_layers floats of scratch */, augcl_stream_t stream)
 {
+    const char *name = "augcl_enc_stack_backward";
     AUGCL_REQUIRE(acts_in && w && grad_out && dw && db && dz_a && dz_b && n_layers >= 1, "augcl_enc_stack_backward: bad argument");
+    AUGCL_REQUIRE(precision >= 0 && precision <= 3, "%s: precision must be 0, 1, 2 or 3", name);
     int hs[64], wsz[64]; // input size of every layer
     AUGCL_REQUIRE(n_layers <= 63, "augcl_enc_stack_backward: too many layers");
     hs[0] = H; wsz[0] = W;
@@ -152,8 +295,19 @@ int augcl_enc_stack_backward(const void *const *acts_in, const float *const *w, 
     } scope{batched};
     if (batched) augcl::reduce_defer_begin();
     size_t fblock = 0;
-    if (precision == 2) { // backward-data fragments (transposed weights, flipped taps) of every 32 -> 32 layer: one launch
-        fblock = x3_prepare(w, n_layers, 1, (char *)frag_ws, frag_ws_bytes, 0, stream, &rc);
+    const bool x2 = precision == 3 && n_layers >= 2;
+    if (x2) {
+        if ((rc = x2_require(name, n_layers, frag_ws, frag_ws_bytes, 1, amax_acts)) != AUGCL_OK) return rc;
+        AUGCL_REQUIRE(amax_dz != nullptr, "%s: precision 3 needs the amax_dz scratch", name);
+    }
+    if (precision == 2 || x2) { // backward-data fragments (transposed weights, flipped taps) of every 32 -> 32 layer: one launch
+        fblock = x3_prepare(w, n_layers, 1, (char *)frag_ws, frag_ws_bytes, 0, stream, &rc, x2);
+        if (rc != AUGCL_OK) return rc;
+    }
+    if (x2) { // amax_dz[i] = max |gradient w.r.t. the output of layer i|: the top one by a reduction, the others by the kernels
+        hipError_t e = hipMemsetAsync(amax_dz, 0, (size_t)n_layers * sizeof(float), (hipStream_t)stream);
+        if (e != hipSuccess) return augcl::fail(AUGCL_E_LAUNCH, "%s: memset: %s", name, hipGetErrorString(e));
+        rc = augcl_internal_amax_f32(grad_out, (size_t)B * 32 * hs[n_layers] * wsz[n_layers], amax_dz + n_layers - 1, stream);
         if (rc != AUGCL_OK) return rc;
     }
     const void *dz = grad_out; // f32 NCHW (B,32,hs[n],ws[n])
@@ -172,7 +326,13 @@ int augcl_enc_stack_backward(const void *const *acts_in, const float *const *w, 
         else if (precision == 2)
             rc = augcl_enc_x3_conv32_backward_weights((const float *)acts_in[i], (const float *)dz, dw[i], db[i], ws_i, ws_i_bytes,
                                                       B, hs[i], wsz[i], stream);
-        else if (bf16_wgrad_mfma)
+        else if (precision == 3) {
+            rc = augcl_internal_x2_conv32_backward_weights((const float *)acts_in[i], (const float *)dz, dw[i], db[i], ws_i,
+                                                           ws_i_bytes, B, hs[i], wsz[i], amax_acts + i - 1, amax_dz + i, stream);
+            if (rc > 0)
+                rc = augcl_enc_x3_conv32_backward_weights((const float *)acts_in[i], (const float *)dz, dw[i], db[i], ws_i,
+                                                          ws_i_bytes, B, hs[i], wsz[i], stream);
+        } else if (bf16_wgrad_mfma)
             rc = augcl_enc_bf16_conv32_backward_weights_mfma(acts_in[i], dz, dw[i], db[i], ws_i, ws_i_bytes, B, hs[i], wsz[i],
                                                              stream);
         else
@@ -184,7 +344,18 @@ int augcl_enc_stack_backward(const void *const *acts_in, const float *const *w, 
         else if (precision == 2)
             rc = augcl_internal_x3_conv32_backward_data((const float *)dz, w[i], (const float *)acts_in[i], (float *)nxt, B, hs[i + 1],
                                                         wsz[i + 1], fblock ? (char *)frag_ws + (size_t)(i - 1) * fblock : nullptr, stream);
-        else
+        else if (precision == 3) {
+            // (the gradient that reaches the first layer's backward-weights needs no maximum: that kernel reads float32)
+            rc = augcl_internal_x2_conv32_backward_data((const float *)dz, (const float *)acts_in[i], (float *)nxt, B, hs[i + 1],
+                                                        wsz[i + 1], (char *)frag_ws + (size_t)(i - 1) * fblock, amax_dz + i,
+                                                        i > 1 ? amax_dz + i - 1 : nullptr, stream);
+            if (rc > 0) {
+                rc = augcl_enc_x3_conv32_backward_data((const float *)dz, w[i], (const float *)acts_in[i], (float *)nxt, B, hs[i + 1],
+                                                       wsz[i + 1], stream);
+                if (rc == AUGCL_OK && i > 1)
+                    rc = augcl_internal_amax_f32((const float *)nxt, (size_t)B * 32 * hs[i] * wsz[i], amax_dz + i - 1, stream);
+            }
+        } else
             rc = augcl_enc_bf16_conv32_backward_data(dz, w[i], acts_in[i], nxt, B, hs[i + 1], wsz[i + 1], stream);
         if (rc != AUGCL_OK) return rc;
         dz = nxt;

@@ -43,7 +43,8 @@ def _out_hw(h, stride):
 
 
 def _conv32_entry(precision):
-    """prefix of the three 32 -> 32 layer entry points for a precision name (the per-layer path has no bf16 form)"""
+    """prefix of the three 32 -> 32 layer entry points for a precision name (the per-layer path has no bf16 form, and no
+    f16-pair form: single-layer calls have no producer that leaves the tensor maxima, so they take the split-bf16 kernels)"""
     return "augcl_enc_conv32" if precision == "f32_mfma" else "augcl_enc_x3_conv32"
 
 
@@ -130,9 +131,12 @@ class ConvStackLayerwiseFn(torch.autograd.Function):  # per-layer calls: HeadCNN
 _BF16_WGRAD = "augcl_enc_bf16_conv32_backward_weights_mfma"
 
 # precision name -> the C ABI's precision code (include/augcl.h, augcl_enc_stack_*): "f32" = f32 NCHW activations with
-# the 32 -> 32 layers' products split onto the bf16 matrix pipe (float32-accurate, the parity path); "f32_mfma" = the
-# same tensors on the native f32 MFMA pipe (round 1-2's parity path, kept for A/B); "bf16" = bf16 NHWC performance mode.
-PRECISION_CODE = {"f32_mfma": 0, "bf16": 1, "f32": 2}
+# the 32 -> 32 layers' products as f16 pairs on the f16 matrix pipe (float32-accurate, the parity path); "f32_x3" = the same
+# with three-way bf16 splits (six products, no range limit); "f32_mfma" = the same tensors on the native f32 MFMA pipe
+# (round 1-2's parity path, kept for A/B); "bf16" = bf16 NHWC performance mode.
+PRECISION_CODE = {"f32_mfma": 0, "bf16": 1, "f32_x3": 2, "f32": 3}
+_SPLIT = ("f32", "f32_x3")  # the precisions whose stack calls take a weight-fragment workspace
+_AMAX = 64                  # floats appended to an arena for the per-tensor maxima of precision "f32" (>= 2 x layers)
 
 
 def _ptr_array(ptrs):
@@ -157,13 +161,15 @@ def conv_stack_dual(x, weights_a, biases_a, weights_b, biases_b, first_stride, i
     numel = [2 * B * 32 * h * w_ for h, w_ in zip(hs, wsz)]
     out = torch.empty((2 * B, 32, hs[-1], wsz[-1]), dtype=torch.float32, device=dev)
     big = (max(numel[:-1]) + 7) // 8 * 8
-    arena = torch.empty(2 * big, dtype=adt, device=dev)  # two ping-pong buffers
+    assert 2 * n_layers <= _AMAX
+    arena = torch.empty(2 * big + (_AMAX if precision == "f32" else 0), dtype=adt, device=dev)  # two ping-pong buffers (+ maxima)
     ptrs = [arena.data_ptr() + (i & 1) * big * arena.element_size() for i in range(n_layers - 1)] + [out.data_ptr()]
     d = lambda ts: _ptr_array([t.detach().data_ptr() for t in ts])  # noqa: E731
-    fws = _frag_ws(dev, n_layers - 1, 2) if precision == "f32" else None
+    fws = _frag_ws(dev, n_layers - 1, 2) if precision in _SPLIT else None
     _lib.call("augcl_enc_stack_forward_dual", x.data_ptr(), d(weights_a), d(biases_a), d(weights_b), d(biases_b),
               _ptr_array(ptrs), n_layers, B, C, H, W, first_stride, input_scale, PRECISION_CODE[precision],
-              _lib.ptr(fws), fws.numel() if fws is not None else 0, _lib.current_stream(dev))
+              _lib.ptr(fws), fws.numel() if fws is not None else 0,
+              arena.data_ptr() + 2 * big * 4 if precision == "f32" else None, _lib.current_stream(dev))
     return out
 
 
@@ -191,31 +197,36 @@ class ConvStackFn(torch.autograd.Function):
         need_grad = any(t.requires_grad for t in wb)
         out = torch.empty((B, 32, hs[-1], wsz[-1]), dtype=torch.float32, device=dev)
         al = 8  # elements: keeps every slice 16-byte aligned in both element types
+        tail = _AMAX if precision == "f32" else 0  # the per-tensor maxima live behind the activations (the backward reads them)
+        assert n_layers <= _AMAX
         if need_grad:  # one arena holds every intermediate activation
             offs, tot = [], 0
             for n in numel[:-1]:
                 offs.append(tot)
                 tot += (n + al - 1) // al * al
-            arena = torch.empty(max(tot, al), dtype=adt, device=dev)
+            tot = max(tot, al)
+            arena = torch.empty(tot + tail, dtype=adt, device=dev)
             ptrs = [arena.data_ptr() + o * arena.element_size() for o in offs]
         else:  # two ping-pong buffers
             big = (max(numel[:-1], default=al) + al - 1) // al * al
-            arena = torch.empty(2 * big, dtype=adt, device=dev)
+            tot = 2 * big
+            arena = torch.empty(tot + tail, dtype=adt, device=dev)
             ptrs = [arena.data_ptr() + (i & 1) * big * arena.element_size() for i in range(n_layers - 1)]
         ptrs.append(out.data_ptr())
-        fws = _frag_ws(dev, n_layers - 1) if precision == "f32" and n_layers > 1 else None
+        amax = arena.data_ptr() + tot * 4 if tail else None
+        fws = _frag_ws(dev, n_layers - 1) if precision in _SPLIT and n_layers > 1 else None
         _lib.call("augcl_enc_stack_forward", x.data_ptr(), _ptr_array([t.data_ptr() for t in weights]),
                   _ptr_array([t.data_ptr() for t in biases]), _ptr_array(ptrs), n_layers, B, C, H, W, first_stride,
-                  input_scale, PRECISION_CODE[precision], _lib.ptr(fws), fws.numel() if fws is not None else 0,
+                  input_scale, PRECISION_CODE[precision], _lib.ptr(fws), fws.numel() if fws is not None else 0, amax,
                   _lib.current_stream(dev))
         if need_grad:
             ctx.save_for_backward(x, arena, *weights)
-            ctx.meta = (first_stride, input_scale, precision, n_layers, ptrs[:-1], max(numel))
+            ctx.meta = (first_stride, input_scale, precision, n_layers, ptrs[:-1], max(numel), amax)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        first_stride, input_scale, precision, n_layers, act_ptrs, max_numel = ctx.meta
+        first_stride, input_scale, precision, n_layers, act_ptrs, max_numel, amax = ctx.meta
         x, arena = ctx.saved_tensors[:2]
         weights = ctx.saved_tensors[2:]
         B, C, H, W = x.shape
@@ -224,14 +235,16 @@ class ConvStackFn(torch.autograd.Function):
         g = grad_out.contiguous()
         dws = [torch.empty_like(w) for w in weights]
         dbs = torch.empty((n_layers, 32), dtype=torch.float32, device=dev)
-        dz = torch.empty(2 * ((max_numel + 7) // 8 * 8), dtype=torch.bfloat16 if bf16 else torch.float32, device=dev)
-        half = dz.numel() // 2 * dz.element_size()
+        half_n = (max_numel + 7) // 8 * 8
+        dz = torch.empty(2 * half_n + (_AMAX if amax else 0), dtype=torch.bfloat16 if bf16 else torch.float32, device=dev)
+        half = half_n * dz.element_size()
         ws32, wsf = _workspace(dev, 32, max(1, n_layers - 1)), _workspace(dev, C)
-        fws = _frag_ws(dev, n_layers - 1) if precision == "f32" and n_layers > 1 else None
+        fws = _frag_ws(dev, n_layers - 1) if precision in _SPLIT and n_layers > 1 else None
         _lib.call("augcl_enc_stack_backward", _ptr_array([x.data_ptr()] + list(act_ptrs)),
                   _ptr_array([w.data_ptr() for w in weights]), g.data_ptr(), _ptr_array([t.data_ptr() for t in dws]),
                   _ptr_array([dbs[i].data_ptr() for i in range(n_layers)]), dz.data_ptr(), dz.data_ptr() + half,
                   ws32.data_ptr(), ws32.numel() * 4, wsf.data_ptr(), wsf.numel() * 4, n_layers, B, C, H, W, first_stride,
                   input_scale, PRECISION_CODE[precision], 1 if _BF16_WGRAD.endswith("_mfma") else 0, _lib.ptr(fws),
-                  fws.numel() if fws is not None else 0, _lib.current_stream(dev))
+                  fws.numel() if fws is not None else 0, amax, dz.data_ptr() + 2 * half if amax else None,
+                  _lib.current_stream(dev))
         return (None, None, None, None, None, *dws, *[dbs[i] for i in range(n_layers)])

@@ -4,10 +4,11 @@ backward-data / backward-weights with fused /255, bias, ReLU and ReLU-mask epilo
 stack, activations kept post-ReLU in a per-call arena.  There is no other backend: without the library or a GPU
 tensor the op raises.  (tools/aten_encoder.py swaps an ATen stack in for A/B timing -- outside the package.)
 
-Precision: "f32" = parity path (f32 NCHW activations; the 32 -> 32 layers split every f32 operand exactly into three bf16
-parts and run the six significant cross products on the bf16 MFMA pipe with f32 accumulation -- float32 accuracy at
-2.67x the f32 MFMA rate, csrc/encoder_x3.hip); "f32_mfma" = the same tensors on the native f32 MFMA pipe (kept for
-A/B); "bf16" = performance mode of BASELINE config 2 (bf16 NHWC activations, bf16 MFMA, f32 accumulation / master
+Precision: "f32" = parity path (f32 NCHW activations; the 32 -> 32 layers write every f32 operand as an f16 pair hi + lo' 2^-11
+under a per-tensor power-of-two scale and run the three significant cross products on the f16 MFMA pipe with f32
+accumulation -- float32 accuracy at 5.3x the f32 MFMA rate, csrc/encoder_x2.hip); "f32_x3" = the same tensors with every
+operand split exactly into three bf16 parts, six products (csrc/encoder_x3.hip: no dynamic-range limit, half the rate);
+"f32_mfma" = the native f32 MFMA pipe (kept for A/B); "bf16" = performance mode of BASELINE config 2 (bf16 NHWC activations, bf16 MFMA, f32 accumulation / master
 weights / weight gradients).  `set_precision` sets the process default; an agent built with `args.precision` (or
 `agent.set_precision(name)`) carries its own choice on its CNN modules, so a bf16 agent and an f32 agent (the pretrained
 agent AugCL loads, an evaluation copy) can live in one process.
@@ -25,8 +26,8 @@ def set_precision(name):
 
 
 def _check(name):
-    if name not in ("f32", "f32_mfma", "bf16"):
-        raise ValueError(f"precision must be 'f32', 'f32_mfma' or 'bf16', got {name!r}")
+    if name not in ("f32", "f32_x3", "f32_mfma", "bf16"):
+        raise ValueError(f"precision must be 'f32', 'f32_x3', 'f32_mfma' or 'bf16', got {name!r}")
     return name
 
 
@@ -54,7 +55,7 @@ def conv_stack(x, weights, biases, first_stride=2, input_scale=255.0, relu_first
     prec = _check(precision or PRECISION)
     if relu_first:  # HeadCNN stacks (num_head_layers > 0): per-layer path, f32
         return encoder_hip.ConvStackLayerwiseFn.apply(x, first_stride, float(input_scale), True, len(weights),
-                                                      "f32_mfma" if prec == "f32_mfma" else "f32", *weights, *biases)
+                                                      "f32_mfma" if prec == "f32_mfma" else "f32_x3", *weights, *biases)
     for w in weights:
         assert w.shape[0] == 32 and w.is_contiguous(), "encoder kernels are built for 32 contiguous filters"
     if len(weights) == 1 and prec == "bf16":

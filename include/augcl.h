@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define AUGCL_ABI_VERSION 2 /* 2: the whole-stack entry points take a weight-fragment workspace */
+#define AUGCL_ABI_VERSION 3 /* 2: the whole-stack entry points take a weight-fragment workspace; 3: ... and the per-tensor maxima of precision 3 */
 
 #define AUGCL_OK 0
 #define AUGCL_E_INVALID (-1)   /* bad argument (null pointer, bad shape, misalignment) */
@@ -313,6 +313,26 @@ int augcl_enc_x3_conv32_backward_weights(const float *act_prev /* (B,32,Hi,Wi) *
                                          float *dw /* (32,32,3,3) */, float *db /* (32) */, float *workspace,
                                          size_t workspace_bytes, int B, int Hi, int Wi, augcl_stream_t stream);
 
+/* ---- ... and as F16 PAIRS (the default parity path inside the whole-stack entry points below, precision 3): every operand
+ * x s = hi + lo' 2^-11 with hi, lo' in f16 and s a per-tensor power of two that brings max |x| into [2^14, 2^15); the three
+ * significant cross products run on v_mfma_f32_32x32x16_f16 with f32 accumulation -- 1.4e-7 relative L2 against float64 at
+ * K = 288, half the matrix instructions of augcl_enc_x3_*.  The scale needs max |x| of each input tensor: inside a stack every
+ * kernel leaves the maximum of what it stores; a single layer takes them as arguments (device floats, exact maxima or upper
+ * bounds within 2x) and can return its output's (amax_out, may be NULL; overwritten, not accumulated).
+ * frag_ws: augcl_enc_frag_workspace_bytes(1, 1) bytes of device scratch, 16-byte aligned (the layer's weight fragments).
+ * Elements smaller than 2^-29 of their tensor's maximum lose relative accuracy (absolute error < 2^-36 of the maximum);
+ * shapes the kernels do not cover run augcl_enc_x3_*. */
+int augcl_enc_amax_f32(const float *x, size_t n, float *amax_out /* device, 1 float */, augcl_stream_t stream);
+int augcl_enc_x2_conv32_forward(const float *in, const float *w, const float *bias, float *out, int B, int Hi, int Wi, int relu,
+                                void *frag_ws, size_t frag_ws_bytes, const float *amax_in, float *amax_out,
+                                augcl_stream_t stream);
+int augcl_enc_x2_conv32_backward_data(const float *dz, const float *w, const float *act_prev, float *dact, int B, int Ho, int Wo,
+                                      void *frag_ws, size_t frag_ws_bytes, const float *amax_dz, float *amax_out,
+                                      augcl_stream_t stream);
+int augcl_enc_x2_conv32_backward_weights(const float *act_prev, const float *dz, float *dw, float *db, float *workspace,
+                                         size_t workspace_bytes, int B, int Hi, int Wi, const float *amax_act,
+                                         const float *amax_dz, augcl_stream_t stream);
+
 /* ---- bf16 PERFORMANCE MODE of the same conv stack (BASELINE config 2 "bf16"; NOT the parity path).
  * Activations are bf16 NHWC (B,H,W,32) in HBM, products on v_mfma_f32_32x32x16_bf16 with f32 accumulation,
  * weights/biases stay f32 masters (rounded to bf16 per launch).  The last layer can emit f32 NCHW for the
@@ -338,23 +358,31 @@ int augcl_enc_nchw_f32_to_nhwc_bf16(const float *in, void *out_bf16_nhwc, int B,
 
 /* ---- whole-stack entry points: every layer of the encoder forward / backward behind ONE call (the host pays one
  * FFI crossing per pass).  precision 0 = f32 NCHW on the f32 MFMA pipe, 1 = bf16 NHWC (performance mode), 2 = f32 NCHW
- * with the 32 -> 32 layers on the split-bf16 kernels (augcl_enc_x3_*: float32-accurate, the default parity path).
+ * with the 32 -> 32 layers on the split-bf16 kernels (augcl_enc_x3_*: float32-accurate, no range limit), 3 = f32 NCHW with
+ * the 32 -> 32 layers on the f16-pair kernels (csrc/encoder_x2.hip: every operand = hi + lo' 2^-11 in f16 under a per-tensor
+ * power-of-two scale, three v_mfma_f32_32x32x16_f16 per product group -- 1.4e-7 relative L2 against float64 at K = 288, half
+ * the matrix instructions of 2; the default parity path).  Precision 3 keeps float32 accuracy for every element within
+ * 2^29 of its tensor's largest magnitude; smaller elements keep an absolute error below 2^-36 of that maximum.
  * forward: acts_out[i] = output buffer of layer i (the last layer always writes f32 NCHW).
  * backward: acts_in[i] = input of layer i (acts_in[0] = the raw f32 image batch); dz_a / dz_b = two scratch buffers
  * of the largest activation's size; dw[i] / db[i] receive the weight / bias gradients.
- * frag_ws (precision 2 only; may be NULL): device scratch of augcl_enc_frag_workspace_bytes(n_layers - 1, sets) bytes
- * (sets = 1, 2 for the dual forward), 16-byte aligned.  With it the bf16 hi / mid / lo fragments of every 32 -> 32
- * layer's weights are made by ONE small launch per pass; without it every layer launch splits its own weights in its
- * prologue (same values, ~6 us per launch more).  The contents are scratch: valid only inside the call. */
+ * frag_ws: device scratch of augcl_enc_frag_workspace_bytes(n_layers - 1, sets) bytes (sets = 1, 2 for the dual forward),
+ * 16-byte aligned; the split weight fragments of every 32 -> 32 layer are made by ONE small launch per pass into it.
+ * Precision 2: may be NULL (every layer launch then splits its own weights in its prologue, ~6 us per launch more);
+ * precision 3: required.  The contents are scratch: valid only inside the call.
+ * amax (precision 3; NULL otherwise): n_layers floats (2 n_layers for the dual forward) on the device.  The forward pass
+ * leaves amax[i] = max |output of layer i| there (each kernel's epilogue takes the maximum of what it stores); the
+ * backward pass of the same activations must be given the same values (amax_acts) plus n_layers floats of scratch
+ * (amax_dz) for the gradients' maxima. */
 size_t augcl_enc_frag_workspace_bytes(int n_layers32, int weight_sets);
 int augcl_enc_stack_forward(const float *x, const float *const *w, const float *const *b, void *const *acts_out,
                             int n_layers, int B, int C, int H, int W, int first_stride, float scale, int precision,
-                            void *frag_ws, size_t frag_ws_bytes, augcl_stream_t stream);
+                            void *frag_ws, size_t frag_ws_bytes, float *amax, augcl_stream_t stream);
 int augcl_enc_stack_backward(const void *const *acts_in, const float *const *w, const float *grad_out, float *const *dw,
                              float *const *db, void *dz_a, void *dz_b, float *ws32, size_t ws32_bytes, float *ws_first,
                              size_t ws_first_bytes, int n_layers, int B, int C, int H, int W, int first_stride,
                              float scale, int precision, int bf16_wgrad_mfma, void *frag_ws, size_t frag_ws_bytes,
-                             augcl_stream_t stream);
+                             const float *amax_acts, float *amax_dz, augcl_stream_t stream);
 
 /* Two encoders with identical shapes over the SAME input batch in one launch per layer (no-grad passes: the actor's CNN
  * and the target critic's CNN over next_obs, src/algorithms/sac.py:94-101).  acts_out[i] holds 2B images: [0,B) from
@@ -363,7 +391,7 @@ int augcl_enc_stack_backward(const void *const *acts_in, const float *const *w, 
 int augcl_enc_stack_forward_dual(const float *x, const float *const *wA, const float *const *bA, const float *const *wB,
                                  const float *const *bB, void *const *acts_out, int n_layers, int B, int C, int H, int W,
                                  int first_stride, float scale, int precision, void *frag_ws, size_t frag_ws_bytes,
-                                 augcl_stream_t stream);
+                                 float *amax, augcl_stream_t stream);
 
 /* ---- device-resident replay sampling: ReplayBuffer.sample -> tensor_buffer_samples / _encode_obses /
  * LazyFrames._force (src/utils.py:206-214, 234-240, 272-280, 293-299).  `frames` is a uint8 ring of RGB frames

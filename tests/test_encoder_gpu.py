@@ -90,17 +90,28 @@ def test_shared_cnn_matches_reference_golden(cuda):
     assert rel_err(out.cpu(), want) <= 1e-5
 
 
-def test_full_batch_linearity_property(cuda):
-    """config-2 size (B=256): conv stack of a batch == stack of its halves (size-independent property)."""
+@pytest.mark.parametrize("precision", ["f32", "f32_x3"])
+def test_full_batch_linearity_property(cuda, precision):
+    """config-2 size (B=256): conv stack of a batch == stack of its halves (size-independent property).  Bit for bit on the
+    split-bf16 / f32 MFMA kernels, whose arithmetic per image does not know the batch.  The f16-pair kernels (precision "f32")
+    derive a power-of-two scale from the BATCH's maximum (exact, but it moves what falls into f16's subnormal range) and
+    alternate the sign of their accumulation strip by strip to cancel the matrix pipe's rounding bias, so an image's result
+    depends on its position in the launch in the last bits: held to 1e-6 of the output's range instead."""
     rs = np.random.RandomState(1)
     x = torch.from_numpy(rs.randint(0, 256, (256, 9, 84, 84)).astype(np.float32)).to(cuda)
     ws = [torch.from_numpy((rs.standard_normal((32, 9 if i == 0 else 32, 3, 3)) * 0.08).astype(np.float32)).to(cuda) for i in range(11)]
     bs = [torch.zeros(32, device=cuda) for _ in range(11)]
     with torch.no_grad():
-        full = encoder_ops.conv_stack(x, ws, bs)
-        halves = torch.cat([encoder_ops.conv_stack(x[:100].contiguous(), ws, bs), encoder_ops.conv_stack(x[100:].contiguous(), ws, bs)])
+        full = encoder_ops.conv_stack(x, ws, bs, precision=precision)
+        again = encoder_ops.conv_stack(x, ws, bs, precision=precision)
+        halves = torch.cat([encoder_ops.conv_stack(x[:100].contiguous(), ws, bs, precision=precision),
+                            encoder_ops.conv_stack(x[100:].contiguous(), ws, bs, precision=precision)])
     assert full.shape == (256, 32, 21, 21)
-    assert torch.equal(full, halves)
+    assert torch.equal(full, again)  # run-to-run: bit for bit in every precision
+    if precision == "f32":
+        assert float((full - halves).abs().max()) <= 1e-6 * float(full.abs().max())
+    else:
+        assert torch.equal(full, halves)
 
 
 def _l2(a, b):
@@ -147,7 +158,7 @@ def test_bf16_perf_mode_tracks_f32(cuda, B, gate_safe):
             assert float(g @ r / (g.norm() * r.norm())) > 0.95, f"dW layer {i} direction"
 
 
-@pytest.mark.parametrize("precision", ["f32", "f32_mfma", "bf16"])
+@pytest.mark.parametrize("precision", ["f32", "f32_x3", "f32_mfma", "bf16"])
 @pytest.mark.parametrize("B", [1, 6, 256])
 def test_dual_stack_forward_equals_two_passes(cuda, B, precision):
     """augcl_enc_stack_forward_dual: two weight sets over the same input in one launch per layer give exactly what two
@@ -167,7 +178,11 @@ def test_dual_stack_forward_equals_two_passes(cuda, B, precision):
     finally:
         encoder_ops.set_precision("f32")
     assert both is not None
-    assert torch.equal(both[0], one_a) and torch.equal(both[1], one_b)
+    if precision == "f32":  # f16 pairs: the same arithmetic up to the strip-wise sign pattern (see the linearity test)
+        for d, o in ((both[0], one_a), (both[1], one_b)):
+            assert float((d - o).abs().max()) <= 1e-6 * float(o.abs().max())
+    else:
+        assert torch.equal(both[0], one_a) and torch.equal(both[1], one_b)
     # shapes without the pipelined first layer fall back (None), they do not fail
     with torch.no_grad():
         assert encoder_ops.conv_stack_dual(torch.rand(2, 3, 40, 40, device=cuda), [w[:, :3].contiguous() if i == 0 else w for i, w in enumerate(wa)], ba,
@@ -218,3 +233,54 @@ def test_conv32_layer_entry_points_on_odd_shapes(cuda, B, H, W, pre):
         assert float((dw.double() - wd.grad).abs().max()) <= 3e-5 * float(wd.grad.abs().max())
         assert float((db.double() - dz.double().sum((0, 2, 3))).abs().max()) <= 3e-5 * float(dz.double().sum((0, 2, 3)).abs().max() + 1)
 
+
+
+@pytest.mark.parametrize("scale_x,scale_dz", [(1.0, 1.0), (3e4, 1e-9), (1e-6, 5e5)])
+@pytest.mark.parametrize("B,H,W", [(2, 12, 70), (3, 70, 12), (1, 10, 100), (2, 33, 35), (5, 11, 11), (1, 3, 9), (1, 5, 6), (2, 6, 9),
+                                   (1, 9, 130), (260, 41, 41), (3, 23, 23)])
+def test_x2_layer_entry_points_on_odd_shapes(cuda, B, H, W, scale_x, scale_dz):
+    """The f16-pair form of the three 32 -> 32 layer kernels (augcl_enc_x2_*: what precision "f32" runs inside the stack) through
+    the C ABI on the same odd shapes, with the tensors' maxima from augcl_enc_amax_f32 -- at magnitudes far outside f16's own
+    range (activations of 1e5, gradients of 1e-9: the per-tensor power-of-two scales carry them) -- against float64 ATen
+    convolutions; the maxima the kernels hand on must be the exact maxima of what they wrote."""
+    import torch.nn.functional as F
+    from augcl_amd import _lib
+    L = _lib.load()
+    g = torch.Generator(device=cuda).manual_seed(B * 1000 + H * 10 + W)
+    x = torch.relu(torch.randn(B, 32, H, W, device=cuda, generator=g)) * scale_x
+    w = torch.randn(32, 32, 3, 3, device=cuda, generator=g) * 0.06
+    bias = torch.randn(32, device=cuda, generator=g) * 0.1 * scale_x
+    dz = torch.randn(B, 32, H - 2, W - 2, device=cuda, generator=g) * scale_dz
+    st = _lib.current_stream(cuda)
+    p = lambda t: t.data_ptr()  # noqa: E731
+    fws = torch.empty(L.augcl_enc_frag_workspace_bytes(1, 1), dtype=torch.uint8, device=cuda)
+    am = torch.full((4,), float("nan"), device=cuda)  # [max|x|, max|dz|, max|y|, max|dx|]
+    _lib.call("augcl_enc_amax_f32", p(x), x.numel(), p(am), st)
+    _lib.call("augcl_enc_amax_f32", p(dz), dz.numel(), p(am) + 4, st)
+    assert float(am[0]) == float(x.abs().max()) and float(am[1]) == float(dz.abs().max())
+    # forward (+ ReLU)
+    y = torch.full((B, 32, H - 2, W - 2), float("nan"), device=cuda)
+    _lib.call("augcl_enc_x2_conv32_forward", p(x), p(w), p(bias), p(y), B, H, W, 1, p(fws), fws.numel(), p(am), p(am) + 8, st)
+    want = torch.relu(F.conv2d(x.double(), w.double(), bias.double()))
+    assert float((y.double() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    assert float(am[2]) == float(y.abs().max())
+    # backward-data, gated by the layer input's ReLU
+    dx = torch.full((B, 32, H, W), float("nan"), device=cuda)
+    _lib.call("augcl_enc_x2_conv32_backward_data", p(dz), p(w), p(x), p(dx), B, H - 2, W - 2, p(fws), fws.numel(), p(am) + 4, p(am) + 12, st)
+    want = F.conv_transpose2d(dz.double(), w.double()) * (x > 0)
+    assert float((dx.double() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    assert float(am[3]) == float(dx.abs().max())
+    # ... and without a gate (and without handing the maximum on)
+    _lib.call("augcl_enc_x2_conv32_backward_data", p(dz), p(w), None, p(dx), B, H - 2, W - 2, p(fws), fws.numel(), p(am) + 4, None, st)
+    full = F.conv_transpose2d(dz.double(), w.double())
+    assert float((dx.double() - full).abs().max()) <= 2e-5 * float(full.abs().max())
+    # backward-weights
+    if W - 2 >= 8:
+        ws = torch.empty(L.augcl_enc_wgrad_workspace_bytes(32) // 4, device=cuda)
+        dw, db = torch.full((32, 32, 3, 3), float("nan"), device=cuda), torch.full((32,), float("nan"), device=cuda)
+        _lib.call("augcl_enc_x2_conv32_backward_weights", p(x), p(dz), p(dw), p(db), p(ws), ws.numel() * 4, B, H, W, p(am), p(am) + 4, st)
+        wd = w.double().clone().requires_grad_(True)
+        F.conv2d(x.double(), wd).backward(dz.double())
+        assert float((dw.double() - wd.grad).abs().max()) <= 3e-5 * float(wd.grad.abs().max())
+        dbw = dz.double().sum((0, 2, 3))
+        assert float((db.double() - dbw).abs().max()) <= 3e-5 * float(dbw.abs().max() + dz.double().abs().sum((0, 2, 3)).max() * 1e-3)

@@ -133,8 +133,12 @@ def hip_forward(x, ws, bs):
         hs.append(hs[-1] - 2)
     acts = [torch.empty((B, 32, h, h), dtype=torch.float32, device=x.device) for h in hs]
     fws = encoder_hip._frag_ws(x.device, n - 1)
+    amax = torch.empty(n, dtype=torch.float32, device=x.device)  # precision "f32": max |output| of every layer
     _lib.call("augcl_enc_stack_forward", x.data_ptr(), _ptrs(ws), _ptrs(bs), _ptrs(acts), n, B, C, H, W, 2, 255.0,
-              encoder_hip.PRECISION_CODE[encoder_ops.PRECISION], fws.data_ptr(), fws.numel(), _lib.current_stream(x.device))
+              encoder_hip.PRECISION_CODE[encoder_ops.PRECISION], fws.data_ptr(), fws.numel(), amax.data_ptr(),
+              _lib.current_stream(x.device))
+    if encoder_ops.PRECISION == "f32":  # the kernels' maxima are the tensors' maxima, exactly
+        assert torch.equal(amax[:-1], torch.stack([a.abs().max() for a in acts[:-1]]))
     return acts
 
 
@@ -148,17 +152,24 @@ def hip_backward(x, acts_in, ws, gout):
     big = (max(t.numel() for t in acts_in[1:]) + 7) // 8 * 8
     dz = torch.empty(2 * big, dtype=torch.float32, device=dev)
     ws32, wsf = encoder_hip._workspace(dev, 32, max(1, n - 1)), encoder_hip._workspace(dev, C)
+    x2 = encoder_ops.PRECISION == "f32"  # the f16-pair kernels need the fragment workspace and the layer inputs' maxima
+    fws = encoder_hip._frag_ws(dev, n - 1) if x2 else None  # ("f32_x3" without it: the in-kernel split path)
+    amax_acts = torch.stack([a.abs().max() for a in acts_in[1:]] + [torch.zeros((), device=dev)]).float() if x2 else None
+    amax_dz = torch.empty(n, dtype=torch.float32, device=dev) if x2 else None
     _lib.call("augcl_enc_stack_backward", _ptrs(acts_in), _ptrs(ws), gout.data_ptr(), _ptrs(dws), _ptrs(dbs), dz.data_ptr(),
               dz.data_ptr() + 4 * big, ws32.data_ptr(), ws32.numel() * 4, wsf.data_ptr(), wsf.numel() * 4, n, B, C, H, W, 2,
-              255.0, encoder_hip.PRECISION_CODE[encoder_ops.PRECISION], 0, None, 0, _lib.current_stream(dev))  # (no fragment
-    return dws, dbs                                                            # workspace: the in-kernel split path)
+              255.0, encoder_hip.PRECISION_CODE[encoder_ops.PRECISION], 0, _lib.ptr(fws), fws.numel() if x2 else 0,
+              _lib.ptr(amax_acts), _lib.ptr(amax_dz), _lib.current_stream(dev))
+    return dws, dbs
 
 
 @pytest.mark.parametrize("B,init,precision", [(8, "he", "f32"), (8, "delta", "f32"), (256, "he", "f32"), (256, "delta", "f32"),
-                                              (512, "he", "f32"), (8, "he", "f32_mfma"), (256, "he", "f32_mfma")])
+                                              (512, "he", "f32"), (8, "he", "f32_x3"), (256, "he", "f32_x3"),
+                                              (8, "he", "f32_mfma"), (256, "he", "f32_mfma")])
 def test_encoder_against_f64_referee(cuda, monkeypatch, B, init, precision):
-    """precision "f32" = the parity path (32 -> 32 layers: float32-accurate products on the bf16 MFMA pipe, csrc/encoder_x3.hip);
-    "f32_mfma" = the native f32 MFMA kernels, held to the same bounds."""
+    """precision "f32" = the parity path (32 -> 32 layers: float32-accurate products as f16 pairs on the f16 MFMA pipe,
+    csrc/encoder_x2.hip); "f32_x3" = three-way bf16 splits (csrc/encoder_x3.hip); "f32_mfma" = the native f32 MFMA kernels;
+    all held to the same bounds."""
     monkeypatch.setattr(encoder_ops, "PRECISION", precision)
     t0 = time.time()
     _, cs = make_states(init, 6, 11)
@@ -256,7 +267,7 @@ def test_bf16_encoder_against_f64_referee(cuda):
     hs = [41 - 2 * i for i in range(n)]
     acts = [torch.empty((B, h, h, 32), dtype=torch.bfloat16, device=cuda) for h in hs[:-1]] + [torch.empty((B, 32, 21, 21), device=cuda)]
     _lib.call("augcl_enc_stack_forward", xd.data_ptr(), _ptrs(wd), _ptrs(bd), _ptrs(acts), n, B, 9, 84, 84, 2, 255.0, 1,
-              None, 0, _lib.current_stream(cuda))
+              None, 0, None, _lib.current_stream(cuda))
     torch.cuda.synchronize()
     fwd = [rel_l2(a.permute(0, 3, 1, 2).float(), torch.relu(z)) for a, z in zip(acts[:-1], pre64)] + [rel_l2(acts[-1], out64)]
     gates_hip = [(a.permute(0, 3, 1, 2) > 0).cpu() for a in acts[:-1]]

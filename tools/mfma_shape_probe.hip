@@ -10,6 +10,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 template <int SHAPE>
 __global__ __launch_bounds__(256, 1) void k_loop(const uint4 *ops, float *out, int iters, unsigned long long *clk)
@@ -30,6 +31,16 @@ __global__ __launch_bounds__(256, 1) void k_loop(const uint4 *ops, float *out, i
             for (int i = 0; i < 6; ++i) p = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[i], p, 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < 6; ++i) n = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[i], a[i], n, 0, 0, 0);
+        }
+        for (int r = 0; r < 16; ++r) sink += p[r] - n[r];
+    } else if (SHAPE == 33) { // v_mfma_f32_32x32x16_f16: same shape and rate as the bf16 form, 11-bit significands (operands: the same bits)
+        f32x16 p, n;
+        for (int r = 0; r < 16; ++r) p[r] = n[r] = 0.f;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) p = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[i]), __builtin_bit_cast(f16x8, b[i]), p, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) n = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, b[i]), __builtin_bit_cast(f16x8, a[i]), n, 0, 0, 0);
         }
         for (int r = 0; r < 16; ++r) sink += p[r] - n[r];
     } else {
@@ -65,14 +76,16 @@ int main()
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int iters = 400000; // x 12 MFMAs of 32 cycles = 154 M cycles ~ 0.1 s; launched 10x back to back
     for (int rep = 0; rep < 2; ++rep)
-        for (int shape : {32, 16}) {
+        for (int shape : {32, 33, 16}) {
             for (int w = 0; w < 3; ++w) {
                 if (shape == 32) hipLaunchKernelGGL(k_loop<32>, dim3(256), dim3(256), 0, 0, ops, out, iters, clk);
+                else if (shape == 33) hipLaunchKernelGGL(k_loop<33>, dim3(256), dim3(256), 0, 0, ops, out, iters, clk);
                 else hipLaunchKernelGGL(k_loop<16>, dim3(256), dim3(256), 0, 0, ops, out, iters, clk);
             }
             hipEventRecord(e0);
             for (int w = 0; w < 10; ++w) {
                 if (shape == 32) hipLaunchKernelGGL(k_loop<32>, dim3(256), dim3(256), 0, 0, ops, out, iters, clk);
+                else if (shape == 33) hipLaunchKernelGGL(k_loop<33>, dim3(256), dim3(256), 0, 0, ops, out, iters, clk);
                 else hipLaunchKernelGGL(k_loop<16>, dim3(256), dim3(256), 0, 0, ops, out, iters, clk);
             }
             hipEventRecord(e1); hipEventSynchronize(e1);

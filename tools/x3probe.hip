@@ -11,6 +11,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int K = 288, NT = 512; // NT independent 32x32 problems
 
@@ -40,6 +41,51 @@ __device__ __forceinline__ void split3(float x, __bf16 &h, __bf16 &m, __bf16 &l)
 // mode 0: f32 MFMA; 1: 3 terms (hh, hm, mh); 2: 5 terms (+ hl, lh); 3: 6 terms (+ mm); 4: 9 terms; 5: 6 terms, truncation split
 // 6: 6 terms, small products first; 7: 6 terms, two accumulators of opposite sign (even k-steps +A, odd k-steps -A), D = P - N:
 // the bf16 MFMA's accumulation has a tiny bias toward -infinity (mean error column); it cancels in P - N
+// f16 pair: x * 2^-e = hi + lo' * 2^-11 (hi = f16(x'), lo' = f16((x' - hi) * 2^11), both RNE): 22..24 significand bits as long as
+// x' sits in f16's normal range; e is a per-tensor power of two (exact)
+__device__ __forceinline__ void split_h(float x, _Float16 &h, _Float16 &l)
+{
+    h = (_Float16)x;
+    l = (_Float16)((x - (float)h) * 2048.0f);
+}
+
+// modes 8..11 (f16 pairs, 3 products hh + (hl' + l'h) 2^-11, two accumulators): 8 = no scaling, 9 = operands scaled by per-tensor
+// powers of two (max -> [2^14, 2^15)), 10 = 9 with +/- main accumulators, 11 = 9 with all four products (+ l'l' 2^-22)
+__global__ void k_probe_h(const float *A, const float *B, float *D, int mode, float sa, float sb)
+{
+    const int lane = threadIdx.x, l31 = lane & 31, h = lane >> 5;
+    const float *a = A + (size_t)blockIdx.x * 32 * K, *b = B + (size_t)blockIdx.x * K * 32;
+    f32x16 acc, accn, accx, accl;
+    for (int r = 0; r < 16; ++r) acc[r] = accn[r] = accx[r] = accl[r] = 0.0f;
+    for (int k = 0; k < K; k += 16) {
+        f16x8 ah, al, bh, bl;
+        for (int j = 0; j < 8; ++j) {
+            _Float16 x, y;
+            split_h(a[l31 * K + k + 8 * h + j] * sa, x, y);
+            ah[j] = x; al[j] = y;
+            split_h(b[(k + 8 * h + j) * 32 + l31] * sb, x, y);
+            bh[j] = x; bl[j] = y;
+        }
+        const bool neg = mode == 10 && ((k >> 4) & 1);
+        if (mode == 11) accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bl, accl, 0, 0, 0);
+        accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accx, 0, 0, 0);
+        accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accx, 0, 0, 0);
+        if (neg) {
+            f16x8 an;
+            for (int j = 0; j < 8; ++j) an[j] = -ah[j];
+            accn = __builtin_amdgcn_mfma_f32_32x32x16_f16(an, bh, accn, 0, 0, 0);
+        } else {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+        }
+    }
+    float *d = D + (size_t)blockIdx.x * 1024;
+    const float inv = 1.0f / (sa * sb);
+    for (int r = 0; r < 16; ++r) {
+        const float cross = accx[r] * (1.0f / 2048.0f) + accl[r] * (1.0f / (2048.0f * 2048.0f));
+        d[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + l31] = ((acc[r] - accn[r]) + cross) * inv;
+    }
+}
+
 __global__ void k_probe(const float *A, const float *B, float *D, int mode)
 {
     const int lane = threadIdx.x, l31 = lane & 31, h = lane >> 5;
@@ -88,7 +134,8 @@ int main()
     hipMalloc(&dA, A.size() * 4); hipMalloc(&dB, B.size() * 4); hipMalloc(&dD, D.size() * 4);
     const char *names[] = {"f32 mfma 32x32x2", "bf16x3: 3 terms", "bf16x3: 5 terms", "bf16x3: 6 terms", "bf16x3: 9 terms",
                            "bf16x3: 6 terms, truncation split", "bf16x3: 6 terms, small first",
-                           "bf16x3: 6 terms, +/- accumulators"};
+                           "bf16x3: 6 terms, +/- accumulators", "f16x2: 3 terms, unscaled", "f16x2: 3 terms, scaled",
+                           "f16x2: 3 terms, scaled, +/- main", "f16x2: 4 terms, scaled"};
     for (int dist = 0; dist < 4; ++dist) {
         srand(1234 + dist);
         auto rnd = []() { return (rand() + 0.5) / (RAND_MAX + 1.0); };
@@ -105,8 +152,17 @@ int main()
         hipMemcpy(dB, B.data(), B.size() * 4, hipMemcpyHostToDevice);
         const char *dn[] = {"gauss", "relu(gauss)", "1e-6*gauss", "gauss*exp(8*gauss)"};
         printf("== B operand: %s\n", dn[dist]);
-        for (int mode = 0; mode < 8; ++mode) {
-            hipLaunchKernelGGL(k_probe, dim3(NT), dim3(64), 0, 0, dA, dB, dD, mode);
+        auto pow2_scale = [](const std::vector<float> &v) { // power of two that brings max |v| into [2^14, 2^15)
+            float m = 0;
+            for (float x : v) m = fmaxf(m, fabsf(x));
+            int e;
+            frexpf(m, &e); // m = f * 2^e, f in [0.5, 1)
+            return ldexpf(1.0f, 15 - e);
+        };
+        const float sa = pow2_scale(A), sb = pow2_scale(B);
+        for (int mode = 0; mode < 12; ++mode) {
+            if (mode >= 8) hipLaunchKernelGGL(k_probe_h, dim3(NT), dim3(64), 0, 0, dA, dB, dD, mode, mode == 8 ? 1.0f : sa, mode == 8 ? 1.0f : sb);
+            else hipLaunchKernelGGL(k_probe, dim3(NT), dim3(64), 0, 0, dA, dB, dD, mode);
             hipMemcpy(D.data(), dD, D.size() * 4, hipMemcpyDeviceToHost);
             double num = 0, den = 0, maxrel = 0, bias = 0, sabs = 0;
             for (int t = 0; t < NT; ++t)
