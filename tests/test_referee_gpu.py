@@ -396,8 +396,10 @@ def test_update_against_f64_referee(cuda, monkeypatch, algo, data_aug, A, B, hpo
         agent = load(make_agent(OBS, (A,), args))
     agent.fuse_front_end = False
 
-    # gates of the HIP run, CNN part: the encoder forward through the C ABI on the very tensors update() will see
-    # (per-image results do not depend on how images are batched -- checked below against the features update() used)
+    # gates of the HIP run, CNN part: the encoder forward through the C ABI on the very tensors update() will see, batched as
+    # update() batches them (SVEA / DrQ run their passes as ONE batch; the f16-pair kernels' last bits depend on an image's
+    # position in the launch, see tests/test_encoder_gpu.py::test_full_batch_linearity_property) -- which of the two batchings
+    # update() used is decided below by the features it computed, bit for bit
     ids = so.conv_layer_ids(11)
     cnn_w = [cs[f"encoder.shared_cnn.layers.{i}.weight"].to(cuda) for i in ids]
     cnn_b = [cs[f"encoder.shared_cnn.layers.{i}.bias"].to(cuda) for i in ids]
@@ -406,7 +408,15 @@ def test_update_against_f64_referee(cuda, monkeypatch, algo, data_aug, A, B, hpo
         acts = hip_forward(x, cnn_w, cnn_b)
         return [(a > 0).cpu() for a in acts[:-1]], acts[-1]
 
-    crit_cnn = [cnn_gates(x) for x in critic_inputs]
+    def cnn_variants(inputs):
+        out = [[cnn_gates(x) for x in inputs]]
+        if len(inputs) > 1:
+            g, f = cnn_gates(torch.cat(inputs))
+            n0 = inputs[0].shape[0]
+            out.append([([gl[i * n0:(i + 1) * n0] for gl in g], f[i * n0:(i + 1) * n0]) for i in range(len(inputs))])
+        return out
+
+    crit_variants = cnn_variants(critic_inputs)
     weak_cnn = [cnn_gates(x) for x in weak_inputs]
     seen_feat = []
     watched = [agent.critic.encoder.shared_cnn] + ([agent.critic_weak.encoder.shared_cnn] if algo == "augcl" else [])
@@ -452,9 +462,13 @@ def test_update_against_f64_referee(cuda, monkeypatch, algo, data_aug, A, B, hpo
     assert not queue
 
     # the features update() computed are the ones the gates were taken from (bit for bit)
-    want_feats = ([f for _, f in weak_cnn] if algo == "augcl" else []) + [f for _, f in crit_cnn]
-    got = torch.cat([f.reshape(-1, 32, 21, 21) for f in seen_feat])[:sum(f.shape[0] for f in want_feats)]
-    assert torch.equal(got, torch.cat(want_feats)), "encoder features inside update() differ from the C-ABI forward"
+    crit_cnn = None
+    for cand in crit_variants:
+        want_feats = ([f for _, f in weak_cnn] if algo == "augcl" else []) + [f for _, f in cand]
+        got = torch.cat([f.reshape(-1, 32, 21, 21) for f in seen_feat])[:sum(f.shape[0] for f in want_feats)]
+        if torch.equal(got, torch.cat(want_feats)):
+            crit_cnn = cand
+    assert crit_cnn is not None, "encoder features inside update() differ from the C-ABI forward"
 
     # assemble the gate sets per oracle pass.  twin_q calls in update() order: the target pass(es) (no gradient: not
     # forced), then the critic passes (AugCL: weak first), last the actor step's critic call.
