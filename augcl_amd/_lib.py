@@ -122,9 +122,9 @@ _SIGS = {
     "augcl_enc_x2_conv32_forward": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _SZ, _P, _P, _P],
     "augcl_enc_x2_conv32_backward_data": [_P, _P, _P, _P, _I, _I, _I, _P, _SZ, _P, _P, _P],
     "augcl_enc_x2_conv32_backward_weights": [_P, _P, _P, _P, _P, _SZ, _I, _I, _I, _P, _P, _P],
-    "augcl_enc_stack_forward": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P, _SZ, _P, _P],
+    "augcl_enc_stack_forward": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P, _SZ, _P, _P, _P],
     "augcl_enc_frag_workspace_bytes": [_I, _I],
-    "augcl_enc_stack_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P, _SZ, _I, _I, _I, _I, _I, _I, _F, _I, _I, _P, _SZ, _P, _P, _P],
+    "augcl_enc_stack_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P, _SZ, _I, _I, _I, _I, _I, _I, _F, _I, _I, _P, _SZ, _P, _P, _P, _P],
     "augcl_enc_stack_forward_dual": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P, _SZ, _P, _P],
     "augcl_replay_gather": [_P, _P, _P, _I, _I, _I, _I, _P],
     "augcl_enc_conv_first_forward": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],

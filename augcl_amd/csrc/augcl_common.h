@@ -67,10 +67,11 @@ __device__ __forceinline__ void store_nt(uint32_t *dst, uint32_t v) { __builtin_
 
 // first layer fast path (encoder_first.hip): AUGCL_OK / negative error after launching, +1 if the shape is not covered
 // w2 / bias2 != null: two-weight-set forward (B images = two halves over the SAME B/2 inputs); amax_out (f32 output only):
-// max |out| is atomically max-ed into it (one float, two per half when dual; zeroed by the caller)
+// max |out| is atomically max-ed into it (one float, two per half when dual; zeroed by the caller); gate_bits_out (f32 output
+// with ReLU only): one word per output pixel (B,Ho,Wo), bit c = (channel c > 0)
 int conv_first9_try(const float *in, const float *w, const float *bias, void *out, int B, int C, int Hi, int Wi, int stride,
                     float scale, int relu, bool out_bf16, hipStream_t s, const char *name, const float *w2 = nullptr,
-                    const float *bias2 = nullptr, float *amax_out = nullptr);
+                    const float *bias2 = nullptr, float *amax_out = nullptr, void *gate_bits_out = nullptr);
 
 #define AUGCL_REQUIRE(cond, ...)                                 \
     do {                                                         \

@@ -46,6 +46,9 @@ struct First9Args {
     // f32 output only: max |out| is atomically max-ed into it (float bits, zeroed by the caller; dual: [0] / [1] per half), or
     // null -- the f16-pair kernels of the next layer derive their operand scale from it (encoder_x2.hip)
     uint32_t *amax_out;
+    // f32 output with ReLU only: gate bits, one word per output pixel (B,Ho,Wo), bit c = (channel c > 0), or null -- the next
+    // layer's backward-data reads them instead of this layer's output (encoder_x2.hip)
+    uint32_t *bits_out;
 };
 
 constexpr int F9_U = 12;  // 16-byte chunks per loader lane per strip
@@ -337,13 +340,20 @@ __global__ __launch_bounds__(512, 2) void k_conv_first9(First9Args a)
                 } else { // buffer stores: lane byte offset + a wave-uniform row offset in an SGPR (no vector address chain)
                     const int chw = a.Ho * a.Wo;
                     const unsigned boff = (unsigned)(((b * 32 + 4 * h) * a.Ho + y) * a.Wo + xx) * 4u; // host: B*32*Ho*Wo < 2^30
+                    uint32_t gbits = 0u;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         float v = acc[r];
                         if (RELU) v = __int_as_float(max(__float_as_int(v), 0)); // one v_max_i32: negative floats are negative ints
                         vmax = fmaxf(vmax, fabsf(v));
+                        if (RELU) gbits |= ((__float_as_uint(v) + 0x7fffffffu) >> 31) << ((r & 3) + 8 * (r >> 2)); // v >= +0: positive <=> bits >= 1
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_out, boff,
                                                               (unsigned)(((r & 3) + 8 * (r >> 2)) * chw) * 4u, 0);
+                    }
+                    if (RELU && a.bits_out != nullptr) { // the two half-waves hold the two channel sets of the same 32 pixels
+                        const uint32_t mine = gbits << (4 * h);
+                        const uint32_t word = mine | (uint32_t)__shfl_xor((int)mine, 32, 64);
+                        if (h == 0) a.bits_out[(size_t)(b * a.Ho + y) * a.Wo + xx] = word;
                     }
                 }
             }
@@ -388,7 +398,7 @@ static int launch_first9_t(First9Args &a, int cus, hipStream_t s, const char *na
 // to the generic kernel)
 int conv_first9_try(const float *in, const float *w, const float *bias, void *out, int B, int C, int Hi, int Wi, int stride,
                     float scale, int relu, bool out_bf16, hipStream_t s, const char *name, const float *w2,
-                    const float *bias2, float *amax_out)
+                    const float *bias2, float *amax_out, void *gate_bits_out)
 {
     if (C != 9 || Wi != 84 || stride != 2 || Hi < 3) return 1;
     if (w2 != nullptr && (B & 1)) return 1;
@@ -398,6 +408,7 @@ int conv_first9_try(const float *in, const float *w, const float *bias, void *ou
     a.in = in; a.w = w; a.bias = bias; a.out = out;
     a.w2 = w2; a.bias2 = bias2; a.dual = w2 != nullptr;
     a.amax_out = reinterpret_cast<uint32_t *>(amax_out);
+    a.bits_out = reinterpret_cast<uint32_t *>(gate_bits_out);
     a.B = B; a.Hi = Hi; a.Ho = (Hi - 3) / 2 + 1; a.Wo = (Wi - 3) / 2 + 1; a.scale = scale;
     // one strip = one round of loads: 9 * (2RT+1) * WI/4 chunks <= 256 * F9_U
     int rt = ((256 * F9_U) / (9 * (Wi / 4)) - 1) / 2;

@@ -14,13 +14,16 @@ int augcl_internal_x3_conv32_backward_data(const float *dz, const float *w, cons
                                            int Wo, const void *wfrag, augcl_stream_t stream);
 int augcl_internal_x3_prep_weights(const float *const *w, int n, int mode, void *out, augcl_stream_t stream);
 // encoder_x2.hip (f16-pair kernels, precision 3); the layer calls return +1 for a shape they do not cover
-int augcl_internal_x2_prep_weights(const float *const *w, int n, int mode, void *out, augcl_stream_t stream);
+int augcl_internal_x2_prep_weights(const float *const *w, int n, int mode, void *out, float *zero, int n_zero,
+                                   augcl_stream_t stream);
 int augcl_internal_amax_f32(const float *x, size_t n, float *out, augcl_stream_t stream);
+int augcl_internal_gate_bits(const float *x, void *bits, int B, int H, int W, augcl_stream_t stream);
 int augcl_internal_x2_conv32_forward(const float *in, const float *bias, const float *bias2, float *out, int B, int Hi, int Wi,
                                      int relu, const void *wfrag, const void *wfrag2, const float *amax_in, float *amax_out,
-                                     augcl_stream_t stream);
+                                     void *gate_bits_out, augcl_stream_t stream);
 int augcl_internal_x2_conv32_backward_data(const float *dz, const float *act_prev, float *dact, int B, int Ho, int Wo,
-                                           const void *wfrag, const float *amax_in, float *amax_out, augcl_stream_t stream);
+                                           const void *wfrag, const float *amax_in, float *amax_out, const void *gate_bits,
+                                           augcl_stream_t stream);
 int augcl_internal_x2_conv32_backward_weights(const float *act_prev, const float *dz, float *dw, float *db, float *workspace,
                                               size_t workspace_bytes, int B, int Hi, int Wi, const float *amax_act,
                                               const float *amax_dz, augcl_stream_t stream);
@@ -29,12 +32,12 @@ int augcl_internal_x2_conv32_backward_weights(const float *act_prev, const float
 // augcl_enc_frag_workspace_bytes(n_layers - 1, sets) bytes; null / too small: every layer launch prepares its own in its
 // prologue -- ~6 us of a 20-90 us launch).  Returns the per-layer block size in bytes, or 0 when not used.
 static size_t x3_prepare(const float *const *w, int n_layers, int mode, char *ws, size_t ws_bytes, size_t at, augcl_stream_t stream,
-                         int *rc, bool f16_pairs = false)
+                         int *rc, bool f16_pairs = false, float *zero = nullptr, int n_zero = 0)
 {
     *rc = AUGCL_OK;
     const size_t block = augcl_enc_frag_workspace_bytes(1, 1), need = at + (size_t)(n_layers - 1) * block;
     if (ws == nullptr || n_layers < 2 || n_layers > 33 || ws_bytes < need) return 0;
-    *rc = f16_pairs ? augcl_internal_x2_prep_weights(w + 1, n_layers - 1, mode, ws + at, stream)
+    *rc = f16_pairs ? augcl_internal_x2_prep_weights(w + 1, n_layers - 1, mode, ws + at, zero, n_zero, stream)
                     : augcl_internal_x3_prep_weights(w + 1, n_layers - 1, mode, ws + at, stream);
     return *rc == AUGCL_OK ? block : 0;
 }
@@ -71,7 +74,7 @@ static int x2_layer_prep(const char *name, const float *w, int mode, void *frag_
         if (e != hipSuccess) return augcl::fail(AUGCL_E_LAUNCH, "%s: memset: %s", name, hipGetErrorString(e));
     }
     const float *wl[1] = {w};
-    return augcl_internal_x2_prep_weights(wl, 1, mode, frag_ws, stream);
+    return augcl_internal_x2_prep_weights(wl, 1, mode, frag_ws, nullptr, 0, stream);
 }
 
 int augcl_enc_x2_conv32_forward(const float *in, const float *w, const float *bias, float *out, int B, int Hi, int Wi, int relu,
@@ -83,7 +86,7 @@ int augcl_enc_x2_conv32_forward(const float *in, const float *w, const float *bi
     if (B == 0) return AUGCL_OK;
     int rc = x2_layer_prep(name, w, 0, frag_ws, frag_ws_bytes, amax_out, stream);
     if (rc != AUGCL_OK) return rc;
-    rc = augcl_internal_x2_conv32_forward(in, bias, nullptr, out, B, Hi, Wi, relu, frag_ws, nullptr, amax_in, amax_out, stream);
+    rc = augcl_internal_x2_conv32_forward(in, bias, nullptr, out, B, Hi, Wi, relu, frag_ws, nullptr, amax_in, amax_out, nullptr, stream);
     if (rc <= 0) return rc;
     rc = augcl_enc_x3_conv32_forward(in, w, bias, out, B, Hi, Wi, relu, stream); // shape not covered: the split-bf16 kernel
     if (rc == AUGCL_OK && amax_out != nullptr) rc = augcl_internal_amax_f32(out, (size_t)B * 32 * (Hi - 2) * (Wi - 2), amax_out, stream);
@@ -99,7 +102,7 @@ int augcl_enc_x2_conv32_backward_data(const float *dz, const float *w, const flo
     if (B == 0) return AUGCL_OK;
     int rc = x2_layer_prep(name, w, 1, frag_ws, frag_ws_bytes, amax_out, stream);
     if (rc != AUGCL_OK) return rc;
-    rc = augcl_internal_x2_conv32_backward_data(dz, act_prev, dact, B, Ho, Wo, frag_ws, amax_dz, amax_out, stream);
+    rc = augcl_internal_x2_conv32_backward_data(dz, act_prev, dact, B, Ho, Wo, frag_ws, amax_dz, amax_out, nullptr, stream);
     if (rc <= 0) return rc;
     rc = augcl_enc_x3_conv32_backward_data(dz, w, act_prev, dact, B, Ho, Wo, stream);
     if (rc == AUGCL_OK && amax_out != nullptr) rc = augcl_internal_amax_f32(dact, (size_t)B * 32 * (Ho + 2) * (Wo + 2), amax_out, stream);
@@ -125,7 +128,7 @@ int augcl_enc_x2_conv32_backward_weights(const float *act_prev, const float *dz,
 // amax[i] = max |output of layer i| on return (the backward pass reads them).
 int augcl_enc_stack_forward(const float *x, const float *const *w, const float *const *b, void *const *acts_out,
                             int n_layers, int B, int C, int H, int W, int first_stride, float scale, int precision,
-                            void *frag_ws, size_t frag_ws_bytes, float *amax, augcl_stream_t stream)
+                            void *frag_ws, size_t frag_ws_bytes, float *amax, void *const *gate_bits, augcl_stream_t stream)
 {
     const char *name = "augcl_enc_stack_forward";
     AUGCL_REQUIRE(x && w && b && acts_out && n_layers >= 1, "%s: bad argument", name);
@@ -137,25 +140,22 @@ int augcl_enc_stack_forward(const float *x, const float *const *w, const float *
     const bool x2 = precision == 3 && n_layers >= 2;
     if (precision == 3 && (rc = x2_require(name, n_layers, frag_ws, frag_ws_bytes, 1, amax)) != AUGCL_OK) return rc;
     if (precision == 2 || x2) {
-        fblock = x3_prepare(w, n_layers, 0, (char *)frag_ws, frag_ws_bytes, 0, stream, &rc, x2);
-        if (rc != AUGCL_OK) return rc;
-    }
-    if (x2) {
-        hipError_t e = hipMemsetAsync(amax, 0, (size_t)n_layers * sizeof(float), (hipStream_t)stream);
-        if (e != hipSuccess) return augcl::fail(AUGCL_E_LAUNCH, "%s: memset: %s", name, hipGetErrorString(e));
+        fblock = x3_prepare(w, n_layers, 0, (char *)frag_ws, frag_ws_bytes, 0, stream, &rc, x2, x2 ? amax : nullptr, n_layers);
+        if (rc != AUGCL_OK) return rc; // (precision 3: the same launch zeroes the maxima)
     }
     for (int i = 0; i < n_layers; ++i) {
         const int relu = i < n_layers - 1;
         const bool last = i == n_layers - 1;
         if (i == 0) {
             if (x2) { // the pipelined first-layer kernel leaves max |a_0| itself; any other shape: generic kernel + one reduction
+                void *gb = gate_bits && relu ? gate_bits[0] : nullptr;
                 rc = augcl::conv_first9_try(x, w[0], b[0], acts_out[0], B, C, h, ww, first_stride, scale, relu, false,
-                                            (hipStream_t)stream, name, nullptr, nullptr, amax);
+                                            (hipStream_t)stream, name, nullptr, nullptr, amax, gb);
                 if (rc > 0) {
+                    const int ho = out_hw(h, first_stride), wo = out_hw(ww, first_stride);
                     rc = augcl_enc_conv_first_forward(x, w[0], b[0], (float *)acts_out[0], B, C, h, ww, first_stride, scale, relu, stream);
-                    if (rc == AUGCL_OK)
-                        rc = augcl_internal_amax_f32((const float *)acts_out[0],
-                                                     (size_t)B * 32 * out_hw(h, first_stride) * out_hw(ww, first_stride), amax, stream);
+                    if (rc == AUGCL_OK) rc = augcl_internal_amax_f32((const float *)acts_out[0], (size_t)B * 32 * ho * wo, amax, stream);
+                    if (rc == AUGCL_OK && gb) rc = augcl_internal_gate_bits((const float *)acts_out[0], gb, B, ho, wo, stream);
                 }
             } else if (precision != 1)
                 rc = augcl_enc_conv_first_forward(x, w[0], b[0], (float *)acts_out[0], B, C, h, ww, first_stride, scale, relu,
@@ -172,13 +172,15 @@ int augcl_enc_stack_forward(const float *x, const float *const *w, const float *
                 rc = augcl_internal_x3_conv32_forward((const float *)cur, w[i], b[i], nullptr, nullptr, (float *)acts_out[i], B, h, ww,
                                                       relu, fblock ? (char *)frag_ws + (size_t)(i - 1) * fblock : nullptr, nullptr, stream);
             else if (precision == 3) {
+                void *gb = gate_bits && relu ? gate_bits[i] : nullptr;
                 rc = augcl_internal_x2_conv32_forward((const float *)cur, b[i], nullptr, (float *)acts_out[i], B, h, ww, relu,
                                                       (char *)frag_ws + (size_t)(i - 1) * fblock, nullptr, amax + i - 1,
-                                                      last ? nullptr : amax + i, stream);
-                if (rc > 0) { // a shape the f16-pair kernel does not cover: the split-bf16 kernel (or its own fallback) + one reduction
+                                                      last ? nullptr : amax + i, gb, stream);
+                if (rc > 0) { // a shape the f16-pair kernel does not cover: the split-bf16 kernel (or its own fallback) + reductions
                     rc = augcl_enc_x3_conv32_forward((const float *)cur, w[i], b[i], (float *)acts_out[i], B, h, ww, relu, stream);
                     if (rc == AUGCL_OK && !last)
                         rc = augcl_internal_amax_f32((const float *)acts_out[i], (size_t)B * 32 * (h - 2) * (ww - 2), amax + i, stream);
+                    if (rc == AUGCL_OK && gb) rc = augcl_internal_gate_bits((const float *)acts_out[i], gb, B, h - 2, ww - 2, stream);
                 }
             } else
                 rc = augcl_enc_bf16_conv32_forward(cur, w[i], b[i], acts_out[i], B, h, ww, relu, last ? 1 : 0, stream);
@@ -213,23 +215,25 @@ int augcl_enc_stack_forward_dual(const float *x, const float *const *wA, const f
     const int B2 = 2 * B;
     int rc;
     const bool x2 = precision == 3;
-    if (x2) { // amax[2 i + set] = max |output of layer i| of that weight set's half
+    const size_t setB = (size_t)(n_layers - 1) * augcl_enc_frag_workspace_bytes(1, 1); // set B's blocks follow set A's
+    size_t fblock = 0;
+    if (x2) { // amax[2 i + set] = max |output of layer i| of that weight set's half; zeroed by the first preparation launch
         if ((rc = x2_require(name, n_layers, frag_ws, frag_ws_bytes, 2, amax)) != AUGCL_OK) return rc;
-        hipError_t e = hipMemsetAsync(amax, 0, (size_t)2 * n_layers * sizeof(float), (hipStream_t)stream);
-        if (e != hipSuccess) return augcl::fail(AUGCL_E_LAUNCH, "%s: memset: %s", name, hipGetErrorString(e));
+        fblock = x3_prepare(wA, n_layers, 0, (char *)frag_ws, frag_ws_bytes, 0, stream, &rc, true, amax, 2 * n_layers);
+        if (rc != AUGCL_OK) return rc;
+        x3_prepare(wB, n_layers, 0, (char *)frag_ws, frag_ws_bytes, setB, stream, &rc, true);
+        if (rc != AUGCL_OK) return rc;
     }
     rc = augcl::conv_first9_try(x, wA[0], bA[0], acts_out[0], B2, C, H, W, first_stride, scale, 1, precision == 1,
                                 (hipStream_t)stream, name, wB[0], bB[0], x2 ? amax : nullptr);
     if (rc > 0) return augcl::fail(AUGCL_E_UNSUPPORTED, "%s: first-layer shape (%d,%d,%d) stride %d not covered", name, C, H, W, first_stride);
     if (rc != AUGCL_OK) return rc;
     int h = out_hw(H, first_stride), ww = out_hw(W, first_stride);
-    size_t fblock = 0;
-    const size_t setB = (size_t)(n_layers - 1) * augcl_enc_frag_workspace_bytes(1, 1); // set B's blocks follow set A's
-    if ((precision == 2 || x2) && frag_ws_bytes >= 2 * setB) {
-        fblock = x3_prepare(wA, n_layers, 0, (char *)frag_ws, frag_ws_bytes, 0, stream, &rc, x2);
+    if (precision == 2 && frag_ws_bytes >= 2 * setB) {
+        fblock = x3_prepare(wA, n_layers, 0, (char *)frag_ws, frag_ws_bytes, 0, stream, &rc);
         if (rc != AUGCL_OK) return rc;
         if (fblock) {
-            x3_prepare(wB, n_layers, 0, (char *)frag_ws, frag_ws_bytes, setB, stream, &rc, x2);
+            x3_prepare(wB, n_layers, 0, (char *)frag_ws, frag_ws_bytes, setB, stream, &rc);
             if (rc != AUGCL_OK) return rc;
         }
     }
@@ -247,7 +251,7 @@ int augcl_enc_stack_forward_dual(const float *x, const float *const *wA, const f
             rc = augcl_internal_x2_conv32_forward((const float *)acts_out[i - 1], bA[i], bB[i], (float *)acts_out[i], B2, h, ww, relu,
                                                   (char *)frag_ws + (size_t)(i - 1) * fblock,
                                                   (char *)frag_ws + setB + (size_t)(i - 1) * fblock, amax + 2 * (i - 1),
-                                                  last ? nullptr : amax + 2 * i, stream);
+                                                  last ? nullptr : amax + 2 * i, nullptr, stream);
             if (rc > 0) { // shape not covered: the split-bf16 kernel, then the two halves' maxima
                 rc = augcl_internal_x3_conv32_forward((const float *)acts_out[i - 1], wA[i], bA[i], wB[i], bB[i], (float *)acts_out[i],
                                                       B2, h, ww, relu, nullptr, nullptr, stream);
@@ -274,7 +278,9 @@ int augcl_enc_stack_backward(const void *const *acts_in, const float *const *w, 
                              size_t ws_first_bytes, int n_layers, int B, int C, int H, int W, int first_stride,
                              float scale, int precision, int bf16_wgrad_mfma, void *frag_ws, size_t frag_ws_bytes,
                              const float *amax_acts /* precision 3: the forward pass's amax */,
-                             float *amax_dz /* precision 3: n_layers floats of scratch */, augcl_stream_t stream)
+                             float *amax_dz /* precision 3: n_layers floats of scratch */,
+                             const void *const *gate_bits /* precision 3: the forward pass's gate bits, or null */,
+                             augcl_stream_t stream)
 {
     const char *name = "augcl_enc_stack_backward";
     AUGCL_REQUIRE(acts_in && w && grad_out && dw && db && dz_a && dz_b && n_layers >= 1, "augcl_enc_stack_backward: bad argument");
@@ -301,12 +307,11 @@ int augcl_enc_stack_backward(const void *const *acts_in, const float *const *w, 
         AUGCL_REQUIRE(amax_dz != nullptr, "%s: precision 3 needs the amax_dz scratch", name);
     }
     if (precision == 2 || x2) { // backward-data fragments (transposed weights, flipped taps) of every 32 -> 32 layer: one launch
-        fblock = x3_prepare(w, n_layers, 1, (char *)frag_ws, frag_ws_bytes, 0, stream, &rc, x2);
+        fblock = x3_prepare(w, n_layers, 1, (char *)frag_ws, frag_ws_bytes, 0, stream, &rc, x2, x2 ? amax_dz : nullptr, n_layers);
         if (rc != AUGCL_OK) return rc;
     }
-    if (x2) { // amax_dz[i] = max |gradient w.r.t. the output of layer i|: the top one by a reduction, the others by the kernels
-        hipError_t e = hipMemsetAsync(amax_dz, 0, (size_t)n_layers * sizeof(float), (hipStream_t)stream);
-        if (e != hipSuccess) return augcl::fail(AUGCL_E_LAUNCH, "%s: memset: %s", name, hipGetErrorString(e));
+    if (x2) { // amax_dz[i] = max |gradient w.r.t. the output of layer i| (zeroed by the preparation launch): the top one by a
+              // reduction, the others by the kernels
         rc = augcl_internal_amax_f32(grad_out, (size_t)B * 32 * hs[n_layers] * wsz[n_layers], amax_dz + n_layers - 1, stream);
         if (rc != AUGCL_OK) return rc;
     }
@@ -346,9 +351,11 @@ int augcl_enc_stack_backward(const void *const *acts_in, const float *const *w, 
                                                         wsz[i + 1], fblock ? (char *)frag_ws + (size_t)(i - 1) * fblock : nullptr, stream);
         else if (precision == 3) {
             // (the gradient that reaches the first layer's backward-weights needs no maximum: that kernel reads float32)
+            // gate: the bit map the forward pass left for acts_in[i] (= the output of layer i - 1), else acts_in[i] itself
             rc = augcl_internal_x2_conv32_backward_data((const float *)dz, (const float *)acts_in[i], (float *)nxt, B, hs[i + 1],
                                                         wsz[i + 1], (char *)frag_ws + (size_t)(i - 1) * fblock, amax_dz + i,
-                                                        i > 1 ? amax_dz + i - 1 : nullptr, stream);
+                                                        i > 1 ? amax_dz + i - 1 : nullptr, gate_bits ? gate_bits[i - 1] : nullptr,
+                                                        stream);
             if (rc > 0) {
                 rc = augcl_enc_x3_conv32_backward_data((const float *)dz, w[i], (const float *)acts_in[i], (float *)nxt, B, hs[i + 1],
                                                        wsz[i + 1], stream);

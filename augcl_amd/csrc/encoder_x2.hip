@@ -26,6 +26,7 @@
 #include "augcl_common.h"
 
 #include <algorithm>
+#include <type_traits>
 
 namespace augcl {
 
@@ -41,8 +42,9 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 constexpr int X2_SLOT = 144;       // LDS bytes per pixel slot: 2 planes x 64 B + 16 B pad (36 p mod 64 dwords: 16 consecutive
                                    // pixels x one 16-byte chunk fall into 16 distinct bank quads)
 constexpr int X2_NU = 2;           // loader rounds per strip: 256 lanes x X2_NU units of (4 pixels x 8 channels)
-constexpr int X2_MAXTILE = 81664;  // bytes per tile buffer: 2 x this + 512 <= 160 KiB
-constexpr int X2_HDR = 512;        // LDS in front of the tiles: +-bias (2 x 128 B), spare
+constexpr int X2_WLF = 18 * 64 * 16; // the weights' lo' fragments: [18 operands][64 lanes] x 16 B (the hi parts stay in registers)
+constexpr int X2_HDR = 512 + X2_WLF; // LDS in front of the tiles: +-bias (2 x 128 B), the maximum's two words, spare, lo' fragments
+constexpr int X2_MAXTILE = 72448;  // bytes per tile buffer: 2 x this + X2_HDR <= 160 KiB (503 pixel slots; a strip's loads cover 512)
 constexpr int X2_FRAG_VU4 = 2 * 18 * 64; // 16-byte entries per layer block, then one entry whose first word is the weights' exponent
 constexpr int X2_BLOCK_BYTES = 55296;    // stride of the per-layer blocks in frag_ws (= the split-bf16 kernels' block: one size function)
 
@@ -97,6 +99,8 @@ struct ConvX2Args {
     const vu4 *wfrag, *wfrag2; // prepared by k_x2_prep: [hi | lo'][18 operands][64 lanes] x 16 B, then the exponent
     const uint32_t *amax_in;   // max |in| (float bits); dual: [0] first half, [1] second half
     uint32_t *amax_out;        // max |out| is atomically max-ed into it (zeroed by the caller), or null; dual: [0], [1]
+    uint32_t *bits;            // ReLU gate bits, one word per pixel (B,Ho,Wo), bit c = (channel c of that pixel > 0): MODE 0 writes
+                               // them for its output (or null), MODE 1 with GATE = 1 reads them instead of the float mask
     int abl;                   // tuning builds only: ablation bits (tools/x2_bench.py)
 };
 
@@ -108,7 +112,9 @@ __device__ unsigned long long g_x2_clk[4];
 // MODE 0: forward (valid 3x3).  MODE 1: backward-data = full correlation of dZ with the flipped, transposed weights; its
 // LDS tile keeps every dZ row with 2 zero pixels in front (which double as the 2 behind the previous row) and zero rows
 // outside the image, so no tap needs masking.
-template <int MODE>
+// GATE (MODE 1): 0 = the ReLU gate is the sign of the float mask (or there is none), 16 dword loads per tile and lane;
+// 1 = the gate bits the forward pass left (ONE dword per tile and lane, 1/32 of the mask's bytes).
+template <int MODE, int GATE>
 __global__ __launch_bounds__(512, 2) void k_conv32_x2(ConvX2Args a)
 {
     extern __shared__ __attribute__((aligned(16))) char ldsx[];
@@ -123,6 +129,7 @@ __global__ __launch_bounds__(512, 2) void k_conv32_x2(ConvX2Args a)
     const int tilepix = (a.RT + 2) * Wl + (MODE ? 2 : 0);
     const int bufbytes = tilepix * X2_SLOT;
     float *lbias = reinterpret_cast<float *>(ldsx);        // [0..32) +bias s_in s_w, [32..64) the same negated
+    char *wlf = ldsx + 512;
     char *tiles = ldsx + X2_HDR;
     const int grp = a.dual ? (int)(blockIdx.x & 1) : 0, nhalf = a.n_items >> 1;
     const int first = a.dual ? grp * nhalf + (int)(blockIdx.x >> 1) : xcd_slot((int)blockIdx.x, (int)gridDim.x);
@@ -281,12 +288,13 @@ __global__ __launch_bounds__(512, 2) void k_conv32_x2(ConvX2Args a)
     }
 
     // ---- compute waves.  Operand i = (tap t = i / 2, channel half s = i & 1); A fragment: W_eff[row l31][k = 16 s + 8 h + j][t],
-    // hi and lo' parts in registers for the whole launch (36 coalesced 16-byte loads per lane).
-    f16x8 wh[18], wl[18];
+    // the hi parts live in registers for the whole launch (72 VGPRs), the lo' parts (one of the three products) in LDS: with
+    // both resident the two accumulator sets below would not fit the 256 registers of a wave.
+    f16x8 wh[18];
 #pragma unroll
     for (int i = 0; i < 18; ++i) {
         wh[i] = __builtin_bit_cast(f16x8, wfrag[i * 64 + lane]);
-        wl[i] = __builtin_bit_cast(f16x8, wfrag[(18 + i) * 64 + lane]);
+        if ((i & 3) == cw) *reinterpret_cast<vu4 *>(wlf + (i * 64 + lane) * 16) = wfrag[(18 + i) * 64 + lane]; // each wave a quarter
     }
     const int rowb = Wl * X2_SLOT; // LDS bytes between tile rows
     const int relu_floor = __builtin_amdgcn_readfirstlane(a.relu ? 0 : (int)0x80000000); // opaque: stays ONE v_max_i32
@@ -294,18 +302,69 @@ __global__ __launch_bounds__(512, 2) void k_conv32_x2(ConvX2Args a)
     // beyond it (kNoStore): the hardware drops the store and the epilogue needs no branch
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)((unsigned)(a.B * 32 * a.Ho * a.Wo) * 4u), 0x00020000);
     constexpr unsigned kNoStore = 0xfffffff0u;
-    const __amdgpu_buffer_rsrc_t rs_mask =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(MODE == 1 && a.mask ? a.mask : a.in), 0, -1, 0x00020000);
+    // backward-data gates: the layer input at the addresses this lane stores to, passed when its bits are >= gate_floor = 1
+    // (a positive float).  Without a mask the floor is INT_MIN -- everything passes -- and the loads read the output tensor
+    // itself (valid memory, value irrelevant): one code path, no branch on the pointer in the hot loop.
+    const __amdgpu_buffer_rsrc_t rs_mask = __builtin_amdgcn_make_buffer_rsrc(
+        MODE == 1 && a.mask ? const_cast<float *>(a.mask) : a.out, 0, (int)((unsigned)(a.B * 32 * a.Ho * a.Wo) * 4u), 0x00020000);
+    const int gate_floor = __builtin_amdgcn_readfirstlane(a.mask ? 1 : (int)0x80000000);
+    // the gate bits (a null pointer gives an empty resource: MODE 0's stores are dropped, nothing branches)
+    const __amdgpu_buffer_rsrc_t rs_bits = __builtin_amdgcn_make_buffer_rsrc(
+        a.bits ? a.bits : reinterpret_cast<uint32_t *>(a.out), 0, a.bits ? (int)((unsigned)(a.B * a.Ho * a.Wo) * 4u) : 0, 0x00020000);
+    const unsigned hoff = (unsigned)(16 * h) * (unsigned)(a.Ho * a.Wo); // boff - hoff - (the image's 31 planes) = the pixel's byte in the bit map
     const int chw = a.Ho * a.Wo; // 32-bit offsets: the host checks B*32*Ho*Wo < 2^30
     const float un_in = pow2f(-k_in), un_w = pow2f(-k_w); // two exact factors (their product may leave float32's range)
 
-    float res[16];             // the previous tile's results (bias, ReLU / gate applied)
-    unsigned pboff = kNoStore; // ... and this lane's byte offset for them
+    // TWO accumulator sets: while a tile's MFMAs run on one, the previous tile's 16 output rows are finished from the other --
+    // un-scale, ReLU / gate, maximum, store -- one row in the shadow of each of the first 16 operand groups (also across the
+    // strip's barrier).  Bunched behind the tile the ~100 vector instructions kept the matrix pipe idle for a tenth of it.
+    f32x16 accs[2], accxs[2]; // main product (seeded with the bias) / the two cross products (x 2^-11 at the end)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accs[0][r] = accs[1][r] = accxs[0][r] = accxs[1][r] = 0.0f;
+    unsigned pboff = kNoStore; // the pending tile: this lane's output byte offset (kNoStore: nothing to store),
+    unsigned pgoff = 0u;       // ... the same offset for its gate loads (always a real pixel's),
+    float pun = 0.0f;          // ... its un-scale factor 2^-k_in with its strip's sign
+    int par = 0;               // the set the NEXT tile accumulates into (the pending tile sits in the other one)
     float vmax = 0.0f;         // max |result| of this lane (a lane past the strip's end repeats a real pixel: harmless)
-    auto store_row = [&](int r) {
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, res[r]), rs_out, pboff,
-                                              (unsigned)(((r & 3) + 8 * (r >> 2)) * chw) * 4u, 0);
+    constexpr int GR = 4;      // float-mask gates in flight (row r in slot r % GR; GR must divide 16)
+    float gq[GR];
+    unsigned ppix = 0u;        // the pending tile's byte in the bit map
+    uint32_t gbits = 0u;       // MODE 0: the pending tile's gate bits so far;  MODE 1 / GATE 1: the pending tile's gate word
+    uint32_t gnext = 0u;       // MODE 1 / GATE 1: the gate word of the tile being accumulated
+    auto rowoff = [&](int r) { return (unsigned)(((r & 3) + 8 * (r >> 2)) * chw) * 4u; };
+    auto gload = [&](unsigned goff, int r) {
+        if (MODE == 1 && GATE == 0)
+            gq[r % GR] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_mask, goff, rowoff(r), 0));
     };
+    auto finish_row = [&](auto PSETC, int r) {
+        constexpr int PSET = decltype(PSETC)::value;
+        float v = __builtin_fmaf(accxs[PSET][r], 1.0f / 2048.0f, accs[PSET][r]) * pun * un_w;
+        const int co = (r & 3) + 8 * (r >> 2); // (+ 4 h: this lane's 16 channels are co and co + 4 of every group of 8)
+        if (MODE == 0) {
+            v = __int_as_float(max(__float_as_int(v), relu_floor));
+            // v >= +0 here whenever the bits are kept (ReLU layers): positive <=> its bit pattern is >= 1.  Three integer
+            // instructions; the compare-and-select form cost six more registers than this kernel has
+            gbits = (((__float_as_uint(v) + 0x7fffffffu) >> 31) << co) | gbits;
+        } else if (GATE == 1) { // bit co + 4 h of the pixel's word (shifted down by 4 h when it was fetched), spread over all 32 bits
+            v = __uint_as_float(__float_as_uint(v) & (uint32_t)__builtin_amdgcn_sbfe((int)gbits, co, 1));
+        } else {
+            v = __float_as_int(gq[r % GR]) >= gate_floor ? v : 0.0f;
+        }
+        vmax = fmaxf(vmax, fabsf(v));
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_out, pboff, rowoff(r), 0);
+    };
+    // MODE 0, after the pending tile's last row: its two half-waves hold channels {0-3, 8-11, ...} and {4-7, 12-15, ...} of the
+    // same 32 pixels; the lower half stores the pixel's word (a lane with nothing to store names an offset beyond the map)
+    auto finish_bits = [&]() {
+        if (MODE == 0) {
+            const uint32_t mine = gbits << (4 * h);
+            const uint32_t word = mine | (uint32_t)__shfl_xor((int)mine, 32, 64);
+            __builtin_amdgcn_raw_buffer_store_b32(word, rs_bits, (h == 0 && pboff != kNoStore) ? ppix : kNoStore, 0, 0);
+            gbits = 0u;
+        }
+    };
+    typedef std::integral_constant<int, 0> Set0;
+    typedef std::integral_constant<int, 1> Set1;
     auto compute = [&](int item, int bi) {
         const int b = a.S == 1 ? item : (int)__umulhi((uint32_t)item, a.magic_s), s = item - b * a.S;
         const int y0 = s * a.RT;
@@ -318,6 +377,7 @@ __global__ __launch_bounds__(512, 2) void k_conv32_x2(ConvX2Args a)
         if (a.abl & 1) return; // ablation: the loaders alone
 #endif
         const float un0 = bi ? -un_in : un_in; // this strip's pixels were scaled by -s
+        const unsigned img31 = (unsigned)(b * 31) * (unsigned)chw * 4u; // the 31 other planes of the images in front of this one
         auto locate = [&](int tl, bool &valid_, int &off_, unsigned &boff_) {
             int m_ = tl * 32 + l31;
             valid_ = m_ < npix;
@@ -327,32 +387,26 @@ __global__ __launch_bounds__(512, 2) void k_conv32_x2(ConvX2Args a)
             boff_ = (unsigned)((b * 32 * a.Ho + (y0 + yy_)) * a.Wo + xx_ + 4 * h * chw) * 4u;
         };
         struct Ops {
-            vu4 xh, xl;
+            vu4 xh, xl, wl;
         };
-        auto rd1 = [&](int off_, int i, Ops &o, int part) { // one of the operand's two reads: row base + immediate
+        auto rd1 = [&](int off_, int i, Ops &o, int part) { // one of the operand's three reads: row base + immediate
             const int t = i >> 1;
             const char *p = tile + off_ + (t / 3) * rowb + ((t % 3) * X2_SLOT + (i & 1) * 32);
             if (part == 0) o.xh = *reinterpret_cast<const vu4 *>(p);
-            else o.xl = *reinterpret_cast<const vu4 *>(p + 64);
+            else if (part == 1) o.xl = *reinterpret_cast<const vu4 *>(p + 64);
+            else o.wl = *reinterpret_cast<const vu4 *>(wlf + (i * 64 + lane) * 16);
         };
         bool valid;
         int off;
         unsigned boff;
         locate(cw, valid, off, boff);
-        // backward-data: this lane's 16 ReLU gates (the layer input at the addresses it will store to).  Row r of the previous
-        // tile is stored and gate r of the CURRENT tile requested in the same slot of the MFMA stream (the result register the
-        // store frees is the one the gate lands in), two rows per operand group over the first eight groups.
-        float gv[16];
-        auto side_row = [&](int r) {
-            store_row(r);
-            if (a.mask != nullptr)
-                gv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                      rs_mask, boff, (unsigned)(((r & 3) + 8 * (r >> 2)) * chw) * 4u, 0));
-        };
         Ops o[3]; // operands i, i + 1, i + 2: reads run two groups (6 MFMAs, ~190 cycles) ahead of their use
-        rd1(off, 0, o[0], 0); rd1(off, 0, o[0], 1);
-        rd1(off, 1, o[1], 0); rd1(off, 1, o[1], 1);
-        for (int tl = cw; tl < ntiles; tl += 4) {
+        rd1(off, 0, o[0], 0); rd1(off, 0, o[0], 2); rd1(off, 0, o[0], 1);
+        rd1(off, 1, o[1], 0); rd1(off, 1, o[1], 2); rd1(off, 1, o[1], 1);
+        // one tile on accumulator set SET; the pending tile (set 1 - SET) is finished in its gaps
+        auto tile_body = [&](auto SETC, int tl) {
+            constexpr int SET = decltype(SETC)::value;
+            typedef std::integral_constant<int, 1 - SET> PSetC;
             bool valid2;
             int off2;
             unsigned boff2;
@@ -360,7 +414,9 @@ __global__ __launch_bounds__(512, 2) void k_conv32_x2(ConvX2Args a)
 #ifdef AUGCL_TUNING
             ++n_tiles;
 #endif
-            f32x16 acc, accx; // main product (seeded with the bias) / the two cross products (x 2^-11 at the end)
+            f32x16 &acc = accs[SET], &accx = accxs[SET];
+            if (MODE == 1 && GATE == 1) // this tile's gate word (this lane's pixel), shifted so that bit co is channel co + 4 h
+                gnext = __builtin_amdgcn_raw_buffer_load_b32(rs_bits, boff - hoff - img31, 0, 0);
             {
                 const float *bsrc = lbias + (bi ? 32 : 0);
 #pragma unroll
@@ -377,41 +433,52 @@ __global__ __launch_bounds__(512, 2) void k_conv32_x2(ConvX2Args a)
                 Ops &cur = o[i % 3];
                 Ops &nn = o[(i + 2) % 3];
                 const int noff = i < 16 ? off : off2, ni = i < 16 ? i + 2 : i - 16; // the operand two groups on (across the tile boundary)
-                // smallest products first: wl' xh, wh xl' (cross), wh xh (main); one LDS read / store / gate load between MFMAs
-                X2_MM(accx, wl[i], cur.xh);
+                // smallest products first: wl' xh, wh xl' (cross), wh xh (main).  Gaps: one LDS read each; the first also finishes
+                // row i of the pending tile.  Backward-data with a float mask: the gate it needs was requested GR groups ago -- the
+                // slot it frees takes the pending tile's row i + GR, then THIS tile's row i + GR - 16 (with gate bits: one word
+                // per tile, requested at the tile's start)
+                X2_MM(accx, __builtin_bit_cast(f16x8, cur.wl), cur.xh);
                 __builtin_amdgcn_sched_barrier(0);
                 rd1(noff, ni, nn, 0);
-                if (MODE == 0 && i < 16) store_row(i);
-                if (MODE == 1 && i < 8) side_row(2 * i);
+                if (i < 16) {
+                    finish_row(PSetC{}, i);
+                    if (i + GR < 16) gload(pgoff, i + GR);
+                    else gload(boff, i + GR - 16); // (GR divides 16: the slot row i frees is the slot of this tile's row i + GR - 16)
+                    if (i == 15) finish_bits();
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 X2_MM(accx, wh[i], cur.xl);
                 __builtin_amdgcn_sched_barrier(0);
-                rd1(noff, ni, nn, 1);
-                if (MODE == 1 && i < 8) side_row(2 * i + 1);
+                rd1(noff, ni, nn, 2);
                 __builtin_amdgcn_sched_barrier(0);
                 X2_MM(acc, wh[i], cur.xh);
                 __builtin_amdgcn_sched_barrier(0);
+                rd1(noff, ni, nn, 1);
+                __builtin_amdgcn_sched_barrier(0);
             }
 #undef X2_MM
-            // rows in accumulator order: co = 0,1,2,3, 8,9,10,11, ... (+4 h in the lane offset)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-#ifdef AUGCL_TUNING
-                if (a.abl & 4) { res[r] = acc[r] + accx[r]; continue; } // ablation: no epilogue arithmetic
-#endif
-                float v = __builtin_fmaf(accx[r], 1.0f / 2048.0f, acc[r]) * un0 * un_w;
-                if (MODE == 0) v = __int_as_float(max(__float_as_int(v), relu_floor));
-                else if (a.mask != nullptr) v = gv[r] > 0.0f ? v : 0.0f;
-                vmax = fmaxf(vmax, fabsf(v));
-                res[r] = v;
-            }
-            pboff = valid ? boff : kNoStore;
-#ifdef AUGCL_TUNING
-            if ((a.abl & 8) && res[0] != 12345.678f) pboff = kNoStore; // ablation: no output stores
-#endif
+            pboff = valid ? boff : kNoStore; // this tile is the pending one now
+            pgoff = boff;
+            ppix = boff - hoff - img31;
+            if (MODE == 1 && GATE == 1) gbits = gnext >> (4 * h);
+            pun = un0;
             // (18 = 6 x 3: the next tile's operands 0 and 1 sit in o[0], o[1] again)
             valid = valid2; off = off2; boff = boff2;
+        };
+        // the wave's tiles alternate between the sets; which one comes first is only known at run time (it continues from
+        // the previous strip), so the loop exists in both phases
+        if (par == 0) {
+            for (int tl = cw; tl < ntiles; tl += 8) {
+                tile_body(Set0{}, tl);
+                if (tl + 4 < ntiles) tile_body(Set1{}, tl + 4);
+            }
+        } else {
+            for (int tl = cw; tl < ntiles; tl += 8) {
+                tile_body(Set1{}, tl);
+                if (tl + 4 < ntiles) tile_body(Set0{}, tl + 4);
+            }
         }
+        par ^= ((ntiles - cw + 3) >> 2) & 1;
     };
     __syncthreads();
     for (int item = first; item < n; item += 2 * NG) {
@@ -421,8 +488,22 @@ __global__ __launch_bounds__(512, 2) void k_conv32_x2(ConvX2Args a)
         compute(item + NG, 1);
         __syncthreads();
     }
+    // the last tile's results
+    if (par == 1) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) store_row(r); // the last tile's results
+        for (int r = 0; r < 16; ++r) {
+            if (r >= GR) gload(pgoff, r);
+            finish_row(Set0{}, r);
+        }
+        finish_bits();
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (r >= GR) gload(pgoff, r);
+            finish_row(Set1{}, r);
+        }
+        finish_bits();
+    }
 #ifdef AUGCL_TUNING
     if (blockIdx.x == 0 && wave == 0 && lane == 0) {
         g_x2_clk[0] = __builtin_amdgcn_s_memtime() - t_start;
@@ -692,6 +773,8 @@ struct PrepX2Args {
     const float *w[32]; // (32,32,3,3) weights of the layers to prepare
     char *out;          // [n] blocks of X2_BLOCK_BYTES
     int mode;           // 0: forward fragments, 1: backward-data (transposed, flipped taps)
+    uint32_t *zero;     // the pass's per-tensor maxima: zeroed here (one launch fewer than a memset), or null
+    int n_zero;
 };
 
 __global__ __launch_bounds__(256) void k_x2_prep(PrepX2Args a)
@@ -734,6 +817,8 @@ __global__ __launch_bounds__(256) void k_x2_prep(PrepX2Args a)
     o[i * 64 + lane] = fh;
     o[(18 + i) * 64 + lane] = fl;
     if (i == 0 && lane == 0) o[X2_FRAG_VU4] = vu4{(uint32_t)k_w, 0u, 0u, 0u};
+    if (i == 1 && blockIdx.y == 0 && a.zero != nullptr)
+        for (int j = lane; j < a.n_zero; j += 64) a.zero[j] = 0u;
 }
 
 // max |x| of a tensor, atomically max-ed into *out (float bits; zeroed by the caller): the gradient that enters the stack
@@ -757,6 +842,20 @@ __global__ __launch_bounds__(1024) void k_amax_f32(const float *x, size_t n4, si
     if (threadIdx.x == 0) atomicMax(out, red); // one global atomic per block (same-address atomics serialise at ~12 ns each)
 }
 
+// gate bits of a tensor no kernel of this path produced (a layer that fell back to another kernel): word (b, y, x) bit c =
+// x[b][c][y][x] > 0; one thread per pixel, 32 coalesced plane reads
+__global__ __launch_bounds__(256) void k_gate_bits(const float *x, uint32_t *bits, int B, int HW)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)B * HW) return;
+    const size_t b = i / HW, p = i - b * HW;
+    const float *src = x + b * 32 * HW + p;
+    uint32_t w = 0u;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) w |= src[(size_t)c * HW] > 0.0f ? (1u << c) : 0u;
+    bits[i] = w;
+}
+
 } // namespace augcl
 
 using namespace augcl;
@@ -774,7 +873,7 @@ int cu_count_x2()
 }
 
 // +1: the shape is outside what these kernels cover (the caller runs the split-bf16 kernel, which has its own fallback)
-template <int MODE>
+template <int MODE, int GATE>
 int launch_conv_x2(ConvX2Args &a, const char *name, hipStream_t s)
 {
     const int Wi = a.Wi;
@@ -811,16 +910,16 @@ int launch_conv_x2(ConvX2Args &a, const char *name, hipStream_t s)
     a.magic_s = (uint32_t)(0x100000000ull / (unsigned)a.S) + 1u; // S == 1 wraps to 1: handled in the kernel
     const int tilepix = (a.RT + 2) * Wl + (MODE ? 2 : 0);
     const size_t lds = (size_t)X2_HDR + 2 * (size_t)tilepix * X2_SLOT;
-    if (lds > 160 * 1024) return 1;
+    if (lds > 160 * 1024) return 1; // (cannot happen: rt is bounded by X2_MAXTILE)
 #ifdef AUGCL_TUNING
     a.abl = getenv("AUGCL_X2_ABL") ? atoi(getenv("AUGCL_X2_ABL")) : 0;
 #endif
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv32_x2<MODE>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv32_x2<MODE, GATE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return augcl::fail(AUGCL_E_LAUNCH, "%s: cannot set dynamic LDS %zu: %s", name, lds, hipGetErrorString(e));
     int grid = a.n_items < cus ? a.n_items : cus;
     if (a.dual) grid &= ~1; // even / odd workgroups serve the two halves
-    hipLaunchKernelGGL((k_conv32_x2<MODE>), dim3(grid), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((k_conv32_x2<MODE, GATE>), dim3(grid), dim3(512), lds, s, a);
     return augcl::check_launch(name);
 }
 
@@ -837,8 +936,10 @@ int augcl_tuning_x2_read_clk(unsigned long long *out4)
 
 // ---- internal entry points (encoder_stack.cpp, precision 3).  All return +1 when the shape is not covered. ----
 
-// fragments of n (<= 32) 32 -> 32 layers into out (blocks of augcl_enc_frag_workspace_bytes(1, 1)): ONE launch
-int augcl_internal_x2_prep_weights(const float *const *w, int n, int mode, void *out, augcl_stream_t stream)
+// fragments of n (<= 32) 32 -> 32 layers into out (blocks of augcl_enc_frag_workspace_bytes(1, 1)): ONE launch, which also
+// zeroes n_zero floats at `zero` (the pass's maxima; null: nothing)
+int augcl_internal_x2_prep_weights(const float *const *w, int n, int mode, void *out, float *zero, int n_zero,
+                                   augcl_stream_t stream)
 {
     const char *name = "augcl_internal_x2_prep_weights";
     AUGCL_REQUIRE(w && out && n >= 1 && n <= 32 && (mode == 0 || mode == 1) && aligned16(out), "%s: bad argument", name);
@@ -850,7 +951,19 @@ int augcl_internal_x2_prep_weights(const float *const *w, int n, int mode, void 
     }
     a.out = reinterpret_cast<char *>(out);
     a.mode = mode;
+    a.zero = reinterpret_cast<uint32_t *>(zero);
+    a.n_zero = zero ? n_zero : 0;
     hipLaunchKernelGGL(k_x2_prep, dim3(5, n), dim3(256), 0, as_stream(stream), a);
+    return augcl::check_launch(name);
+}
+
+int augcl_internal_gate_bits(const float *x, void *bits, int B, int H, int W, augcl_stream_t stream)
+{
+    const char *name = "augcl_internal_gate_bits";
+    AUGCL_REQUIRE(x && bits && B >= 1 && H >= 1 && W >= 1, "%s: bad argument", name);
+    const size_t n = (size_t)B * H * W;
+    hipLaunchKernelGGL(k_gate_bits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), x,
+                       reinterpret_cast<uint32_t *>(bits), B, H * W);
     return augcl::check_launch(name);
 }
 
@@ -868,7 +981,7 @@ int augcl_internal_amax_f32(const float *x, size_t n, float *out, augcl_stream_t
 // amax_in / amax_out: one float (two when dual)
 int augcl_internal_x2_conv32_forward(const float *in, const float *bias, const float *bias2, float *out, int B, int Hi, int Wi,
                                      int relu, const void *wfrag, const void *wfrag2, const float *amax_in, float *amax_out,
-                                     augcl_stream_t stream)
+                                     void *gate_bits_out, augcl_stream_t stream)
 {
     const char *name = wfrag2 ? "augcl_enc_stack_forward_dual" : "augcl_enc_stack_forward";
     AUGCL_REQUIRE(B >= 0 && Hi >= 3 && Wi >= 3, "%s: bad shape", name);
@@ -884,12 +997,15 @@ int augcl_internal_x2_conv32_forward(const float *in, const float *bias, const f
     a.wfrag2 = reinterpret_cast<const vu4 *>(wfrag2);
     a.amax_in = reinterpret_cast<const uint32_t *>(amax_in);
     a.amax_out = reinterpret_cast<uint32_t *>(amax_out);
+    a.bits = reinterpret_cast<uint32_t *>(gate_bits_out);
     a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ho = Hi - 2; a.Wo = Wi - 2; a.relu = relu;
-    return launch_conv_x2<0>(a, name, as_stream(stream));
+    return launch_conv_x2<0, 0>(a, name, as_stream(stream));
 }
 
+// gate_bits != null: the ReLU gate comes from the bit map the forward pass left for act_prev (act_prev itself is not read)
 int augcl_internal_x2_conv32_backward_data(const float *dz, const float *act_prev, float *dact, int B, int Ho, int Wo,
-                                           const void *wfrag, const float *amax_in, float *amax_out, augcl_stream_t stream)
+                                           const void *wfrag, const float *amax_in, float *amax_out, const void *gate_bits,
+                                           augcl_stream_t stream)
 {
     const char *name = "augcl_enc_stack_backward";
     AUGCL_REQUIRE(B >= 0 && Ho >= 1 && Wo >= 1, "%s: bad shape", name);
@@ -902,8 +1018,9 @@ int augcl_internal_x2_conv32_backward_data(const float *dz, const float *act_pre
     a.wfrag = reinterpret_cast<const vu4 *>(wfrag);
     a.amax_in = reinterpret_cast<const uint32_t *>(amax_in);
     a.amax_out = reinterpret_cast<uint32_t *>(amax_out);
+    a.bits = reinterpret_cast<uint32_t *>(const_cast<void *>(gate_bits));
     a.B = B; a.Hi = Ho; a.Wi = Wo; a.Ho = Ho + 2; a.Wo = Wo + 2; a.relu = 0;
-    return launch_conv_x2<1>(a, name, as_stream(stream));
+    return gate_bits ? launch_conv_x2<1, 1>(a, name, as_stream(stream)) : launch_conv_x2<1, 0>(a, name, as_stream(stream));
 }
 
 int augcl_internal_x2_conv32_backward_weights(const float *act_prev, const float *dz, float *dw, float *db, float *workspace,

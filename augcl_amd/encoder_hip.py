@@ -199,14 +199,23 @@ class ConvStackFn(torch.autograd.Function):
         al = 8  # elements: keeps every slice 16-byte aligned in both element types
         tail = _AMAX if precision == "f32" else 0  # the per-tensor maxima live behind the activations (the backward reads them)
         assert n_layers <= _AMAX
+        bits = None
         if need_grad:  # one arena holds every intermediate activation
             offs, tot = [], 0
             for n in numel[:-1]:
                 offs.append(tot)
                 tot += (n + al - 1) // al * al
             tot = max(tot, al)
+            if tail:  # ... and, behind the maxima, one gate word per pixel of every intermediate activation (backward-data's ReLU gate)
+                boffs, btot = [], 0
+                for h, w_ in zip(hs[:-1], wsz[:-1]):
+                    boffs.append(btot)
+                    btot += (B * h * w_ + 3) // 4 * 4
+                tail += btot
             arena = torch.empty(tot + tail, dtype=adt, device=dev)
             ptrs = [arena.data_ptr() + o * arena.element_size() for o in offs]
+            if tail:
+                bits = _ptr_array([arena.data_ptr() + (tot + _AMAX + o) * 4 for o in boffs] + [None])
         else:  # two ping-pong buffers
             big = (max(numel[:-1], default=al) + al - 1) // al * al
             tot = 2 * big
@@ -217,16 +226,16 @@ class ConvStackFn(torch.autograd.Function):
         fws = _frag_ws(dev, n_layers - 1) if precision in _SPLIT and n_layers > 1 else None
         _lib.call("augcl_enc_stack_forward", x.data_ptr(), _ptr_array([t.data_ptr() for t in weights]),
                   _ptr_array([t.data_ptr() for t in biases]), _ptr_array(ptrs), n_layers, B, C, H, W, first_stride,
-                  input_scale, PRECISION_CODE[precision], _lib.ptr(fws), fws.numel() if fws is not None else 0, amax,
+                  input_scale, PRECISION_CODE[precision], _lib.ptr(fws), fws.numel() if fws is not None else 0, amax, bits,
                   _lib.current_stream(dev))
         if need_grad:
             ctx.save_for_backward(x, arena, *weights)
-            ctx.meta = (first_stride, input_scale, precision, n_layers, ptrs[:-1], max(numel), amax)
+            ctx.meta = (first_stride, input_scale, precision, n_layers, ptrs[:-1], max(numel), amax, bits)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        first_stride, input_scale, precision, n_layers, act_ptrs, max_numel, amax = ctx.meta
+        first_stride, input_scale, precision, n_layers, act_ptrs, max_numel, amax, bits = ctx.meta
         x, arena = ctx.saved_tensors[:2]
         weights = ctx.saved_tensors[2:]
         B, C, H, W = x.shape
@@ -245,6 +254,6 @@ class ConvStackFn(torch.autograd.Function):
                   _ptr_array([dbs[i].data_ptr() for i in range(n_layers)]), dz.data_ptr(), dz.data_ptr() + half,
                   ws32.data_ptr(), ws32.numel() * 4, wsf.data_ptr(), wsf.numel() * 4, n_layers, B, C, H, W, first_stride,
                   input_scale, PRECISION_CODE[precision], 1 if _BF16_WGRAD.endswith("_mfma") else 0, _lib.ptr(fws),
-                  fws.numel() if fws is not None else 0, amax, dz.data_ptr() + 2 * half if amax else None,
+                  fws.numel() if fws is not None else 0, amax, dz.data_ptr() + 2 * half if amax else None, bits,
                   _lib.current_stream(dev))
         return (None, None, None, None, None, *dws, *[dbs[i] for i in range(n_layers)])

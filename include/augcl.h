@@ -373,16 +373,20 @@ int augcl_enc_nchw_f32_to_nhwc_bf16(const float *in, void *out_bf16_nhwc, int B,
  * amax (precision 3; NULL otherwise): n_layers floats (2 n_layers for the dual forward) on the device.  The forward pass
  * leaves amax[i] = max |output of layer i| there (each kernel's epilogue takes the maximum of what it stores); the
  * backward pass of the same activations must be given the same values (amax_acts) plus n_layers floats of scratch
- * (amax_dz) for the gradients' maxima. */
+ * (amax_dz) for the gradients' maxima.
+ * gate_bits (precision 3; may be NULL, and so may any entry): n_layers device pointers; gate_bits[i] receives one 32-bit word
+ * per pixel of layer i's output (B x h_i x w_i words), bit c = (channel c > 0) -- the ReLU gate of the NEXT layer's
+ * backward-data, 1/32 of the activation's bytes.  Given the same array, the backward pass reads the bits instead of the
+ * activations wherever an entry is non-NULL (an entry the forward pass did not fill must be NULL there). */
 size_t augcl_enc_frag_workspace_bytes(int n_layers32, int weight_sets);
 int augcl_enc_stack_forward(const float *x, const float *const *w, const float *const *b, void *const *acts_out,
                             int n_layers, int B, int C, int H, int W, int first_stride, float scale, int precision,
-                            void *frag_ws, size_t frag_ws_bytes, float *amax, augcl_stream_t stream);
+                            void *frag_ws, size_t frag_ws_bytes, float *amax, void *const *gate_bits, augcl_stream_t stream);
 int augcl_enc_stack_backward(const void *const *acts_in, const float *const *w, const float *grad_out, float *const *dw,
                              float *const *db, void *dz_a, void *dz_b, float *ws32, size_t ws32_bytes, float *ws_first,
                              size_t ws_first_bytes, int n_layers, int B, int C, int H, int W, int first_stride,
                              float scale, int precision, int bf16_wgrad_mfma, void *frag_ws, size_t frag_ws_bytes,
-                             const float *amax_acts, float *amax_dz, augcl_stream_t stream);
+                             const float *amax_acts, float *amax_dz, const void *const *gate_bits, augcl_stream_t stream);
 
 /* Two encoders with identical shapes over the SAME input batch in one launch per layer (no-grad passes: the actor's CNN
  * and the target critic's CNN over next_obs, src/algorithms/sac.py:94-101).  acts_out[i] holds 2B images: [0,B) from

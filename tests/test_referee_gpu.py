@@ -135,7 +135,7 @@ def hip_forward(x, ws, bs):
     fws = encoder_hip._frag_ws(x.device, n - 1)
     amax = torch.empty(n, dtype=torch.float32, device=x.device)  # precision "f32": max |output| of every layer
     _lib.call("augcl_enc_stack_forward", x.data_ptr(), _ptrs(ws), _ptrs(bs), _ptrs(acts), n, B, C, H, W, 2, 255.0,
-              encoder_hip.PRECISION_CODE[encoder_ops.PRECISION], fws.data_ptr(), fws.numel(), amax.data_ptr(),
+              encoder_hip.PRECISION_CODE[encoder_ops.PRECISION], fws.data_ptr(), fws.numel(), amax.data_ptr(), None,
               _lib.current_stream(x.device))
     if encoder_ops.PRECISION == "f32":  # the kernels' maxima are the tensors' maxima, exactly
         assert torch.equal(amax[:-1], torch.stack([a.abs().max() for a in acts[:-1]]))
@@ -159,7 +159,7 @@ def hip_backward(x, acts_in, ws, gout):
     _lib.call("augcl_enc_stack_backward", _ptrs(acts_in), _ptrs(ws), gout.data_ptr(), _ptrs(dws), _ptrs(dbs), dz.data_ptr(),
               dz.data_ptr() + 4 * big, ws32.data_ptr(), ws32.numel() * 4, wsf.data_ptr(), wsf.numel() * 4, n, B, C, H, W, 2,
               255.0, encoder_hip.PRECISION_CODE[encoder_ops.PRECISION], 0, _lib.ptr(fws), fws.numel() if x2 else 0,
-              _lib.ptr(amax_acts), _lib.ptr(amax_dz), _lib.current_stream(dev))
+              _lib.ptr(amax_acts), _lib.ptr(amax_dz), None, _lib.current_stream(dev))
     return dws, dbs
 
 
@@ -267,7 +267,7 @@ def test_bf16_encoder_against_f64_referee(cuda):
     hs = [41 - 2 * i for i in range(n)]
     acts = [torch.empty((B, h, h, 32), dtype=torch.bfloat16, device=cuda) for h in hs[:-1]] + [torch.empty((B, 32, 21, 21), device=cuda)]
     _lib.call("augcl_enc_stack_forward", xd.data_ptr(), _ptrs(wd), _ptrs(bd), _ptrs(acts), n, B, 9, 84, 84, 2, 255.0, 1,
-              None, 0, None, _lib.current_stream(cuda))
+              None, 0, None, None, _lib.current_stream(cuda))
     torch.cuda.synchronize()
     fwd = [rel_l2(a.permute(0, 3, 1, 2).float(), torch.relu(z)) for a, z in zip(acts[:-1], pre64)] + [rel_l2(acts[-1], out64)]
     gates_hip = [(a.permute(0, 3, 1, 2) > 0).cpu() for a in acts[:-1]]

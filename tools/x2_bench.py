@@ -31,8 +31,8 @@ dw, db = torch.empty(32, 32, 3, 3, device=dev), torch.empty(32, device=dev)
 frag = torch.empty(2 * L.augcl_enc_frag_workspace_bytes(1, 1), dtype=torch.uint8, device=dev)
 fb = L.augcl_enc_frag_workspace_bytes(1, 1)
 warr = (ctypes.c_void_p * 1)(w.data_ptr())
-chk(L.augcl_internal_x2_prep_weights(warr, 1, 0, p(frag), st), "prep0")
-chk(L.augcl_internal_x2_prep_weights(warr, 1, 1, P(frag.data_ptr() + fb), st), "prep1")
+chk(L.augcl_internal_x2_prep_weights(warr, 1, 0, p(frag), None, 0, st), "prep0")
+chk(L.augcl_internal_x2_prep_weights(warr, 1, 1, P(frag.data_ptr() + fb), None, 0, st), "prep1")
 am = torch.zeros(8, device=dev)
 def amax(t, slot):
     am[slot] = 0
@@ -45,6 +45,9 @@ for H in range(41, 21, -2):
     dz = torch.randn(B, 32, H - 2, H - 2, device=dev) * 1e-3
     dx = torch.empty(B, 32, H, H, device=dev)
     amax(x, 0); amax(dz, 1)
+    gbits = torch.empty(B * H * H, dtype=torch.int32, device=dev)  # gate bits of x (the backward-data mask), as the forward pass of
+    chk(L.augcl_internal_gate_bits(p(x), p(gbits), B, H, H, st), "bits")  # the layer below would have left them
+    ybits = torch.empty(B * (H - 2) * (H - 2), dtype=torch.int32, device=dev)
     row = []
     for kind in ("forward", "backward_data", "backward_weights"):
         for x2 in (False, True):
@@ -55,9 +58,9 @@ for H in range(41, 21, -2):
                 else: fn = lambda: _lib.call(pre + kind, p(x), p(dz), p(dw), p(db), p(ws), ctypes.c_size_t(ws.numel() * 4), B, H, H, st)
             else:
                 if kind == "forward":
-                    fn = lambda: chk(L.augcl_internal_x2_conv32_forward(p(x), p(bias), None, p(y), B, H, H, 1, p(frag), None, P(am.data_ptr()), P(am.data_ptr() + 8), st), "fwd")
+                    fn = lambda: chk(L.augcl_internal_x2_conv32_forward(p(x), p(bias), None, p(y), B, H, H, 1, p(frag), None, P(am.data_ptr()), P(am.data_ptr() + 8), p(ybits), st), "fwd")
                 elif kind == "backward_data":
-                    fn = lambda: chk(L.augcl_internal_x2_conv32_backward_data(p(dz), p(x), p(dx), B, H - 2, H - 2, P(frag.data_ptr() + fb), P(am.data_ptr() + 4), P(am.data_ptr() + 12), st), "bwd")
+                    fn = lambda: chk(L.augcl_internal_x2_conv32_backward_data(p(dz), p(x), p(dx), B, H - 2, H - 2, P(frag.data_ptr() + fb), P(am.data_ptr() + 4), P(am.data_ptr() + 12), p(gbits), st), "bwd")
                 else:
                     fn = lambda: chk(L.augcl_internal_x2_conv32_backward_weights(p(x), p(dz), p(dw), p(db), p(ws), ctypes.c_size_t(ws.numel() * 4), B, H, H, P(am.data_ptr()), P(am.data_ptr() + 4), st), "wg")
             t = timeit(fn)
