@@ -357,8 +357,11 @@ __global__ __launch_bounds__(512, 2) void k_conv32_x2(ConvX2Args a)
     // same 32 pixels; the lower half stores the pixel's word (a lane with nothing to store names an offset beyond the map)
     auto finish_bits = [&]() {
         if (MODE == 0) {
+            // (v_permlane32_swap hands lanes 0-31 the upper half's value without touching LDS: a shuffle through LDS would wait
+            // for every operand read in flight)
             const uint32_t mine = gbits << (4 * h);
-            const uint32_t word = mine | (uint32_t)__shfl_xor((int)mine, 32, 64);
+            const auto sw = __builtin_amdgcn_permlane32_swap(mine, mine, false, false);
+            const uint32_t word = mine | (uint32_t)sw[1];
             __builtin_amdgcn_raw_buffer_store_b32(word, rs_bits, (h == 0 && pboff != kNoStore) ? ppix : kNoStore, 0, 0);
             gbits = 0u;
         }
@@ -534,6 +537,7 @@ struct WgX2Args {
     int B, Hi, Wi, Ho, Wo, RT, S, n_items;
     uint32_t magic_wo, magic_s;
     const uint32_t *amax_act, *amax_dz; // max |act|, max |dz| (float bits)
+    int abl;                            // tuning builds only: ablation bits (tools/x2_bench.py)
 };
 
 constexpr int WGH_SLAB = 32 * 288 + 32;
@@ -594,7 +598,11 @@ __global__ __launch_bounds__(512, 2) void k_wgrad32_x2(WgX2Args a)
         };
         auto issue = [&](int item, Regs &R) {
             const Geo g = geom(item);
-            const int pa0 = min(4 * q0, g.na - 4), pz0 = min(4 * q0, g.nz - 4); // lanes past a run repeat its last quad
+#ifdef AUGCL_TUNING
+            if (a.abl & 16) return; // ablation: no global loads
+#endif
+            // lanes past a run repeat its last quad (idempotent)
+            const int pa0 = min(4 * q0, g.na - 4), pz0 = min(4 * q0, g.nz - 4);
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 R.d[0][c] = __builtin_bit_cast(vu4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, lane_a + 4u * (unsigned)pa0, g.base_a + (unsigned)c * csA4, 0));
@@ -604,6 +612,17 @@ __global__ __launch_bounds__(512, 2) void k_wgrad32_x2(WgX2Args a)
         auto commit = [&](int item, int bi, const Regs &R) {
             const Geo g = geom(item);
             char *dst = ldsw + bi * bufbytes;
+#ifdef AUGCL_TUNING
+            if (a.abl & 2) { // ablation: no split, no LDS stores (the loads stay live)
+                uint32_t x = 0;
+#pragma unroll
+                for (int u = 0; u < WGH_NU; ++u)
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) x ^= R.d[u][c][0] ^ R.d[u][c][1] ^ R.d[u][c][2] ^ R.d[u][c][3];
+                if (x == 0x12345678u) *reinterpret_cast<uint32_t *>(dst) = x;
+                return;
+            }
+#endif
             const int pa0 = min(4 * q0, g.na - 4), pz0 = min(4 * q0, g.nz - 4);
 #pragma unroll
             for (int u = 0; u < WGH_NU; ++u) {
@@ -667,6 +686,9 @@ __global__ __launch_bounds__(512, 2) void k_wgrad32_x2(WgX2Args a)
         const char *Zt = At + 2 * abytes;
         const int nsteps = (npix + 15) >> 4;
         if (cw >= nsteps) return; // wave-uniform
+#ifdef AUGCL_TUNING
+        if (a.abl & 1) return; // ablation: the loaders alone
+#endif
         // Software pipeline at tap granularity, two taps deep: the four transposed reads of tap t + 2 (two planes x two row groups)
         // are issued before the three MFMAs of tap t, the NEXT step's dZ fragments during tap 6.
         typedef s16x4 Frag[2][2]; // [plane][row group]
@@ -1040,7 +1062,9 @@ int augcl_internal_x2_conv32_backward_weights(const float *act_prev, const float
     // per buffer: 2 planes x ((RT+2)*Wi + roundup16(RT*Wo)) pixels of 64 bytes; one item = WGH_NU rounds of loader units
     const int budget_pix = 80 * 1024 / 128;
     int rt = (budget_pix - 2 * Wi - 16) / (Wi + a.Wo);
-    rt = std::min(rt, std::min(256 / Wi - 2, 256 / a.Wo)); // one loader round (64 quads) per operand: (RT+2)*Wi, RT*Wo <= 256
+    // one loader round (64 quads) per operand: (RT+2)*Wi, RT*Wo <= 256.  (Three rounds -- two for the activations, strips half
+    // again as high -- measured the same 0.50 ms over the ten layers at B = 512: the loaders' ~3.5 TB/s bound this kernel.)
+    rt = std::min(rt, std::min(256 / Wi - 2, 256 / a.Wo));
     if (rt < 1 || a.Wo < 4) return 1;
     if (rt > a.Ho) rt = a.Ho;
     const int cus = cu_count_x2();
@@ -1056,6 +1080,9 @@ int augcl_internal_x2_conv32_backward_weights(const float *act_prev, const float
     const size_t red = (size_t)(145 * 64) * 4;
     if (lds < red) lds = red;
     const int grid = a.n_items < cus ? a.n_items : cus;
+#ifdef AUGCL_TUNING
+    a.abl = getenv("AUGCL_X2_ABL") ? atoi(getenv("AUGCL_X2_ABL")) : 0;
+#endif
     AUGCL_REQUIRE(workspace_bytes >= (size_t)(grid + 8) * WGH_SLAB * 4, "%s: workspace too small", name);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wgrad32_x2),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
