@@ -42,9 +42,8 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 constexpr int X2_SLOT = 144;       // LDS bytes per pixel slot: 2 planes x 64 B + 16 B pad (36 p mod 64 dwords: 16 consecutive
                                    // pixels x one 16-byte chunk fall into 16 distinct bank quads)
 constexpr int X2_NU = 2;           // loader rounds per strip: 256 lanes x X2_NU units of (4 pixels x 8 channels)
-constexpr int X2_WLF = 18 * 64 * 16; // the weights' lo' fragments: [18 operands][64 lanes] x 16 B (the hi parts stay in registers)
-constexpr int X2_HDR = 512 + X2_WLF; // LDS in front of the tiles: +-bias (2 x 128 B), the maximum's two words, spare, lo' fragments
-constexpr int X2_MAXTILE = 72448;  // bytes per tile buffer: 2 x this + X2_HDR <= 160 KiB (503 pixel slots; a strip's loads cover 512)
+constexpr int X2_HDR = 512;        // LDS in front of the tiles: +-bias (2 x 128 B), the maximum's two words, spare
+constexpr int X2_MAXTILE = 81664;  // bytes per tile buffer: 2 x this + X2_HDR <= 160 KiB
 constexpr int X2_FRAG_VU4 = 2 * 18 * 64; // 16-byte entries per layer block, then one entry whose first word is the weights' exponent
 constexpr int X2_BLOCK_BYTES = 55296;    // stride of the per-layer blocks in frag_ws (= the split-bf16 kernels' block: one size function)
 
@@ -112,8 +111,9 @@ __device__ unsigned long long g_x2_clk[4];
 // MODE 0: forward (valid 3x3).  MODE 1: backward-data = full correlation of dZ with the flipped, transposed weights; its
 // LDS tile keeps every dZ row with 2 zero pixels in front (which double as the 2 behind the previous row) and zero rows
 // outside the image, so no tap needs masking.
-// GATE (MODE 1): 0 = the ReLU gate is the sign of the float mask (or there is none), 16 dword loads per tile and lane;
-// 1 = the gate bits the forward pass left (ONE dword per tile and lane, 1/32 of the mask's bytes).
+// GATE: MODE 0: 1 = also write the output's gate bits (a.bits);  MODE 1: 0 = the ReLU gate is the sign of the float mask (or
+// there is none), 16 dword loads per tile and lane; 1 = the gate bits the forward pass left (ONE dword per tile and lane,
+// 1/32 of the mask's bytes).
 template <int MODE, int GATE>
 __global__ __launch_bounds__(512, 2) void k_conv32_x2(ConvX2Args a)
 {
@@ -129,7 +129,6 @@ __global__ __launch_bounds__(512, 2) void k_conv32_x2(ConvX2Args a)
     const int tilepix = (a.RT + 2) * Wl + (MODE ? 2 : 0);
     const int bufbytes = tilepix * X2_SLOT;
     float *lbias = reinterpret_cast<float *>(ldsx);        // [0..32) +bias s_in s_w, [32..64) the same negated
-    char *wlf = ldsx + 512;
     char *tiles = ldsx + X2_HDR;
     const int grp = a.dual ? (int)(blockIdx.x & 1) : 0, nhalf = a.n_items >> 1;
     const int first = a.dual ? grp * nhalf + (int)(blockIdx.x >> 1) : xcd_slot((int)blockIdx.x, (int)gridDim.x);
@@ -288,86 +287,43 @@ __global__ __launch_bounds__(512, 2) void k_conv32_x2(ConvX2Args a)
     }
 
     // ---- compute waves.  Operand i = (tap t = i / 2, channel half s = i & 1); A fragment: W_eff[row l31][k = 16 s + 8 h + j][t],
-    // the hi parts live in registers for the whole launch (72 VGPRs), the lo' parts (one of the three products) in LDS: with
-    // both resident the two accumulator sets below would not fit the 256 registers of a wave.
-    f16x8 wh[18];
+    // hi and lo' parts in registers for the whole launch (36 coalesced 16-byte loads per lane).
+    f16x8 wh[18], wl[18];
 #pragma unroll
     for (int i = 0; i < 18; ++i) {
         wh[i] = __builtin_bit_cast(f16x8, wfrag[i * 64 + lane]);
-        if ((i & 3) == cw) *reinterpret_cast<vu4 *>(wlf + (i * 64 + lane) * 16) = wfrag[(18 + i) * 64 + lane]; // each wave a quarter
+        wl[i] = __builtin_bit_cast(f16x8, wfrag[(18 + i) * 64 + lane]);
     }
     const int rowb = Wl * X2_SLOT; // LDS bytes between tile rows
     const int relu_floor = __builtin_amdgcn_readfirstlane(a.relu ? 0 : (int)0x80000000); // opaque: stays ONE v_max_i32
-    // raw buffer resources: the output's is bounded by the tensor's size, so a lane with nothing to store names an offset
+    // raw buffer resources: the output's is bounded by the tensor's size, so a lane with nothing to store just names an offset
     // beyond it (kNoStore): the hardware drops the store and the epilogue needs no branch
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)((unsigned)(a.B * 32 * a.Ho * a.Wo) * 4u), 0x00020000);
     constexpr unsigned kNoStore = 0xfffffff0u;
-    // backward-data gates: the layer input at the addresses this lane stores to, passed when its bits are >= gate_floor = 1
-    // (a positive float).  Without a mask the floor is INT_MIN -- everything passes -- and the loads read the output tensor
-    // itself (valid memory, value irrelevant): one code path, no branch on the pointer in the hot loop.
+    // backward-data with a float mask (GATE 0): the layer input at the addresses this lane stores to, passed when its bits are
+    // >= gate_floor = 1 (a positive float).  Without a mask the floor is INT_MIN -- everything passes -- and the loads read the
+    // output tensor itself (valid memory, value irrelevant): one code path, no branch on the pointer in the hot loop.
     const __amdgpu_buffer_rsrc_t rs_mask = __builtin_amdgcn_make_buffer_rsrc(
         MODE == 1 && a.mask ? const_cast<float *>(a.mask) : a.out, 0, (int)((unsigned)(a.B * 32 * a.Ho * a.Wo) * 4u), 0x00020000);
     const int gate_floor = __builtin_amdgcn_readfirstlane(a.mask ? 1 : (int)0x80000000);
-    // the gate bits (a null pointer gives an empty resource: MODE 0's stores are dropped, nothing branches)
+    // the gate bits: one word per pixel (B,Ho,Wo)
     const __amdgpu_buffer_rsrc_t rs_bits = __builtin_amdgcn_make_buffer_rsrc(
-        a.bits ? a.bits : reinterpret_cast<uint32_t *>(a.out), 0, a.bits ? (int)((unsigned)(a.B * a.Ho * a.Wo) * 4u) : 0, 0x00020000);
-    const unsigned hoff = (unsigned)(16 * h) * (unsigned)(a.Ho * a.Wo); // boff - hoff - (the image's 31 planes) = the pixel's byte in the bit map
+        GATE == 1 ? a.bits : reinterpret_cast<uint32_t *>(a.out), 0, (int)((unsigned)(a.B * a.Ho * a.Wo) * 4u), 0x00020000);
     const int chw = a.Ho * a.Wo; // 32-bit offsets: the host checks B*32*Ho*Wo < 2^30
+    const unsigned hoff = (unsigned)(16 * h) * (unsigned)chw; // boff - hoff - (the image's 31 other planes) = the pixel's byte in the bit map
     const float un_in = pow2f(-k_in), un_w = pow2f(-k_w); // two exact factors (their product may leave float32's range)
 
-    // TWO accumulator sets: while a tile's MFMAs run on one, the previous tile's 16 output rows are finished from the other --
-    // un-scale, ReLU / gate, maximum, store -- one row in the shadow of each of the first 16 operand groups (also across the
-    // strip's barrier).  Bunched behind the tile the ~100 vector instructions kept the matrix pipe idle for a tenth of it.
-    f32x16 accs[2], accxs[2]; // main product (seeded with the bias) / the two cross products (x 2^-11 at the end)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) accs[0][r] = accs[1][r] = accxs[0][r] = accxs[1][r] = 0.0f;
-    unsigned pboff = kNoStore; // the pending tile: this lane's output byte offset (kNoStore: nothing to store),
-    unsigned pgoff = 0u;       // ... the same offset for its gate loads (always a real pixel's),
-    float pun = 0.0f;          // ... its un-scale factor 2^-k_in with its strip's sign
-    int par = 0;               // the set the NEXT tile accumulates into (the pending tile sits in the other one)
+    // A tile's 16 output rows are stored WHILE the next tile's MFMAs run (one store after the first MFMA of each of its first
+    // 16 operand groups), also across the strip's barrier.  (Finishing them there as well -- un-scale, ReLU, maximum from a second
+    // accumulator set -- measured 8 % SLOWER in the stack: the vector instructions compete with the loader wave of the same SIMD
+    // for the issue port in exactly the cycles the MFMAs need it; tools/rejected/x2_two_accumulator_sets.patch.)
+    float res[16];             // the previous tile's results (bias, ReLU / gate applied)
+    unsigned pboff = kNoStore; // ... and this lane's byte offset for them
     float vmax = 0.0f;         // max |result| of this lane (a lane past the strip's end repeats a real pixel: harmless)
-    constexpr int GR = 4;      // float-mask gates in flight (row r in slot r % GR; GR must divide 16)
-    float gq[GR];
-    unsigned ppix = 0u;        // the pending tile's byte in the bit map
-    uint32_t gbits = 0u;       // MODE 0: the pending tile's gate bits so far;  MODE 1 / GATE 1: the pending tile's gate word
-    uint32_t gnext = 0u;       // MODE 1 / GATE 1: the gate word of the tile being accumulated
-    auto rowoff = [&](int r) { return (unsigned)(((r & 3) + 8 * (r >> 2)) * chw) * 4u; };
-    auto gload = [&](unsigned goff, int r) {
-        if (MODE == 1 && GATE == 0)
-            gq[r % GR] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_mask, goff, rowoff(r), 0));
+    auto store_row = [&](int r) {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, res[r]), rs_out, pboff,
+                                              (unsigned)(((r & 3) + 8 * (r >> 2)) * chw) * 4u, 0);
     };
-    auto finish_row = [&](auto PSETC, int r) {
-        constexpr int PSET = decltype(PSETC)::value;
-        float v = __builtin_fmaf(accxs[PSET][r], 1.0f / 2048.0f, accs[PSET][r]) * pun * un_w;
-        const int co = (r & 3) + 8 * (r >> 2); // (+ 4 h: this lane's 16 channels are co and co + 4 of every group of 8)
-        if (MODE == 0) {
-            v = __int_as_float(max(__float_as_int(v), relu_floor));
-            // v >= +0 here whenever the bits are kept (ReLU layers): positive <=> its bit pattern is >= 1.  Three integer
-            // instructions; the compare-and-select form cost six more registers than this kernel has
-            gbits = (((__float_as_uint(v) + 0x7fffffffu) >> 31) << co) | gbits;
-        } else if (GATE == 1) { // bit co + 4 h of the pixel's word (shifted down by 4 h when it was fetched), spread over all 32 bits
-            v = __uint_as_float(__float_as_uint(v) & (uint32_t)__builtin_amdgcn_sbfe((int)gbits, co, 1));
-        } else {
-            v = __float_as_int(gq[r % GR]) >= gate_floor ? v : 0.0f;
-        }
-        vmax = fmaxf(vmax, fabsf(v));
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_out, pboff, rowoff(r), 0);
-    };
-    // MODE 0, after the pending tile's last row: its two half-waves hold channels {0-3, 8-11, ...} and {4-7, 12-15, ...} of the
-    // same 32 pixels; the lower half stores the pixel's word (a lane with nothing to store names an offset beyond the map)
-    auto finish_bits = [&]() {
-        if (MODE == 0) {
-            // (v_permlane32_swap hands lanes 0-31 the upper half's value without touching LDS: a shuffle through LDS would wait
-            // for every operand read in flight)
-            const uint32_t mine = gbits << (4 * h);
-            const auto sw = __builtin_amdgcn_permlane32_swap(mine, mine, false, false);
-            const uint32_t word = mine | (uint32_t)sw[1];
-            __builtin_amdgcn_raw_buffer_store_b32(word, rs_bits, (h == 0 && pboff != kNoStore) ? ppix : kNoStore, 0, 0);
-            gbits = 0u;
-        }
-    };
-    typedef std::integral_constant<int, 0> Set0;
-    typedef std::integral_constant<int, 1> Set1;
     auto compute = [&](int item, int bi) {
         const int b = a.S == 1 ? item : (int)__umulhi((uint32_t)item, a.magic_s), s = item - b * a.S;
         const int y0 = s * a.RT;
@@ -390,26 +346,33 @@ __global__ __launch_bounds__(512, 2) void k_conv32_x2(ConvX2Args a)
             boff_ = (unsigned)((b * 32 * a.Ho + (y0 + yy_)) * a.Wo + xx_ + 4 * h * chw) * 4u;
         };
         struct Ops {
-            vu4 xh, xl, wl;
+            vu4 xh, xl;
         };
-        auto rd1 = [&](int off_, int i, Ops &o, int part) { // one of the operand's three reads: row base + immediate
+        auto rd1 = [&](int off_, int i, Ops &o, int part) { // one of the operand's two reads: row base + immediate
             const int t = i >> 1;
             const char *p = tile + off_ + (t / 3) * rowb + ((t % 3) * X2_SLOT + (i & 1) * 32);
             if (part == 0) o.xh = *reinterpret_cast<const vu4 *>(p);
-            else if (part == 1) o.xl = *reinterpret_cast<const vu4 *>(p + 64);
-            else o.wl = *reinterpret_cast<const vu4 *>(wlf + (i * 64 + lane) * 16);
+            else o.xl = *reinterpret_cast<const vu4 *>(p + 64);
         };
         bool valid;
         int off;
         unsigned boff;
         locate(cw, valid, off, boff);
+        // backward-data, float mask: this lane's 16 ReLU gates.  Row r of the previous tile is stored and gate r of the CURRENT
+        // tile requested in the same slot of the MFMA stream (the result register the store frees is the one the gate lands
+        // in), two rows per operand group over the first eight groups.  With gate bits: ONE word per tile, requested up front.
+        float gv[16];
+        uint32_t gword = 0u;
+        auto side_row = [&](int r) {
+            store_row(r);
+            if (GATE == 0)
+                gv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                      rs_mask, boff, (unsigned)(((r & 3) + 8 * (r >> 2)) * chw) * 4u, 0));
+        };
         Ops o[3]; // operands i, i + 1, i + 2: reads run two groups (6 MFMAs, ~190 cycles) ahead of their use
-        rd1(off, 0, o[0], 0); rd1(off, 0, o[0], 2); rd1(off, 0, o[0], 1);
-        rd1(off, 1, o[1], 0); rd1(off, 1, o[1], 2); rd1(off, 1, o[1], 1);
-        // one tile on accumulator set SET; the pending tile (set 1 - SET) is finished in its gaps
-        auto tile_body = [&](auto SETC, int tl) {
-            constexpr int SET = decltype(SETC)::value;
-            typedef std::integral_constant<int, 1 - SET> PSetC;
+        rd1(off, 0, o[0], 0); rd1(off, 0, o[0], 1);
+        rd1(off, 1, o[1], 0); rd1(off, 1, o[1], 1);
+        for (int tl = cw; tl < ntiles; tl += 4) {
             bool valid2;
             int off2;
             unsigned boff2;
@@ -417,9 +380,8 @@ __global__ __launch_bounds__(512, 2) void k_conv32_x2(ConvX2Args a)
 #ifdef AUGCL_TUNING
             ++n_tiles;
 #endif
-            f32x16 &acc = accs[SET], &accx = accxs[SET];
-            if (MODE == 1 && GATE == 1) // this tile's gate word (this lane's pixel), shifted so that bit co is channel co + 4 h
-                gnext = __builtin_amdgcn_raw_buffer_load_b32(rs_bits, boff - hoff - img31, 0, 0);
+            if (MODE == 1 && GATE == 1) gword = __builtin_amdgcn_raw_buffer_load_b32(rs_bits, boff - hoff - img31, 0, 0);
+            f32x16 acc, accx; // main product (seeded with the bias) / the two cross products (x 2^-11 at the end)
             {
                 const float *bsrc = lbias + (bi ? 32 : 0);
 #pragma unroll
@@ -436,52 +398,52 @@ __global__ __launch_bounds__(512, 2) void k_conv32_x2(ConvX2Args a)
                 Ops &cur = o[i % 3];
                 Ops &nn = o[(i + 2) % 3];
                 const int noff = i < 16 ? off : off2, ni = i < 16 ? i + 2 : i - 16; // the operand two groups on (across the tile boundary)
-                // smallest products first: wl' xh, wh xl' (cross), wh xh (main).  Gaps: one LDS read each; the first also finishes
-                // row i of the pending tile.  Backward-data with a float mask: the gate it needs was requested GR groups ago -- the
-                // slot it frees takes the pending tile's row i + GR, then THIS tile's row i + GR - 16 (with gate bits: one word
-                // per tile, requested at the tile's start)
-                X2_MM(accx, __builtin_bit_cast(f16x8, cur.wl), cur.xh);
+                // smallest products first: wl' xh, wh xl' (cross), wh xh (main); one LDS read / store / gate load between MFMAs
+                X2_MM(accx, wl[i], cur.xh);
                 __builtin_amdgcn_sched_barrier(0);
                 rd1(noff, ni, nn, 0);
-                if (i < 16) {
-                    finish_row(PSetC{}, i);
-                    if (i + GR < 16) gload(pgoff, i + GR);
-                    else gload(boff, i + GR - 16); // (GR divides 16: the slot row i frees is the slot of this tile's row i + GR - 16)
-                    if (i == 15) finish_bits();
-                }
+                if (MODE == 0 && i < 16) store_row(i);
+                if (MODE == 1 && i < 8) side_row(2 * i);
                 __builtin_amdgcn_sched_barrier(0);
                 X2_MM(accx, wh[i], cur.xl);
                 __builtin_amdgcn_sched_barrier(0);
-                rd1(noff, ni, nn, 2);
+                rd1(noff, ni, nn, 1);
+                if (MODE == 1 && i < 8) side_row(2 * i + 1);
                 __builtin_amdgcn_sched_barrier(0);
                 X2_MM(acc, wh[i], cur.xh);
                 __builtin_amdgcn_sched_barrier(0);
-                rd1(noff, ni, nn, 1);
-                __builtin_amdgcn_sched_barrier(0);
             }
 #undef X2_MM
-            pboff = valid ? boff : kNoStore; // this tile is the pending one now
-            pgoff = boff;
-            ppix = boff - hoff - img31;
-            if (MODE == 1 && GATE == 1) gbits = gnext >> (4 * h);
-            pun = un0;
+            // rows in accumulator order: co = 0,1,2,3, 8,9,10,11, ... (+4 h in the lane offset)
+            uint32_t gbits = 0u;
+            const uint32_t gmine = gword >> (4 * h); // MODE 1 / GATE 1: bit co of it is this lane's channel co + 4 h
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = (r & 3) + 8 * (r >> 2);
+                float v = __builtin_fmaf(accx[r], 1.0f / 2048.0f, acc[r]) * un0 * un_w;
+                if (MODE == 0) {
+                    v = __int_as_float(max(__float_as_int(v), relu_floor));
+                    // gate bit of the NEXT layer's backward-data: v >= +0 here (ReLU layers), positive <=> bit pattern >= 1
+                    if (GATE == 1) gbits = (min(__float_as_uint(v), 1u) << co) | gbits;
+                } else if (GATE == 1) {
+                    v = __uint_as_float(__float_as_uint(v) & (uint32_t)__builtin_amdgcn_sbfe((int)gmine, co, 1));
+                } else {
+                    v = __float_as_int(gv[r]) >= gate_floor ? v : 0.0f;
+                }
+                vmax = fmaxf(vmax, fabsf(v));
+                res[r] = v;
+            }
+            pboff = valid ? boff : kNoStore;
+            if (MODE == 0 && GATE == 1) {
+                // the two half-waves hold channels {0-3, 8-11, ...} and {4-7, 12-15, ...} of the same 32 pixels: v_permlane32_swap
+                // hands lanes 0-31 the upper half's bits (no LDS round trip), and they store the pixel's word
+                const uint32_t mine = gbits << (4 * h);
+                const auto sw = __builtin_amdgcn_permlane32_swap(mine, mine, false, false);
+                __builtin_amdgcn_raw_buffer_store_b32(mine | (uint32_t)sw[1], rs_bits, (h == 0 && valid) ? boff - img31 : kNoStore, 0, 0);
+            }
             // (18 = 6 x 3: the next tile's operands 0 and 1 sit in o[0], o[1] again)
             valid = valid2; off = off2; boff = boff2;
-        };
-        // the wave's tiles alternate between the sets; which one comes first is only known at run time (it continues from
-        // the previous strip), so the loop exists in both phases
-        if (par == 0) {
-            for (int tl = cw; tl < ntiles; tl += 8) {
-                tile_body(Set0{}, tl);
-                if (tl + 4 < ntiles) tile_body(Set1{}, tl + 4);
-            }
-        } else {
-            for (int tl = cw; tl < ntiles; tl += 8) {
-                tile_body(Set1{}, tl);
-                if (tl + 4 < ntiles) tile_body(Set0{}, tl + 4);
-            }
         }
-        par ^= ((ntiles - cw + 3) >> 2) & 1;
     };
     __syncthreads();
     for (int item = first; item < n; item += 2 * NG) {
@@ -491,22 +453,8 @@ __global__ __launch_bounds__(512, 2) void k_conv32_x2(ConvX2Args a)
         compute(item + NG, 1);
         __syncthreads();
     }
-    // the last tile's results
-    if (par == 1) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            if (r >= GR) gload(pgoff, r);
-            finish_row(Set0{}, r);
-        }
-        finish_bits();
-    } else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            if (r >= GR) gload(pgoff, r);
-            finish_row(Set1{}, r);
-        }
-        finish_bits();
-    }
+    for (int r = 0; r < 16; ++r) store_row(r); // the last tile's results
 #ifdef AUGCL_TUNING
     if (blockIdx.x == 0 && wave == 0 && lane == 0) {
         g_x2_clk[0] = __builtin_amdgcn_s_memtime() - t_start;
@@ -1021,7 +969,8 @@ int augcl_internal_x2_conv32_forward(const float *in, const float *bias, const f
     a.amax_out = reinterpret_cast<uint32_t *>(amax_out);
     a.bits = reinterpret_cast<uint32_t *>(gate_bits_out);
     a.B = B; a.Hi = Hi; a.Wi = Wi; a.Ho = Hi - 2; a.Wo = Wi - 2; a.relu = relu;
-    return launch_conv_x2<0, 0>(a, name, as_stream(stream));
+    AUGCL_REQUIRE(gate_bits_out == nullptr || relu, "%s: gate bits are those of a ReLU layer", name);
+    return gate_bits_out ? launch_conv_x2<0, 1>(a, name, as_stream(stream)) : launch_conv_x2<0, 0>(a, name, as_stream(stream));
 }
 
 // gate_bits != null: the ReLU gate comes from the bit map the forward pass left for act_prev (act_prev itself is not read)

@@ -40,9 +40,10 @@ def amax(t, slot):
 tot = {}
 print("H    fwd x3 -> x2       bwd x3 -> x2       wgrad x3 -> x2    (us)   x2: fwd TB/s")
 for H in range(41, 21, -2):
-    x = torch.rand(B, 32, H, H, device=dev)
+    x = torch.relu(torch.randn(B, 32, H, H, device=dev))  # post-ReLU statistics (half zeros): all-dense operands cost the
+    # matrix pipe more power and hide what the kernels are bound by in the real stack
     y = torch.empty(B, 32, H - 2, H - 2, device=dev)
-    dz = torch.randn(B, 32, H - 2, H - 2, device=dev) * 1e-3
+    dz = torch.randn(B, 32, H - 2, H - 2, device=dev) * 1e-3 * (torch.rand(B, 32, H - 2, H - 2, device=dev) > 0.5)  # gated gradient
     dx = torch.empty(B, 32, H, H, device=dev)
     amax(x, 0); amax(dz, 1)
     gbits = torch.empty(B * H * H, dtype=torch.int32, device=dev)  # gate bits of x (the backward-data mask), as the forward pass of
