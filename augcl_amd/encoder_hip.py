@@ -136,6 +136,7 @@ _BF16_WGRAD = "augcl_enc_bf16_conv32_backward_weights_mfma"
 # (round 1-2's parity path, kept for A/B); "bf16" = bf16 NHWC performance mode.
 PRECISION_CODE = {"f32_mfma": 0, "bf16": 1, "f32_x3": 2, "f32": 3}
 _SPLIT = ("f32", "f32_x3")  # the precisions whose stack calls take a weight-fragment workspace
+_GATE_BITS = True           # (A/B switch: False = backward-data gates on the float activations, as the split-bf16 path does)
 _AMAX = 64                  # floats appended to an arena for the per-tensor maxima of precision "f32" (>= 2 x layers)
 
 
@@ -206,7 +207,7 @@ class ConvStackFn(torch.autograd.Function):
                 offs.append(tot)
                 tot += (n + al - 1) // al * al
             tot = max(tot, al)
-            if tail:  # ... and, behind the maxima, one gate word per pixel of every intermediate activation (backward-data's ReLU gate)
+            if tail and _GATE_BITS:  # ... and, behind the maxima, one gate word per pixel of every intermediate activation (backward-data's ReLU gate)
                 boffs, btot = [], 0
                 for h, w_ in zip(hs[:-1], wsz[:-1]):
                     boffs.append(btot)
@@ -214,7 +215,7 @@ class ConvStackFn(torch.autograd.Function):
                 tail += btot
             arena = torch.empty(tot + tail, dtype=adt, device=dev)
             ptrs = [arena.data_ptr() + o * arena.element_size() for o in offs]
-            if tail:
+            if tail and _GATE_BITS:
                 bits = _ptr_array([arena.data_ptr() + (tot + _AMAX + o) * 4 for o in boffs] + [None])
         else:  # two ping-pong buffers
             big = (max(numel[:-1], default=al) + al - 1) // al * al

@@ -3,8 +3,10 @@ two weight sets), the no-grad single forward (B = 256), forward + backward (B = 
   for t in _prev .; do python tools/ab_stack.py $t; done"""
 import sys, time, numpy as np, torch
 tree = sys.argv[1] if len(sys.argv) > 1 else "."
-sys.path.insert(0, tree)
-from augcl_amd import encoder_ops
+sys.path.insert(0, tree.split(":")[0])
+from augcl_amd import encoder_ops, encoder_hip
+if tree.endswith(":nobits"):
+    encoder_hip._GATE_BITS = False
 dev = torch.device("cuda:0")
 rs = np.random.RandomState(0)
 ws = [torch.from_numpy((rs.standard_normal((32, 9 if i == 0 else 32, 3, 3)) * (0.2 if i == 0 else 0.08)).astype(np.float32)).to(dev) for i in range(11)]

@@ -4,7 +4,8 @@ import json, subprocess, sys
 trees = sys.argv[1:3]
 rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 prec = sys.argv[4] if len(sys.argv) > 4 else "f32"
-code = ("import sys, json, torch; sys.path.insert(0, sys.argv[1]); from augcl_amd import bench_update; "
+code = ("import sys, json, os, torch; sys.path.insert(0, sys.argv[1].split(':')[0]); from augcl_amd import bench_update, encoder_hip; "
+        "encoder_hip._GATE_BITS = not sys.argv[1].endswith(':nobits'); "
         "r = bench_update.run(torch.device('cuda:0'), None, 1, 0, steps=200, warmup=10, B=256, precision=sys.argv[2], graph=True); "
         "print('RES', json.dumps(r['ms_per_update']))")
 res = {t: [] for t in trees}
