@@ -441,6 +441,7 @@ def main():
         use_graph = dist is None or (args.dp_graph and not args.rehearse_one_gpu and graph_collectives_ok(dist, dev, torch))
         busy = load_profile_json("r03_mfma_busy.json")
         hbm16 = load_profile_json("r03_bf16_conv_hbm.json")
+        hbm32 = load_profile_json("r03_f32_conv_hbm.json")
 
         def leg(precision):
             """Both execution modes of update(); the faster one is the reported figure, the other sits beside it
@@ -451,18 +452,27 @@ def main():
             for r in runs:
                 if r is not best:
                     best["hip_graph_ms_per_update" if r["hip_graph"] else "eager_ms_per_update"] = r["ms_per_update"]
-            # The f32 parity path runs its 32 -> 32 layers as SIX bf16 MFMAs per product group (csrc/encoder_x3.hip): its roof
-            # is the bf16 matrix pipe.  achieved = the bf16-MFMA flops those layers ISSUE (6 x their executed f32-equivalent
-            # flops) per second, whole update in the denominator; the f32-equivalent rates sit beside it.  The bf16 mode's conv
-            # kernels are HBM-paced: its roofline is the time-weighted HBM fraction of those kernels,
-            # from the rocprofv3 stats of the same tree (null when the profile on file is stale).
+            # The f32 parity path runs its 32 -> 32 layers as THREE f16 MFMAs per product group (csrc/encoder_x2.hip: every f32
+            # operand an f16 pair under a per-tensor power-of-two scale).  Two roofs are quoted: the f16 matrix pipe -- achieved =
+            # the MFMA flops those layers ISSUE (3 x their executed f32-equivalent flops) per second, whole update in the
+            # denominator -- and HBM: the conv kernels' algorithmic bytes over their rocprofv3 durations, time-weighted (from the
+            # profile of the same tree, null when the one on file is stale).  The bound is the roof the path sits closer to.
             if precision == "f32":
-                issued = 6.0 * best["executed_conv32_GFLOP_per_update"] * 1e9 / (best["ms_per_update"] * 1e-3) / 1e12
-                best["roofline"] = {"bound": "mfma_bf16 (f32-accurate products: 6 bf16 MFMAs per product group)", "achieved": issued,
-                                    "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": issued / MFMA_BF16_PEAK_TFLOPS,
-                                    "f32_equivalent_executed_TFLOP/s": best["executed_TFLOP/s"],
-                                    "f32_equivalent_algorithmic_TFLOP/s": best["algorithmic_TFLOP/s"],
-                                    "native_f32_mfma_peak_TFLOP/s": MFMA_F32_PEAK_TFLOPS}
+                issued = 3.0 * best["executed_conv32_GFLOP_per_update"] * 1e9 / (best["ms_per_update"] * 1e-3) / 1e12
+                h = hbm32 if not hbm32.get("stale_profile") else {}
+                hb = h.get("conv_GBps_time_weighted")
+                mf = {"achieved": issued, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": issued / MFMA_BF16_PEAK_TFLOPS,
+                      "note": "f16 MFMA flops issued (3 per f32 product), whole update() in the denominator"}
+                if hb and hb / HBM_PEAK_GBS > mf["frac"]:
+                    best["roofline"] = {"bound": "hbm (conv kernels of the f32 path: f32 NCHW activations in and out)", "achieved": hb,
+                                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hb / HBM_PEAK_GBS,
+                                        "source": "profiles/r03_f32_conv_hbm.json (algorithmic bytes of every conv launch / its rocprofv3 "
+                                                  "duration, time-weighted)", "mfma_f16": mf}
+                else:
+                    best["roofline"] = {"bound": "mfma_f16 (f32-accurate products: 3 f16 MFMAs per product group)", **mf}
+                best["roofline"].update({"f32_equivalent_executed_TFLOP/s": best["executed_TFLOP/s"],
+                                         "f32_equivalent_algorithmic_TFLOP/s": best["algorithmic_TFLOP/s"],
+                                         "native_f32_mfma_peak_TFLOP/s": MFMA_F32_PEAK_TFLOPS})
             else:
                 h = hbm16 if not hbm16.get("stale_profile") else {}
                 best["roofline"] = {"bound": "hbm (conv kernels; heads and optimiser stay f32)", "achieved": h.get("conv_GBps_time_weighted"),
@@ -474,7 +484,7 @@ def main():
             best["roofline"]["mfma_busy"] = b_
             best["roofline"]["mfma_busy_source"] = ("profiles/r03_mfma_busy.json (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES per conv "
                                                     "kernel / launch duration x 2.4 GHz x 1024 SIMDs, time-weighted)") if b_ else None
-            if busy.get("stale_profile") or hbm16.get("stale_profile"):
+            if busy.get("stale_profile") or hbm16.get("stale_profile") or hbm32.get("stale_profile"):
                 best["roofline"]["stale_profile"] = True
             return best
 

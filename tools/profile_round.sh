@@ -26,12 +26,13 @@ python tools/pmc_summary.py $O/${R}_write
 echo "[profile_round] traffic done"
 
 # 3. SVEA update(): per-kernel durations (hipGraph replay), MFMA-busy counters and HBM traffic of the encoder kernels,
-#    f32 parity path (split-bf16 kernels), native f32 MFMA path and bf16 mode
-for P in f32 bf16 f32_mfma; do
+#    f32 parity path (f16-pair kernels) and bf16 mode; durations only for the split-bf16 and native f32 MFMA forms of the parity path
+for P in f32 bf16 f32_x3 f32_mfma; do
     rocprofv3 --kernel-trace --stats --output-format csv -d $O/${R}_update_$P -- python tools/prof_update.py 40 $P graph > $O/${R}_update_$P.log 2>&1
     python tools/prof_summary.py $O/${R}_update_$P 48 "SVEA update() B=256, $P, hipGraph replay (tools/prof_update.py 40 $P graph: 8 warm-up + 40 timed)"
     echo "[profile_round] update $P stats done"
     [ "$P" = "f32_mfma" ] && continue
+    [ "$P" = "f32_x3" ] && continue
     rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/${R}_mfma_$P -- python tools/prof_update.py 12 $P > /dev/null 2>&1
     python tools/pmc_summary.py $O/${R}_mfma_$P
     rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${R}_ufetch_$P -- python tools/prof_update.py 12 $P > /dev/null 2>&1

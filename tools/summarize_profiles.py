@@ -25,7 +25,8 @@ except Exception as e:  # noqa: BLE001
 CLK_HZ, SIMDS = 2.4e9, 256 * 4  # MI355X engine clock (peak), 256 CUs x 4 SIMDs
 
 for src, dst in (("bench.csv", f"{tag}_bench_kernel_stats.csv"), ("update_f32.csv", f"{tag}_update_kernel_stats.csv"),
-                 ("update_bf16.csv", f"{tag}_update_bf16_kernel_stats.csv"), ("update_f32_mfma.csv", f"{tag}_update_f32_mfma_kernel_stats.csv")):
+                 ("update_bf16.csv", f"{tag}_update_bf16_kernel_stats.csv"), ("update_f32_mfma.csv", f"{tag}_update_f32_mfma_kernel_stats.csv"),
+                 ("update_f32_x3.csv", f"{tag}_update_f32_x3_kernel_stats.csv")):
     if os.path.exists(G(src)):
         shutil.copy(G(src), os.path.join(out, dst))
 
@@ -126,22 +127,24 @@ if "f32" in busy or "bf16" in busy:
 HS = [41 - 2 * i for i in range(11)]  # output size of layer i (input of layer i + 1)
 
 
-def conv_mix(elem):
-    """{kernel-name fragment: (launches per update, algorithmic bytes per update)} for activations of `elem` bytes"""
+def conv_mix(elem, gate_bits=False):
+    """{kernel-name fragment: (launches per update, algorithmic bytes per update)} for activations of `elem` bytes;
+    gate_bits: backward-data reads one 32-bit word per pixel (the forward pass's gate bits) instead of the layer input"""
     px = lambda n: 32 * n * n  # noqa: E731
     fwd = bwd = wg = 0.0
     for i in range(1, 11):
         hi, ho = HS[i - 1], HS[i]
         o_el = 4 if (i == 10) else elem  # the last layer always writes f32
         fwd += (512 + 512 + 0.5 * 256) * (px(hi) * elem + px(ho) * o_el)
-        bwd += 512 * (px(ho) * elem + 2 * px(hi) * elem)       # dZ in, gate (layer input) in, dX out
+        gate = hi * hi * 4 if gate_bits else px(hi) * elem
+        bwd += 512 * (px(ho) * elem + gate + px(hi) * elem)    # dZ in, gate in, dX out
         wg += 512 * (px(hi) * elem + px(ho) * elem)
     first = (256 + 512 + 0.5 * 256) * (9 * 84 * 84 * 4) + (512 + 512 + 0.5 * 256) * px(41) * elem  # dual launch reads x once
     wfirst = 512 * (9 * 84 * 84 * 4 + px(41) * elem)
     return {"fwd": (25, fwd), "bwd": (10, bwd), "wgrad": (10, wg), "first": (2.5, first), "wfirst": (1, wfirst)}
 
 
-KERNEL_ROLE = [("k_conv32_x3<0", "fwd"), ("k_conv32_x3<1", "bwd"), ("k_wgrad32_x3", "wgrad"), ("k_conv32_bf16<0", "fwd"),
+KERNEL_ROLE = [("k_conv32_x2<0", "fwd"), ("k_conv32_x2<1", "bwd"), ("k_wgrad32_x2", "wgrad"), ("k_conv32_x3<0", "fwd"), ("k_conv32_x3<1", "bwd"), ("k_wgrad32_x3", "wgrad"), ("k_conv32_bf16<0", "fwd"),
                ("k_conv32_bf16<1", "bwd"), ("k_wgrad32_bf16", "wgrad"), ("k_conv_first9", "first"), ("k_wgrad_first", "wfirst"),
                ("k_conv32<0", "fwd"), ("k_conv32<1", "bwd"), ("k_wgrad32<", "wgrad")]
 
@@ -170,7 +173,7 @@ upd = {"round": tag, "source_hash": SRC_HASH, "note": "conv encoder kernels insi
 for prec, elem in (("f32", 4), ("bf16", 2)):
     if not os.path.exists(G(f"update_{prec}.csv")):
         continue
-    mix = conv_mix(elem)
+    mix = conv_mix(elem, gate_bits=(prec == "f32"))
     times = kernel_times(G(f"update_{prec}.csv"))
     fetch = json.load(open(G(f"ufetch_{prec}.json"))) if os.path.exists(G(f"ufetch_{prec}.json")) else {}
     write = json.load(open(G(f"uwrite_{prec}.json"))) if os.path.exists(G(f"uwrite_{prec}.json")) else {}
@@ -203,10 +206,11 @@ for prec, elem in (("f32", 4), ("bf16", 2)):
                  "conv_GBps_time_weighted": round(tot_b / tot_t / 1e3, 1) if tot_t else None}
 if "f32" in upd or "bf16" in upd:
     json.dump(upd, open(os.path.join(out, f"{tag}_update_conv_traffic.json"), "w"), indent=1)
-    if "bf16" in upd:
-        json.dump({"round": tag, "source_hash": SRC_HASH, "conv_GBps_time_weighted": upd["bf16"]["conv_GBps_time_weighted"],
-                   "conv_us_per_update": upd["bf16"]["conv_us_per_update"], "frac_of_8TBps": round(upd["bf16"]["conv_GBps_time_weighted"] / 8000.0, 3),
-                   "source": f"profiles/{tag}_update_conv_traffic.json"}, open(os.path.join(out, f"{tag}_bf16_conv_hbm.json"), "w"), indent=1)
+    for p_ in ("f32", "bf16"):
+        if p_ in upd:
+            json.dump({"round": tag, "source_hash": SRC_HASH, "conv_GBps_time_weighted": upd[p_]["conv_GBps_time_weighted"],
+                       "conv_us_per_update": upd[p_]["conv_us_per_update"], "frac_of_8TBps": round(upd[p_]["conv_GBps_time_weighted"] / 8000.0, 3),
+                       "source": f"profiles/{tag}_update_conv_traffic.json"}, open(os.path.join(out, f"{tag}_{p_}_conv_hbm.json"), "w"), indent=1)
     print("update conv traffic:", {p: upd[p]["conv_GBps_time_weighted"] for p in ("f32", "bf16") if p in upd})
 
 # ---- the launch sequence of graph-replayed updates: launches per update() with and without the actor step
