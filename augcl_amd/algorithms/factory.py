@@ -22,7 +22,7 @@ def make_agent(obs_shape, action_shape, args):
             return default
 
     agent = cls(obs_shape, action_shape, args)
-    if opt("precision") is not None:  # "f32" (parity path) / "f32_mfma" / "bf16" (performance mode): THIS agent's conv stacks
+    if opt("precision") is not None:  # "f32" (parity path) / "f32_x3" / "f32_mfma" / "bf16" (performance mode): THIS agent's conv stacks
         agent.set_precision(opt("precision"))
     if opt("hip_graph"):    # replay update() as captured hipGraphs
         agent.enable_hip_graphs()

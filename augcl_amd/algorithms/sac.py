@@ -291,9 +291,10 @@ class SAC(object):
         return [m for net in nets if net is not None for m in net.modules() if isinstance(m, (SharedCNN, HeadCNN))]
 
     def set_precision(self, name):
-        """Arithmetic of THIS agent's conv stacks (not in the reference): "f32" = parity path, "f32_mfma" = the same tensors
-        on the native f32 MFMA pipe, "bf16" = performance mode, None = follow encoder_ops' process default.  Captured
-        hipGraphs bake the kernels in, so they are dropped and recaptured."""
+        """Arithmetic of THIS agent's conv stacks (not in the reference): "f32" = parity path (f16 pairs), "f32_x3" = the same
+        tensors as range-free bf16 triples, "f32_mfma" = the same tensors on the native f32 MFMA pipe, "bf16" = performance
+        mode, None = follow encoder_ops' process default.  Captured hipGraphs bake the kernels in, so they are dropped and
+        recaptured."""
         from .. import encoder_ops
         if name is not None:
             encoder_ops._check(name)

@@ -193,7 +193,7 @@ def test_dual_stack_forward_equals_two_passes(cuda, B, precision):
 @pytest.mark.parametrize("B,H,W", [(2, 12, 70), (3, 70, 12), (1, 10, 100), (2, 33, 35), (5, 11, 11), (1, 3, 9), (1, 5, 6), (2, 6, 9),
                                    (1, 9, 130), (260, 41, 41), (3, 23, 23)])
 def test_conv32_layer_entry_points_on_odd_shapes(cuda, B, H, W, pre):
-    """The three 32 -> 32 layer kernels through the C ABI -- the split-bf16 form (augcl_enc_x3_*: the parity path) and the
+    """The three 32 -> 32 layer kernels through the C ABI -- the split-bf16 form (augcl_enc_x3_*: precision "f32_x3") and the
     native f32 MFMA form -- on shapes the square training stack never produces: wide rows (more than one 64-lane chunk per
     row in the backward-data loader; rows too wide for the split tiles, which hand over to the f32 MFMA kernel), tall thin
     images, single-strip images, the smallest legal sizes (one quad per row), a batch that is not a multiple of the grid --
@@ -284,3 +284,42 @@ def test_x2_layer_entry_points_on_odd_shapes(cuda, B, H, W, scale_x, scale_dz):
         assert float((dw.double() - wd.grad).abs().max()) <= 3e-5 * float(wd.grad.abs().max())
         dbw = dz.double().sum((0, 2, 3))
         assert float((db.double() - dbw).abs().max()) <= 3e-5 * float(dbw.abs().max() + dz.double().abs().sum((0, 2, 3)).max() * 1e-3)
+
+
+def test_x2_layer_degenerate_inputs(cuda):
+    """f16-pair layer kernels at the edges of their scaling: an all-zero input (maximum 0: the scale clamps, the output is exactly
+    relu(bias)), an all-zero gradient, and a tensor with ONE element 2^20 above the rest (the small elements keep an absolute
+    accuracy of 2^-36 of the maximum, i.e. the result stays within float32 rounding OF THE LARGE TERM'S SCALE)."""
+    import torch.nn.functional as F
+    from augcl_amd import _lib
+    L = _lib.load()
+    B, H, W = 3, 14, 17
+    g = torch.Generator(device=cuda).manual_seed(5)
+    w = torch.randn(32, 32, 3, 3, device=cuda, generator=g) * 0.06
+    bias = torch.randn(32, device=cuda, generator=g)
+    st = _lib.current_stream(cuda)
+    p = lambda t: t.data_ptr()  # noqa: E731
+    fws = torch.empty(L.augcl_enc_frag_workspace_bytes(1, 1), dtype=torch.uint8, device=cuda)
+    am = torch.zeros(4, device=cuda)
+    x = torch.zeros(B, 32, H, W, device=cuda)
+    _lib.call("augcl_enc_amax_f32", p(x), x.numel(), p(am), st)
+    y = torch.full((B, 32, H - 2, W - 2), float("nan"), device=cuda)
+    _lib.call("augcl_enc_x2_conv32_forward", p(x), p(w), p(bias), p(y), B, H, W, 1, p(fws), fws.numel(), p(am), p(am) + 4, st)
+    assert torch.equal(y, torch.relu(bias).view(1, 32, 1, 1).expand_as(y))
+    assert float(am[1]) == float(torch.relu(bias).max())
+    dz = torch.zeros(B, 32, H - 2, W - 2, device=cuda)
+    dx = torch.full((B, 32, H, W), float("nan"), device=cuda)
+    _lib.call("augcl_enc_amax_f32", p(dz), dz.numel(), p(am) + 8, st)
+    _lib.call("augcl_enc_x2_conv32_backward_data", p(dz), p(w), None, p(dx), B, H - 2, W - 2, p(fws), fws.numel(), p(am) + 8, None, st)
+    assert float(dx.abs().max()) == 0.0
+    # one outlier
+    x = torch.relu(torch.randn(B, 32, H, W, device=cuda, generator=g))
+    x[1, 7, 5, 6] = 2.0 ** 20
+    _lib.call("augcl_enc_amax_f32", p(x), x.numel(), p(am), st)
+    _lib.call("augcl_enc_x2_conv32_forward", p(x), p(w), p(bias), p(y), B, H, W, 0, p(fws), fws.numel(), p(am), None, st)
+    want = F.conv2d(x.double(), w.double(), bias.double())
+    err = (y.double() - want).abs()
+    assert float(err.max()) <= 2.0 ** 20 * 0.06 * 4 * 2.0 ** -24 * 8  # float32 rounding at the outlier's scale
+    far = torch.ones_like(err, dtype=torch.bool)
+    far[1, :, 3:6, 4:7] = False  # outputs that do not see the outlier: absolute error <= sum |w| x 2^-36 x 2^20 (~ 2e-5 of a value of order 1)
+    assert float(err[far].max()) <= 288 * 0.3 * 2.0 ** -36 * 2.0 ** 20 + 1e-6
