@@ -88,7 +88,7 @@ def run(dev, dist, world, rank, steps=20, warmup=4, B=256, A=6, algo="svea", dat
             "ms_per_update_min": min(walls) / steps * 1e3, "ms_per_update_max": max(walls) / steps * 1e3,
             "repeats": len(walls), "timed_s": sum(walls),
             "algo": f"{algo}+{data_aug}", "batch_per_gpu": B, "steps": steps,
-            "dtype": "f32" if precision == "f32" else "bf16 conv stack (f32 accumulate, f32 heads/optimizer)",
+            "dtype": "f32" if precision.startswith("f32") else "bf16 conv stack (f32 accumulate, f32 heads/optimizer)",
             "approx_TFLOP/s_per_gpu": flops * steps / wall / 1e12, "algorithmic_TFLOP/s": flops * steps / wall / 1e12,
             "executed_TFLOP/s": flops_exec["total"] * steps / wall / 1e12, "executed_GFLOP_per_update": flops_exec["total"] / 1e9,
             "executed_conv32_GFLOP_per_update": flops_exec["conv32"] / 1e9, "encoder_backend": "hip",

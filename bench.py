@@ -491,6 +491,12 @@ def main():
         try:
             res["sac"] = leg("f32")  # the parity path
             res["sac"]["bf16_mode"] = leg("bf16")
+            # the parity path's two other arithmetic forms on the same box, same harness (short legs): range-free bf16 triples
+            # (6 MFMAs per product group) and the native f32 MFMA pipe -- what the f16-pair kernels are measured against
+            if use_graph:
+                res["sac"]["other_f32_forms_ms_per_update"] = {
+                    p_: bench_update.run(dev, dist, world, rank, steps=max(10, n_upd // 2), precision=p_, graph=True, min_s=0.2)["ms_per_update"]
+                    for p_ in ("f32_x3", "f32_mfma")}
             res["sac"]["select_action_us"] = bench_update.action_latency(dev)  # batch-1 acting, eager vs captured graph
         except Exception as e:  # noqa: BLE001 -- the headline above is measured: report the failure, do not lose the line
             import traceback
