@@ -42,6 +42,7 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 constexpr int X2_SLOT = 144;       // LDS bytes per pixel slot: 2 planes x 64 B + 16 B pad (36 p mod 64 dwords: 16 consecutive
                                    // pixels x one 16-byte chunk fall into 16 distinct bank quads)
 constexpr int X2_NU = 2;           // loader rounds per strip: 256 lanes x X2_NU units of (4 pixels x 8 channels)
+constexpr int X2_ROWPAD = 224;     // forward: extra bytes per LDS tile row (14 chunks of 16 B: see k_conv32_x2's row pitch)
 constexpr int X2_HDR = 512;        // LDS in front of the tiles: +-bias (2 x 128 B), the maximum's two words, spare
 constexpr int X2_MAXTILE = 81664;  // bytes per tile buffer: 2 x this + X2_HDR <= 160 KiB
 constexpr int X2_FRAG_VU4 = 2 * 18 * 64; // 16-byte entries per layer block, then one entry whose first word is the weights' exponent
@@ -93,6 +94,7 @@ struct ConvX2Args {
     uint32_t magic_wo;   // floor(2^32 / Wo) + 1
     uint32_t magic_s;    // floor(2^32 / S) + 1 (S == 1 is tested for)
     uint32_t magic_qw;   // MODE 1: floor(2^32 / QW) + 1, QW = quads per dZ row
+    uint32_t magic_wi;   // MODE 0: floor(2^32 / Wi) + 1
     const float *bias2;  // two-weight-set forward: images [B/2, B) use wfrag2 / bias2 (odd workgroups)
     int dual;
     const vu4 *wfrag, *wfrag2; // prepared by k_x2_prep: [hi | lo'][18 operands][64 lanes] x 16 B, then the exponent
@@ -127,7 +129,13 @@ __global__ __launch_bounds__(512, 2) void k_conv32_x2(ConvX2Args a)
     const int Wi = a.Wi;
     const int Wl = MODE ? Wi + 2 : Wi;                     // LDS row pitch in pixels
     const int tilepix = (a.RT + 2) * Wl + (MODE ? 2 : 0);
-    const int bufbytes = tilepix * X2_SLOT;
+    // LDS bytes between tile rows.  A 32-pixel tile crosses one or two output-row ends; backward-data's rows are as long as its
+    // output's (W + 2), so consecutive pixels are consecutive slots and a 16-lane read group never meets a bank twice.  The
+    // forward's tile row is TWO slots longer than an output row: 14 chunks of padding per row make the chunk index
+    // 9 (y Wl + x) + 14 y = 9 m + 32 y linear in the pixel number m again (mod 16) -- without it a third of the forward
+    // kernels' LDS cycles were bank-conflict cycles (profiles/r03_x2_pmc.txt), against 6 % in backward-data.
+    const int rowb = Wl * X2_SLOT + (MODE ? 0 : X2_ROWPAD);
+    const int bufbytes = tilepix * X2_SLOT + (MODE ? 0 : (a.RT + 2) * X2_ROWPAD);
     float *lbias = reinterpret_cast<float *>(ldsx);        // [0..32) +bias s_in s_w, [32..64) the same negated
     char *tiles = ldsx + X2_HDR;
     const int grp = a.dual ? (int)(blockIdx.x & 1) : 0, nhalf = a.n_items >> 1;
@@ -242,8 +250,10 @@ __global__ __launch_bounds__(512, 2) void k_conv32_x2(ConvX2Args a)
                         split2h(__uint_as_float(R.d[u][2 * e][j]) * s, __uint_as_float(R.d[u][2 * e + 1][j]) * s, th, tl);
                         hi[e] = th; lo[e] = tl;
                     }
-                    *reinterpret_cast<vu4 *>(o + j * X2_SLOT) = hi;
-                    *reinterpret_cast<vu4 *>(o + j * X2_SLOT + 64) = lo;
+                    // forward: the quad may straddle a row end of the contiguous run: every pixel takes its own row's padding
+                    const int pad = MODE ? 0 : (int)__umulhi((uint32_t)(min(4 * (q0 + 64 * u), g.nrow * Wi - 4) + j), a.magic_wi) * X2_ROWPAD;
+                    *reinterpret_cast<vu4 *>(o + j * X2_SLOT + pad) = hi;
+                    *reinterpret_cast<vu4 *>(o + j * X2_SLOT + pad + 64) = lo;
                 }
             }
             if (MODE == 1) {
@@ -294,7 +304,6 @@ __global__ __launch_bounds__(512, 2) void k_conv32_x2(ConvX2Args a)
         wh[i] = __builtin_bit_cast(f16x8, wfrag[i * 64 + lane]);
         wl[i] = __builtin_bit_cast(f16x8, wfrag[(18 + i) * 64 + lane]);
     }
-    const int rowb = Wl * X2_SLOT; // LDS bytes between tile rows
     const int relu_floor = __builtin_amdgcn_readfirstlane(a.relu ? 0 : (int)0x80000000); // opaque: stays ONE v_max_i32
     // raw buffer resources: the output's is bounded by the tensor's size, so a lane with nothing to store just names an offset
     // beyond it (kNoStore): the hardware drops the store and the epilogue needs no branch
@@ -342,7 +351,7 @@ __global__ __launch_bounds__(512, 2) void k_conv32_x2(ConvX2Args a)
             valid_ = m_ < npix;
             if (!valid_) m_ = npix - 1; // read a real pixel, discard the result
             const int yy_ = (int)__umulhi((uint32_t)m_, a.magic_wo), xx_ = m_ - yy_ * a.Wo;
-            off_ = (yy_ * Wl + xx_) * X2_SLOT + h * 16;
+            off_ = yy_ * rowb + xx_ * X2_SLOT + h * 16;
             boff_ = (unsigned)((b * 32 * a.Ho + (y0 + yy_)) * a.Wo + xx_ + 4 * h * chw) * 4u;
         };
         struct Ops {
@@ -850,7 +859,7 @@ int launch_conv_x2(ConvX2Args &a, const char *name, hipStream_t s)
     const int Wl = MODE ? Wi + 2 : Wi;
     if (Wi < (MODE ? 5 : 4)) return 1; // a quad of 4 pixels per unit; MODE 1 divides by QW >= 2
     // rows per strip: the tile fits its LDS buffer and one strip is X2_NU rounds of loader units
-    int rt = (X2_MAXTILE / X2_SLOT - (MODE ? 2 : 0)) / Wl - 2;
+    int rt = MODE ? (X2_MAXTILE / X2_SLOT - 2) / Wl - 2 : X2_MAXTILE / (Wl * X2_SLOT + X2_ROWPAD) - 2;
     const int QW = (Wi + 3) >> 2;
     rt = std::min(rt, (MODE ? 64 * X2_NU / QW : 256 * X2_NU / Wi) - 2); // quads of the tile's RT + 2 input rows <= 64 * X2_NU
     if (rt < 1) return 1;
@@ -877,9 +886,10 @@ int launch_conv_x2(ConvX2Args &a, const char *name, hipStream_t s)
     a.n_items = a.B * a.S;
     a.magic_wo = (uint32_t)(0x100000000ull / (unsigned)a.Wo) + 1u;
     a.magic_qw = (uint32_t)(0x100000000ull / (unsigned)QW) + 1u;
+    a.magic_wi = (uint32_t)(0x100000000ull / (unsigned)Wi) + 1u;
     a.magic_s = (uint32_t)(0x100000000ull / (unsigned)a.S) + 1u; // S == 1 wraps to 1: handled in the kernel
     const int tilepix = (a.RT + 2) * Wl + (MODE ? 2 : 0);
-    const size_t lds = (size_t)X2_HDR + 2 * (size_t)tilepix * X2_SLOT;
+    const size_t lds = (size_t)X2_HDR + 2 * ((size_t)tilepix * X2_SLOT + (MODE ? 0 : (size_t)(a.RT + 2) * X2_ROWPAD));
     if (lds > 160 * 1024) return 1; // (cannot happen: rt is bounded by X2_MAXTILE)
 #ifdef AUGCL_TUNING
     a.abl = getenv("AUGCL_X2_ABL") ? atoi(getenv("AUGCL_X2_ABL")) : 0;

@@ -4,7 +4,10 @@ two weight sets), the no-grad single forward (B = 256), forward + backward (B = 
 import sys, time, numpy as np, torch
 tree = sys.argv[1] if len(sys.argv) > 1 else "."
 sys.path.insert(0, tree.split(":")[0])
-from augcl_amd import encoder_ops, encoder_hip
+import os
+from augcl_amd import _lib, encoder_ops, encoder_hip
+if os.environ.get("AUGCL_LIB"):  # A/B of two library builds of the SAME tree (same ABI): AUGCL_LIB=tools/libaugcl_variant.so
+    _lib.LIB_PATH = os.path.abspath(os.environ["AUGCL_LIB"])
 if tree.endswith(":nobits"):
     encoder_hip._GATE_BITS = False
 dev = torch.device("cuda:0")
