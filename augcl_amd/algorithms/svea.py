@@ -56,7 +56,12 @@ class SVEA(RAD):
         static = self._graph["static"] if self._graph is not None and self._graph["seen"] >= self._graph["warmup"] else None
         if static is not None and static[0].shape[0] != 2 * replay_buffer.batch_size:
             static = None  # another batch size: the graphs are about to be re-captured
-        return fused(out=None if static is None else static[0])
+        if static is None:
+            return fused()
+        try:  # the graph's static obs_both / next_obs tensors are written in place: nothing to copy before the replay
+            return fused(out=static[0], out_next=static[3])
+        except TypeError:  # a buffer whose sample_shift_conv predates out_next
+            return fused(out=static[0])
 
     def _front_end(self, obs, action, reward, next_obs, not_done, out=None):
         """svea.py:66-68.  Returns (obs_both | obs, action, reward, next_obs, not_done): with the fused front end

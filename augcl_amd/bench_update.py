@@ -27,13 +27,36 @@ class _SyntheticReplay:
         return self.items[self.i % len(self.items)]
 
 
+def _ring_replay(dev, B, A, transitions=3000, seed=0):
+    """The product's ReplayBuffer (augcl_amd/replay.py: uint8 frame ring in HBM, frames stored once) filled with `transitions`
+    steps of synthetic 3-frame-stacked episodes -- update() then samples it as the training loop does (SVEA: sample + shift +
+    conv in one pass over the ring, next_obs gathered into the graph's static input)."""
+    import numpy as np
+    from .replay import LazyFrames, ReplayBuffer
+    rs = np.random.RandomState(seed)
+    buf = ReplayBuffer((9, 84, 84), (A,), capacity=transitions + 64, batch_size=B, device=dev)
+    frames = [rs.randint(0, 256, (3, 84, 84)).astype(np.uint8) for _ in range(3)]
+    obs = LazyFrames(list(frames))
+    for t in range(transitions):
+        frames = frames[1:] + [rs.randint(0, 256, (3, 84, 84)).astype(np.uint8)]
+        nxt = LazyFrames(list(frames))
+        done = (t % 500) == 499
+        buf.add(obs, rs.uniform(-1, 1, A).astype(np.float32), float(rs.uniform(0, 4)), nxt, done)
+        if done:
+            frames = [rs.randint(0, 256, (3, 84, 84)).astype(np.uint8) for _ in range(3)]
+            obs = LazyFrames(list(frames))
+        else:
+            obs = nxt
+    return buf
+
+
 class _NullLogger:
     def log(self, key, value, step, n=1):
         pass
 
 
 def run(dev, dist, world, rank, steps=20, warmup=4, B=256, A=6, algo="svea", data_aug="conv", precision="f32", graph=False,
-        min_s=0.5):
+        min_s=0.5, replay="synthetic"):
     from . import dist as apdist
     from . import encoder_ops
     from . import utils as au
@@ -54,7 +77,7 @@ def run(dev, dist, world, rank, steps=20, warmup=4, B=256, A=6, algo="svea", dat
     if graph:  # replay the learning part of update() as captured hipGraphs (SAC.enable_hip_graphs)
         agent.enable_hip_graphs()
         warmup = max(warmup, 8)  # 3 eager updates, then one capture per (actor step?, target step?) variant
-    buf = _SyntheticReplay(dev, B, A, seed=100 + rank)
+    buf = _SyntheticReplay(dev, B, A, seed=100 + rank) if replay == "synthetic" else _ring_replay(dev, B, A, seed=100 + rank)
     L = None  # no logging inside the timed region (the reference's Logger syncs per scalar)
     for s in range(warmup):
         agent.update(buf, L, s)

@@ -497,6 +497,10 @@ def main():
                 res["sac"]["other_f32_forms_ms_per_update"] = {
                     p_: bench_update.run(dev, dist, world, rank, steps=max(10, n_upd // 2), precision=p_, graph=True, min_s=0.2)["ms_per_update"]
                     for p_ in ("f32_x3", "f32_mfma")}
+                # ... and the same update() fed by the product's uint8 replay ring instead of pre-staged float batches (SVEA's
+                # sample + shift + conv as one pass over the ring; next_obs gathered straight into the graph's static input)
+                res["sac"]["from_uint8_replay_ring_ms_per_update"] = bench_update.run(
+                    dev, dist, world, rank, steps=max(10, n_upd // 2), precision="f32", graph=True, min_s=0.2, replay="ring")["ms_per_update"]
             res["sac"]["select_action_us"] = bench_update.action_latency(dev)  # batch-1 acting, eager vs captured graph
         except Exception as e:  # noqa: BLE001 -- the headline above is measured: report the failure, do not lose the line
             import traceback

@@ -204,6 +204,16 @@ def test_fused_sample_shift_conv_equals_sample_then_front_end(cuda):
         assert torch.equal(both, want), "fused front end differs from sample() + shift_conv"
         for x, y in ((act, act2), (rew, rew2), (nobs, nobs2), (nd, nd2)):
             assert torch.equal(x, y)
+    # out / out_next: the same values written into caller-owned tensors (a hipGraph's static inputs)
+    np.random.seed(21)
+    aug.manual_seed(5)
+    ref = rb.sample_shift_conv()
+    np.random.seed(21)
+    aug.manual_seed(5)
+    o1, o2 = torch.full_like(ref[0], float("nan")), torch.full_like(ref[3], float("nan"))
+    got = rb.sample_shift_conv(out=o1, out_next=o2)
+    assert got[0].data_ptr() == o1.data_ptr() and got[3].data_ptr() == o2.data_ptr()
+    assert torch.equal(o1, ref[0]) and torch.equal(o2, ref[3])
     # SVEA through the fused path walks the same trajectory as through sample() + its own front end
     snaps = []
     for fused in (True, False):
