@@ -4,16 +4,16 @@
 //
 // An f16 carries 11 significand bits.  With a per-tensor power of two s (exact) that brings max|x| into [2^14, 2^15),
 //     x s = hi + lo' 2^-11,   hi = f16(x s),   lo' = f16((x s - hi) 2^11)        (both round-to-nearest-even)
-// holds to 2^-24 relative for every element down to 2^-29 of the tensor's maximum (below that the absolute error stays
-// under 2^-36 of the maximum: hi goes subnormal, lo' still holds 11 bits of the residual).  f16 x f16 products are exact in
+// holds to 2^-23 relative for every element down to 2^-26 of the tensor's maximum and to 2^-21 down to 2^-29 (lo', then hi
+// go subnormal); below that the absolute error stays under 2^-36 of the maximum (tests/test_f16_pair_numerics.py).  f16 x f16 products are exact in
 // f32, the MFMA accumulates in f32, and of the four cross products hh + (h l' + l' h) 2^-11 + l' l' 2^-22 the last one is
 // below float32's resolution.  Measured on this chip (tools/x3probe.hip, K = 288, against float64): 1.36e-7 relative L2 for
 // the three products (all four: 1.29e-7; split-bf16 six products: 2.6e-7; native f32 MFMA chain: 3.0e-7).  The main
 // product accumulates in one register set, the two cross products in a second one that is scaled by 2^-11 at the end.
 //
 // What f16 lacks is float32's exponent range, hence the scales: every producer of an activation / gradient tensor on this
-// path leaves max|x| next to it (one v_max per output value, one atomic per wave), every consumer derives s from it.  The
-// weights' maximum is taken by the fragment-preparation launch.  Tensors whose elements span more than 2^29 lose RELATIVE
+// path leaves max|x| next to it (one v_max per output value, one atomic per workgroup), every consumer derives s from it.  The
+// weights' maximum is taken by the fragment-preparation launch.  Tensors whose elements span more than 2^26 lose RELATIVE
 // accuracy in their smallest elements (not in any norm); the split-bf16 kernels (precision "f32_x3") have no such limit.
 //
 // The f16 MFMA's accumulation is biased toward -infinity like the bf16 one's, 16x less (-9e-11 sum|w x| per output): each

@@ -320,7 +320,8 @@ int augcl_enc_x3_conv32_backward_weights(const float *act_prev /* (B,32,Hi,Wi) *
  * kernel leaves the maximum of what it stores; a single layer takes them as arguments (device floats, exact maxima or upper
  * bounds within 2x) and can return its output's (amax_out, may be NULL; overwritten, not accumulated).
  * frag_ws: augcl_enc_frag_workspace_bytes(1, 1) bytes of device scratch, 16-byte aligned (the layer's weight fragments).
- * Elements smaller than 2^-29 of their tensor's maximum lose relative accuracy (absolute error < 2^-36 of the maximum);
+ * Elements smaller than 2^-26 of their tensor's maximum lose relative accuracy (2^-21 at 2^-29; absolute error < 2^-36 of
+ * the maximum below);
  * shapes the kernels do not cover run augcl_enc_x3_*. */
 int augcl_enc_amax_f32(const float *x, size_t n, float *amax_out /* device, 1 float */, augcl_stream_t stream);
 int augcl_enc_x2_conv32_forward(const float *in, const float *w, const float *bias, float *out, int B, int Hi, int Wi, int relu,
@@ -361,8 +362,9 @@ int augcl_enc_nchw_f32_to_nhwc_bf16(const float *in, void *out_bf16_nhwc, int B,
  * with the 32 -> 32 layers on the split-bf16 kernels (augcl_enc_x3_*: float32-accurate, no range limit), 3 = f32 NCHW with
  * the 32 -> 32 layers on the f16-pair kernels (csrc/encoder_x2.hip: every operand = hi + lo' 2^-11 in f16 under a per-tensor
  * power-of-two scale, three v_mfma_f32_32x32x16_f16 per product group -- 1.4e-7 relative L2 against float64 at K = 288, half
- * the matrix instructions of 2; the default parity path).  Precision 3 keeps float32 accuracy for every element within
- * 2^29 of its tensor's largest magnitude; smaller elements keep an absolute error below 2^-36 of that maximum.
+ * the matrix instructions of 2; the default parity path).  Precision 3 keeps float32 accuracy (2^-23) for every element
+ * within 2^26 of its tensor's largest magnitude, 2^-21 within 2^29; smaller elements keep an absolute error below 2^-36 of
+ * that maximum.
  * forward: acts_out[i] = output buffer of layer i (the last layer always writes f32 NCHW).
  * backward: acts_in[i] = input of layer i (acts_in[0] = the raw f32 image batch); dz_a / dz_b = two scratch buffers
  * of the largest activation's size; dw[i] / db[i] receive the weight / bias gradients.
