@@ -34,6 +34,8 @@ class AugCL(RAD):
         own = self.critic.encoder.shared_cnn.precision  # the aliased critic now computes inside THIS agent's update()
         for m in self._cnn_modules():
             m.precision = own
+        if self._act is not None:  # acting graphs captured earlier replay the old precision's kernels
+            self._act["graphs"] = {}
         if self._graph is not None:  # graphs captured before the hand-off reference the old weak critic
             self.critic_weak_optimizer.make_capturable()
             self._graph.update(graphs={}, static=None, pool=None, seen=0)

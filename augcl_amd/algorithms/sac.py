@@ -302,6 +302,8 @@ class SAC(object):
             m.precision = name
         if getattr(self, "_graph", None) is not None:
             self._graph["graphs"].clear()
+        if getattr(self, "_act", None) is not None:  # the acting graphs replay the old precision's kernels as well
+            self._act["graphs"] = {}
         return self
 
     def enable_hip_graphs(self, warmup=3):

@@ -1,9 +1,27 @@
 """SVEA (src/algorithms/svea.py:9-76): random_shift on obs, then two critic passes -- the shifted
 batch and its strongly augmented copy -- against one un-augmented target, weighted alpha / beta."""
+import inspect
+
 import torch
 
 from .. import augmentations, head_ops
 from .rad import RAD
+
+
+def _accepts(fn, name):
+    key = getattr(fn, "__func__", fn)
+    hit = _accepts.cache.get(key)
+    if hit is None or hit[0] != name:
+        try:
+            params = inspect.signature(fn).parameters
+            ok = name in params or any(p.kind is inspect.Parameter.VAR_KEYWORD for p in params.values())
+        except (TypeError, ValueError):
+            ok = False
+        _accepts.cache[key] = hit = (name, ok)
+    return hit[1]
+
+
+_accepts.cache = {}
 
 
 class SVEA(RAD):
@@ -58,10 +76,12 @@ class SVEA(RAD):
             static = None  # another batch size: the graphs are about to be re-captured
         if static is None:
             return fused()
-        try:  # the graph's static obs_both / next_obs tensors are written in place: nothing to copy before the replay
+        # the graph's static obs_both / next_obs tensors are written in place: nothing to copy before the replay.  Whether
+        # the buffer's sample_shift_conv takes out_next is read off its signature ONCE -- catching TypeError around the
+        # call would also swallow one raised inside it, after the index draw had advanced the RNG streams
+        if _accepts(fused, "out_next"):
             return fused(out=static[0], out_next=static[3])
-        except TypeError:  # a buffer whose sample_shift_conv predates out_next
-            return fused(out=static[0])
+        return fused(out=static[0])
 
     def _front_end(self, obs, action, reward, next_obs, not_done, out=None):
         """svea.py:66-68.  Returns (obs_both | obs, action, reward, next_obs, not_done): with the fused front end

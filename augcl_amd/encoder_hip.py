@@ -25,16 +25,25 @@ def _workspace(dev, c_in, count=1):
 _fws = {}
 
 
+_FWS_MAX_LAYERS32 = 32  # the C ABI's limit (augcl_enc_stack_*: at most 33 layers), two weight sets
+
+
 def _frag_ws(dev, n_layers32, sets=1):
-    """scratch for the prepared weight fragments of the split-bf16 layers (augcl_enc_stack_*'s frag_ws): one buffer per
-    device, sized for the largest request; its contents only live inside one stack call"""
-    need = _lib.load().augcl_enc_frag_workspace_bytes(int(n_layers32), int(sets))
+    """scratch for the prepared weight fragments of the split layers (augcl_enc_stack_*'s frag_ws): ONE buffer per device,
+    allocated once at the ABI's maximum (32 layers x 2 weight sets, ~3.5 MB) and never replaced -- captured hipGraphs bake
+    its address in, so growing it on demand would leave them writing into freed memory (the acting graph is captured with
+    one weight set, the first update() then asks for two).  Its contents only live inside one stack call."""
+    lib = _lib.load()
+    need = lib.augcl_enc_frag_workspace_bytes(int(n_layers32), int(sets))
     t = _fws.get(dev)
-    if t is None or t.numel() < need:
+    if t is None:
         if dev.type == "cuda" and torch.cuda.is_current_stream_capturing():
             raise _lib.AugclError("weight-fragment workspace requested for the first time inside a hipGraph capture; run one "
                                   "eager update first (SAC.enable_hip_graphs keeps warmup >= 1)")
-        t = _fws[dev] = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
+        t = _fws[dev] = torch.empty(max(lib.augcl_enc_frag_workspace_bytes(_FWS_MAX_LAYERS32, 2), 16), dtype=torch.uint8,
+                                    device=dev)
+    if t.numel() < need:
+        raise _lib.AugclError(f"weight-fragment workspace: {n_layers32} layers x {sets} sets exceed the ABI maximum")
     return t
 
 

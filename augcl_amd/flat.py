@@ -252,7 +252,13 @@ class FlatAdam:
             if missing:
                 raise _lib.AugclError("FlatAdam: parameters without a gradient cannot be skipped inside a captured hipGraph "
                                       f"(no gradient for {missing[:3]}...)")
-            self._tensor_steps = None  # per-tensor counts left over from a resume, nothing missing now: the plain path
+            if len(set(self._tensor_steps.values())) != 1:
+                # tensors that lag behind (partial eager steps before make_capturable) need their own bias correction; the
+                # captured launch has ONE device-side count for the whole group
+                raise _lib.AugclError("FlatAdam: per-tensor step counts differ "
+                                      f"({sorted(set(self._tensor_steps.values()))}); a captured hipGraph steps every tensor "
+                                      "with one count -- bring the group to a common count eagerly first")
+            self._tensor_steps = None  # equal per-tensor counts left over from a resume, nothing missing now: the plain path
             return self._apply((), reduced=True, scale=scale)
         if self._tensor_steps is None:
             self._tensor_steps = {n: self._step_count for n in g.names}

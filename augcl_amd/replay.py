@@ -153,7 +153,8 @@ class ReplayBuffer(object):
             per = max(1.0, float(self.obs_seq[newest].max() - self.obs_seq[oldest].min() + 1) / span)
             need = int(np.ceil((per - 1.0) * self.capacity)) + 4 * self.stack + 16
             raise _lib.AugclError(
-                f"replay frame ring too small: this stream stores {per:.2f} new frames per transition, so {self.capacity} "
+                f"replay frame ring too small ({self._adds} transitions stored, {self.frame_seq} frames): this stream stores "
+                f"{per:.2f} new frames per transition, so {self.capacity} "
                 f"live transitions need more than the {self.n_slots} slots of the ring; construct "
                 f"ReplayBuffer(..., frame_slack={need}) or more")
 
@@ -324,6 +325,7 @@ class ReplayBuffer(object):
             self.rewards[start:end] = payload["rewards"].to(self.device)
             self.not_dones[start:end] = payload["not_dones"].to(self.device)
             self.idx = end
+            self._adds += end - start  # loaded transitions count as stored ones (the counters of a resumed run)
             if end == end_step:
                 break
         self._ids.clear()
@@ -336,11 +338,13 @@ class ReplayBuffer(object):
     def state_dict(self):
         return dict(frames=self.frames.cpu(), frame_seq=self.frame_seq, obs_seq=self.obs_seq.copy(),
                     next_seq=self.next_seq.copy(), actions=self.actions.cpu(), rewards=self.rewards.cpu(),
-                    not_dones=self.not_dones.cpu(), idx=self.idx, full=self.full)
+                    not_dones=self.not_dones.cpu(), idx=self.idx, full=self.full, adds=self._adds)
 
     def load_state_dict(self, sd):
         self.frames.copy_(sd["frames"])
         self.frame_seq, self.idx, self.full = int(sd["frame_seq"]), int(sd["idx"]), bool(sd["full"])
+        # transitions ever stored: saved by state_dict(); a dict from before that field = the live transitions
+        self._adds = int(sd.get("adds", self.capacity if self.full else self.idx))
         self.obs_seq[:], self.next_seq[:] = sd["obs_seq"], sd["next_seq"]
         self._sync_tables()
         self.actions.copy_(sd["actions"])

@@ -167,7 +167,28 @@ def test_chunked_save_and_load_like_the_reference(cuda, tmp_path):
     # end_step stops after the chunk that ends there; a gap in the chunk sequence is refused like the reference
     rb3 = ReplayBuffer((9, 84, 84), (A,), cap, B, device=cuda)
     rb3.load(d, end_step=30)
-    assert rb3.idx == 30
+    assert rb3.idx == 30 and rb3._adds == 30
+    # the counters of a resumed run (src/utils.py:177-204 restores idx; here also the transitions ever stored): load() and
+    # load_state_dict() carry them over, and the ring-overwrite message of a RESUMED buffer asks for the slack its stream
+    # needs -- the same figure a buffer that saw the whole stream reports, not one inflated by the lost counters
+    assert rb2._adds == 40
+    rb4 = ReplayBuffer((9, 84, 84), (A,), cap, B, device=cuda)
+    rb4.load_state_dict(rb2.state_dict())
+    assert rb4._adds == 40 and rb4.idx == 40
+    from augcl_amd import _lib
+
+    def overrun(buf):
+        with pytest.raises(_lib.AugclError, match="frame_slack") as ei:
+            for fo, a, r, fn, done in gi.replay_stream(seed=33, n=6 * cap, A=A, ep_len=2):
+                buf.add(LazyFrames(fo), a, r, LazyFrames(fn), done)
+        msg = str(ei.value)
+        return int(msg.split("frame_slack=")[1].split(")")[0]), int(msg.split("(")[1].split(" transitions")[0])
+    fresh = ReplayBuffer((9, 84, 84), (A,), cap, B, device=cuda)
+    for fo, a, r, fn, done in stream:
+        fresh.add(LazyFrames(fo), a, r, LazyFrames(fn), done)
+    (need_f, adds_f), (need_r, adds_r), (need_s, adds_s) = overrun(fresh), overrun(rb2), overrun(rb4)
+    assert adds_f == adds_r == adds_s and adds_f > 40
+    assert need_r == need_f == need_s and need_f < 4 * cap  # 2-step episodes: ~2 new frames per transition, not dozens
     os.remove(os.path.join(d, "0_15.tar"))
     with pytest.raises(AssertionError):
         ReplayBuffer((9, 84, 84), (A,), cap, B, device=cuda).load(d)

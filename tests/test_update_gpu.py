@@ -361,10 +361,22 @@ def test_action_graphs_match_eager_and_follow_training(cuda, tmp_path):
     batch = (torch.randint(0, 256, (B, 9, 84, 84), device=cuda, generator=g).float(), torch.rand(B, 6, device=cuda) * 2 - 1,
              torch.rand(B, 1, device=cuda), torch.randint(0, 256, (B, 9, 84, 84), device=cuda, generator=g).float(),
              torch.ones(B, 1, device=cuda))
+    # the weight-fragment workspace the acting graph baked in (one weight set) must be the very buffer the update's dual
+    # forward (two weight sets) uses: a buffer replaced on growth would leave the graph writing into freed memory
+    from augcl_amd import encoder_hip
+    fws_ptr, fws_len = encoder_hip._fws[cuda].data_ptr(), encoder_hip._fws[cuda].numel()
     for step in range(2):
         agent.update(FakeBuffer(batch), None, step)
+    assert encoder_hip._fws[cuda].data_ptr() == fws_ptr and encoder_hip._fws[cuda].numel() == fws_len
+    assert encoder_hip._frag_ws(cuda, 32, 2).data_ptr() == fws_ptr  # the ABI's maximum fits without a new allocation
     after = agent.select_action(frames[1])
     assert not np.array_equal(after, eager[1])
+    agent.set_precision("f32_x3")  # another arithmetic: the acting graphs are dropped with the update graphs
+    assert agent._act["graphs"] == {}
+    x3 = agent.select_action(frames[1])
+    assert np.allclose(x3, after, atol=1e-5)
+    agent.set_precision("f32")
+    assert np.array_equal(agent.select_action(frames[1]), after)
     agent._act = None
     assert np.array_equal(agent.select_action(frames[1]), after)  # eager on the trained weights == the old graph
     agent.enable_action_graphs()

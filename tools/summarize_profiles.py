@@ -11,7 +11,7 @@ rnd = sys.argv[1]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = lambda n: os.path.join(ROOT, "gpurun_out", f"{rnd}_{n}")  # noqa: E731
 tag = "r%02d" % int(rnd[1:])
-out = os.path.join(ROOT, "profiles")
+out = os.environ.get("AUGCL_PROFILES_OUT", os.path.join(ROOT, "profiles"))
 # hash of the source tree whose binary produced these counters (written on the box by tools/profile_round.sh)
 SRC_HASH = open(G("source_hash.txt")).read().strip() if os.path.exists(G("source_hash.txt")) else None
 sys.path.insert(0, ROOT)
@@ -186,24 +186,50 @@ for prec, elem in (("f32", 4), ("bf16", 2)):
                 den += v[counter]["n"]
         return num / den if den else None
 
-    rows, tot_b, tot_t = {}, 0.0, 0.0
+    # Kernels are merged BY ROLE before the launch mix is applied: several instantiations share a role (k_conv32_x2<0,0>, the
+    # no-grad / dual forward, and k_conv32_x2<0,1>, the gradient-carrying forward that also writes gate bits, are both "fwd"),
+    # and round 3's per-kernel loop added the whole role's launches and bytes once per instantiation (conv_us_per_update came
+    # out larger than the update itself).  The time per update is MEASURED: every conv kernel's total time in the trace over
+    # the number of update() calls in it (= launches of the first layer's backward-weights kernel, one per update).
+    by_role = {}
     for name, (calls, total_us) in times.items():
         role = role_of(name)
         if role is None or "augcl::" not in name:
             continue
+        by_role.setdefault(role, []).append((name, calls, total_us))
+    n_upd = sum(c for _, c, _ in by_role.get("wfirst", [])) or None
+    rows, tot_b, tot_t = {}, 0.0, 0.0
+    for role, ks in by_role.items():
         launches, bytes_upd = mix[role]
-        avg_us = total_us / calls
-        ent = {"role": role, "avg_us": round(avg_us, 2), "launches_per_update": launches,
-               "algorithmic_bytes_per_launch": int(bytes_upd / launches), "algorithmic_GBps": round(bytes_upd / launches / avg_us / 1e3, 1)}
-        f_kb, w_kb = pmc_avg(fetch, name, "FETCH_SIZE"), pmc_avg(write, name, "WRITE_SIZE")
-        if f_kb is not None and w_kb is not None:
-            ent["hbm_bytes_per_launch"] = int(2 * f_kb * 1024 + w_kb * 1024)
-            ent["traffic_over_algorithmic"] = round(ent["hbm_bytes_per_launch"] / ent["algorithmic_bytes_per_launch"], 3)
-        rows[name.split("(")[0][:70]] = ent
+        calls = sum(c for _, c, _ in ks)
+        total_us = sum(t for _, _, t in ks)
+        us_per_update = total_us / n_upd if n_upd else total_us / calls * launches
+        ent = {"kernels": {n.split("(")[0][:70]: {"calls": c, "avg_us": round(t / c, 2)} for n, c, t in ks},
+               "launches_per_update_assumed": launches, "launches_per_update_in_trace": round(calls / n_upd, 2) if n_upd else None,
+               "us_per_update": round(us_per_update, 1), "algorithmic_bytes_per_update": int(bytes_upd),
+               "algorithmic_GBps": round(bytes_upd / us_per_update / 1e3, 1)}
+        hb = 0.0
+        for n, c, _ in ks:  # PMC traffic: per-launch averages of each instantiation, weighted by its share of the role's launches
+            f_kb, w_kb = pmc_avg(fetch, n, "FETCH_SIZE"), pmc_avg(write, n, "WRITE_SIZE")
+            if f_kb is None or w_kb is None:
+                hb = None
+                break
+            hb += (2 * f_kb * 1024 + w_kb * 1024) * c / calls * launches
+            ent["kernels"][n.split("(")[0][:70]]["hbm_bytes_per_launch"] = int(2 * f_kb * 1024 + w_kb * 1024)
+        if hb is not None:
+            ent["hbm_bytes_per_update"] = int(hb)
+            ent["traffic_over_algorithmic"] = round(hb / bytes_upd, 3)
+        rows[role] = ent
         tot_b += bytes_upd
-        tot_t += avg_us * launches
-    upd[prec] = {"kernels": rows, "conv_us_per_update": round(tot_t, 1), "conv_algorithmic_MB_per_update": round(tot_b / 1e6, 1),
+        tot_t += us_per_update
+    upd[prec] = {"updates_in_trace": n_upd, "roles": rows, "conv_us_per_update": round(tot_t, 1),
+                 "conv_algorithmic_MB_per_update": round(tot_b / 1e6, 1),
                  "conv_GBps_time_weighted": round(tot_b / tot_t / 1e3, 1) if tot_t else None}
+    meas = G(f"update_{prec}_ms.txt")  # the same run's update() time, when the profiling script left it
+    if os.path.exists(meas):
+        ms = float(open(meas).read().split()[0])
+        upd[prec]["update_ms_same_run"] = ms
+        assert tot_t <= ms * 1e3 * 1.02, f"{prec}: conv kernels {tot_t:.0f} us per update exceed the update itself ({ms} ms)"
 if "f32" in upd or "bf16" in upd:
     json.dump(upd, open(os.path.join(out, f"{tag}_update_conv_traffic.json"), "w"), indent=1)
     for p_ in ("f32", "bf16"):
