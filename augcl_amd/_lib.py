@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_PKG, "libaugcl_hip.so")
 HEADER_PATH = os.path.join(_ROOT, "include", "augcl.h")
 
 AUGCL_OK = 0
+AUGCL_E_UNSUPPORTED = -3  # include/augcl.h
 
 
 class AugclError(RuntimeError):
@@ -126,6 +127,8 @@ _SIGS = {
     "augcl_enc_frag_workspace_bytes": [_I, _I],
     "augcl_enc_stack_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P, _SZ, _I, _I, _I, _I, _I, _I, _F, _I, _I, _P, _SZ, _P, _P, _P, _P],
     "augcl_enc_stack_forward_dual": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P, _SZ, _P, _P],
+    "augcl_enc_stack_infer_scratch_bytes": [_I, _I, _I, _I, _I, _I],
+    "augcl_enc_stack_infer": [_P, _P, _P, _P, _P, _P, _P, _SZ, _I, _I, _I, _I, _I, _I, _F, _P, _SZ, _P, _P],
     "augcl_replay_gather": [_P, _P, _P, _I, _I, _I, _I, _P],
     "augcl_enc_conv_first_forward": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
     "augcl_enc_conv32_forward": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
@@ -137,7 +140,8 @@ _SIGS = {
     "augcl_enc_conv32_backward_weights": [_P, _P, _P, _P, _P, _SZ, _I, _I, _I, _P],
     "augcl_enc_conv_first_backward_weights": [_P, _P, _P, _P, _P, _SZ, _I, _I, _I, _I, _I, _F, _P],
 }
-_RESTYPE = {"augcl_last_error": _c.c_char_p, "augcl_enc_wgrad_workspace_bytes": _SZ, "augcl_enc_frag_workspace_bytes": _SZ}
+_RESTYPE = {"augcl_last_error": _c.c_char_p, "augcl_enc_wgrad_workspace_bytes": _SZ, "augcl_enc_frag_workspace_bytes": _SZ,
+            "augcl_enc_stack_infer_scratch_bytes": _SZ}
 
 _lib = None
 
@@ -160,8 +164,8 @@ def load():
         fn.argtypes = argtypes
         fn.restype = _RESTYPE.get(name, _I)
     ver = lib.augcl_abi_version()
-    if ver != 3:
-        raise AugclError(f"libaugcl_hip.so ABI version {ver} != 3 (stale build: run `make -C augcl_amd/csrc`)")
+    if ver != 4:
+        raise AugclError(f"libaugcl_hip.so ABI version {ver} != 4 (stale build: run `make -C augcl_amd/csrc`)")
     _lib = lib
     return lib
 

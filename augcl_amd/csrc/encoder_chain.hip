@@ -1,0 +1,475 @@
+// encoder_chain.hip -- SEVERAL consecutive 32 -> 32 layers of the shared conv encoder (src/algorithms/modules.py:145-165) in
+// ONE launch, for passes whose intermediate activations nobody reads again: the two no-grad passes of
+// SAC.calculate_target_Q (src/algorithms/sac.py:94-101), the actor step's detached pass (sac.py:119-122) and acting
+// (sac.py:73-92).  Arithmetic = encoder_x2.hip's f16 pairs (float32-accurate products, three v_mfma_f32_32x32x16_f16 per
+// product group); what changes is where the data lives.
+//
+// A work item is (image, part): the rows of the chain's LAST layer that one workgroup produces.  Its input -- those rows plus
+// two halo rows per layer, all 32 channels -- is staged ONCE into a pixel-major LDS image (slot = f16 hi | lo' x 32 channels +
+// pad = 144 B, pitch = the input's width) and then every layer of the chain runs IN PLACE on that image: output pixel (y, x)
+// of layer j overwrites input pixel (y, x), which is dead as soon as every output pixel up to (y, x) in raster order has been
+// computed (a valid 3x3 convolution only looks right and down).  The four compute waves take the layer's 32-pixel tiles in
+// raster order, four at a time; ONE workgroup barrier per round separates the round's operand reads from its in-place writes
+// (a round only writes pixels in front of every later round's reads, and later tiles' operands are never behind a pixel a
+// round writes), one more per layer hands the layer's output over.  Nothing but the chain's input and its last layer's
+// output touches HBM: for the encoder's ten 32 -> 32 layers (chains 41 -> 33 in two half-image parts, 33 -> 21 whole
+// images) that is 1/5 of the per-layer kernels' bytes, 3 launches instead of 11, and no loader work beside the matrix waves
+// except the one staging pass per item.
+//
+// Scales.  An intermediate that never leaves the workgroup needs no tensor-wide maximum: layer j's output is stored under
+// 2^k with k from an A-PRIORI bound of THIS item's values, |y| <= max_co sum_{ci,t} |w[co][ci][t]| max|x| + max|b| (the
+// weights' row sums come with the prepared fragments, k_x2_prep), where max|x| is the exact maximum of the item's previous
+// layer (every epilogue takes the maximum of what it stores; one LDS atomic per wave and layer).  The bound is rigorous (no
+// overflow, no fallback) and does not compound: each layer's looseness (2^3..2^5) only costs that many bits at the BOTTOM
+// of f16's range (absolute error < 2^-36 of the bound), none of float32's 24.  The chain's input is scaled by its tensor's
+// maximum like encoder_x2.hip's (its producer leaves it).
+//
+// Loader waves: they fetch the NEXT item's whole input into registers (160 per lane) while the compute waves work, split it
+// there, and dump it into LDS between two barriers when the image is free -- the global loads of an item hide behind the
+// previous item's ~25 us of matrix work, and the only loader instructions that meet the matrix waves are ~450 per item.
+#include "encoder_x2_common.h"
+
+#include <algorithm>
+#include <type_traits>
+
+namespace augcl {
+
+constexpr int CH_MAXL = 6;    // layers per launch
+constexpr int CH_NU = 5;      // loader rounds per item: 256 lanes x CH_NU units of (4 pixels x 8 channels) = 1280 pixels
+constexpr int CH_HDR = 1024;  // LDS in front of the image: 4 x 128 B bias seeds (one copy per compute wave), the maxima
+
+struct ChainArgs {
+    const float *in;              // (B,32,Hi,Wi) f32 NCHW: input of the chain's first layer (post-ReLU activations)
+    float *out;                   // (B,32,Hi-2nl,Wi-2nl) f32 NCHW: output of its last layer
+    const float *bias[2][CH_MAXL]; // [weight set][layer] (32) or null
+    const vu4 *wfrag[2][CH_MAXL];  // prepared by k_x2_prep (mode 0)
+    int nl, B, Hi, Wi, parts, rows_out, relu_last, dual, n_items;
+    uint32_t magic_w[CH_MAXL];    // floor(2^32 / width of layer j's output) + 1
+    uint32_t magic_parts;         // floor(2^32 / parts) + 1 (parts == 1 is tested for)
+    const uint32_t *amax_in;      // max |in| (float bits); dual: [0] images [0, B/2), [1] images [B/2, B)
+    uint32_t *amax_out;           // max |out| is atomically max-ed into it (zeroed by the caller), or null; dual: [0], [1]
+};
+
+#ifdef AUGCL_TUNING
+// tuning builds: compute wave 0 of workgroup 0 adds up where its cycles go (s_memtime): [0] matrix loops, [1] waiting at the
+// round barriers, [2] epilogues, [3] layer hand-over (barrier + next layer's set-up), [4] item switch (F .. A), [5] rounds,
+// [6] whole kernel, [7] 100 MHz ticks of the whole kernel
+__device__ unsigned long long g_chain_clk[8];
+#define CH_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#else
+#define CH_STAMP(var)
+#endif
+
+struct ChainItem {
+    int b, y0, ny, grp;
+};
+
+__device__ __forceinline__ ChainItem chain_item(const ChainArgs &a, int item)
+{
+    ChainItem it;
+    it.b = a.parts == 1 ? item : (int)__umulhi((uint32_t)item, a.magic_parts);
+    const int p = item - it.b * a.parts;
+    it.y0 = p * a.rows_out;
+    it.ny = min(a.rows_out, a.Hi - 2 * a.nl - it.y0);
+    it.grp = (a.dual && it.b >= (a.B >> 1)) ? 1 : 0;
+    return it;
+}
+
+// rounds of four 32-pixel tiles that layer j of an item with ny final rows takes
+__device__ __forceinline__ int chain_rounds(const ChainArgs &a, int j, int ny)
+{
+    const int npix = (ny + 2 * (a.nl - 1 - j)) * (a.Wi - 2 * (j + 1));
+    return (((npix + 31) >> 5) + 3) >> 2;
+}
+
+__global__ __launch_bounds__(512, 2) void k_conv32_chain(ChainArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char ldsc[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = wave >= 4;
+    const int cw = wave & 3;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int Wi = a.Wi, nl = a.nl;
+    const int Hf = a.Hi - 2 * nl, Wf = Wi - 2 * nl;
+    uint32_t *lred = reinterpret_cast<uint32_t *>(ldsc + 512); // [j] max of layer j's stored (scaled) output of this item; [8..9]: kernel end
+    char *img = ldsc + CH_HDR;
+    const int G = (int)gridDim.x, n = a.n_items, first = xcd_slot((int)blockIdx.x, G);
+    const int rowb = Wi * X2_SLOT;
+
+    if (loader) {
+        const int lt = cw * 64 + lane;
+        const int cg = lt & 3, q0 = lt >> 2; // this lane's channel group (8 channels) and first pixel quad
+        const unsigned cs4 = (unsigned)(a.Hi * Wi) * 4u; // bytes per channel plane
+        const unsigned lane_c = (unsigned)cg * 8u * cs4;
+        const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.in), 0, -1, 0x00020000);
+        vu4 d[CH_NU][8]; // the next item: raw f32 (8 channels x 4 pixels per unit), then in place its f16 (hi | lo') pairs
+        int npx = 0;     // pixels of the staged item
+        auto issue = [&](int item) {
+            const ChainItem it = chain_item(a, item);
+            npx = (it.ny + 2 * nl) * Wi; // rows [y0, y0 + ny + 2 nl) of every channel plane: one contiguous run each
+            const unsigned base = (unsigned)((it.b * 32 * a.Hi + it.y0) * Wi) * 4u;
+#pragma unroll
+            for (int u = 0; u < CH_NU; ++u) {
+                if (256 * u < npx) { // wave-uniform: this round holds pixels of the run
+                    const int p0 = min(4 * (q0 + 64 * u), npx - 4); // units past the run repeat its last quad (idempotent)
+#pragma unroll
+                    for (int c = 0; c < 8; ++c)
+                        d[u][c] = __builtin_bit_cast(vu4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, lane_c + 4u * (unsigned)p0,
+                                                                                                 base + (unsigned)c * cs4, 0));
+                }
+            }
+        };
+        auto split = [&](int item) { // in place: d[u][2e], d[u][2e+1] (channels 2e, 2e+1 of 4 pixels) -> their hi dwords in d[u][2e], lo' in d[u][2e+1]
+            const ChainItem it = chain_item(a, item);
+            const float s = pow2f(scale_exp(__builtin_amdgcn_readfirstlane((int)a.amax_in[it.grp])));
+#pragma unroll
+            for (int u = 0; u < CH_NU; ++u) {
+                if (256 * u < npx) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            uint32_t th, tl;
+                            split2h(__uint_as_float(d[u][2 * e][j]) * s, __uint_as_float(d[u][2 * e + 1][j]) * s, th, tl);
+                            d[u][2 * e][j] = th; d[u][2 * e + 1][j] = tl;
+                        }
+                }
+            }
+        };
+        auto dump = [&]() { // registers -> the LDS image (slot = pixel of the run: the image's pitch is the input's width)
+#pragma unroll
+            for (int u = 0; u < CH_NU; ++u) {
+                if (256 * u < npx) {
+                    const int p0 = min(4 * (q0 + 64 * u), npx - 4);
+                    char *o = img + p0 * X2_SLOT + cg * 16;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        *reinterpret_cast<vu4 *>(o + j * X2_SLOT) = vu4{d[u][0][j], d[u][2][j], d[u][4][j], d[u][6][j]};
+                        *reinterpret_cast<vu4 *>(o + j * X2_SLOT + 64) = vu4{d[u][1][j], d[u][3][j], d[u][5][j], d[u][7][j]};
+                    }
+                }
+            }
+            if (lt < 16) lred[lt] = 0u; // the item's maxima: every read of the previous item's is behind us (barrier F)
+        };
+        if (first < n) {
+            issue(first);
+            split(first);
+            dump();
+        }
+        for (int item = first; item < n; item += G) {
+            __syncthreads(); // A: the image is ready
+            const int nxt = item + G;
+            if (nxt < n) issue(nxt);
+            const int ny = chain_item(a, item).ny;
+            int nb = 0; // the compute waves' barriers inside this item: one per round and one per layer, last layer excepted
+            for (int j = 0; j + 1 < nl; ++j) nb += chain_rounds(a, j, ny) + 1;
+            bool done = nxt >= n;
+            for (int i = 0; i < nb; ++i) {
+                if (!done && 2 * i >= nb) { // half way: the loads issued at the item's start have long landed
+                    split(nxt);
+                    done = true;
+                }
+                __syncthreads();
+            }
+            if (!done) split(nxt);
+            __syncthreads(); // F: every read of the image is done
+            if (nxt < n) dump();
+        }
+        return;
+    }
+
+    // ---- compute waves.  Operand i = (tap t = i / 2, channel half s = i & 1); A fragment: W[row l31][k = 16 s + 8 h + j][t], hi and lo'
+    // parts in registers for one layer; the next layer's are requested as soon as the layer's last matrix instruction is out.
+    f16x8 wh[18], wl[18];
+    auto load_weights = [&](const vu4 *wf) {
+#pragma unroll
+        for (int i = 0; i < 18; ++i) {
+            wh[i] = __builtin_bit_cast(f16x8, wf[i * 64 + lane]);
+            wl[i] = __builtin_bit_cast(f16x8, wf[(18 + i) * 64 + lane]);
+        }
+    };
+    float *lbias = reinterpret_cast<float *>(ldsc) + 32 * cw; // this wave's copy of the layer's bias seeds (accumulator scale)
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)((unsigned)(a.B * 32 * Hf * Wf) * 4u), 0x00020000);
+    constexpr unsigned kNoStore = 0xfffffff0u;
+    const int chw = Hf * Wf;
+    float vmax_out[2] = {0.0f, 0.0f}; // max |final output| per weight set (amax_out)
+#ifdef AUGCL_TUNING
+    unsigned long long c_mma = 0, c_wait = 0, c_epi = 0, c_layer = 0, c_item = 0, c_rounds = 0;
+    const unsigned long long t_kernel = __builtin_amdgcn_s_memtime(), r_kernel = __builtin_amdgcn_s_memrealtime();
+    unsigned long long t_mark = t_kernel;
+#endif
+    if (first < n) load_weights(a.wfrag[chain_item(a, first).grp][0]);
+
+    for (int item = first; item < n; item += G) {
+        const ChainItem it = chain_item(a, item);
+        __syncthreads(); // A
+#ifdef AUGCL_TUNING
+        { const unsigned long long t = __builtin_amdgcn_s_memtime(); c_item += t - t_mark; t_mark = t; }
+#endif
+        int k_in = scale_exp(__builtin_amdgcn_readfirstlane((int)a.amax_in[it.grp]));
+        float amax_true = __uint_as_float(__builtin_amdgcn_readfirstlane((int)a.amax_in[it.grp])); // an upper bound of this item's max |x|
+        for (int j = 0; j < nl; ++j) {
+            const bool last = j == nl - 1;
+            const int Wout = Wi - 2 * (j + 1), nrow = it.ny + 2 * (nl - 1 - j);
+            const int npix = nrow * Wout, ntiles = (npix + 31) >> 5, rounds = (ntiles + 3) >> 2;
+            const uint32_t magic = a.magic_w[j];
+            const vu4 *wf = a.wfrag[it.grp][j];
+            const uint32_t *tail = reinterpret_cast<const uint32_t *>(wf + X2_FRAG_VU4);
+            const int k_w = __builtin_amdgcn_readfirstlane((int)tail[0]);
+            const float l1 = __uint_as_float(__builtin_amdgcn_readfirstlane((int)tail[1]));
+            const float *bsrc = a.bias[it.grp][j];
+            // bias seeds and their maximum (this wave's own LDS copy: no barrier between the layers' bias traffic)
+            float bv = (bsrc && lane < 32) ? bsrc[lane] : 0.0f;
+            const float bmax = wave_max(fabsf(bv));
+            if (lane < 32) lbias[lane] = bv * pow2f(k_in) * pow2f(k_w);
+            // the scale of what this layer stores: 0 for the chain's output (float32), else from the a-priori bound of the item
+            int k_out = 0;
+            if (!last) k_out = scale_exp(__float_as_uint((l1 * amax_true + bmax) * 1.001f));
+            const float un_in = pow2f(-k_in), c2 = pow2f(k_out - k_w); // two exact factors (their product may leave float32's range)
+            const int relu_floor = __builtin_amdgcn_readfirstlane((!last || a.relu_last) ? 0 : (int)0x80000000);
+            float vmax = 0.0f;
+
+            auto locate = [&](int tl, bool &valid_, int &off_, int &yy_, int &xx_) {
+                int m_ = tl * 32 + l31;
+                valid_ = m_ < npix;
+                if (!valid_) m_ = npix - 1; // read a real pixel, discard the result
+                yy_ = (int)__umulhi((uint32_t)m_, magic);
+                xx_ = m_ - yy_ * Wout;
+                off_ = (yy_ * Wi + xx_) * X2_SLOT + h * 16;
+            };
+            struct Ops {
+                vu4 xh, xl;
+            };
+            auto rd1 = [&](int off_, int i, Ops &o, int part) { // one of the operand's two reads: row base + immediate
+                const int t = i >> 1;
+                const char *p = img + off_ + (t / 3) * rowb + ((t % 3) * X2_SLOT + (i & 1) * 32);
+                if (part == 0) o.xh = *reinterpret_cast<const vu4 *>(p);
+                else o.xl = *reinterpret_cast<const vu4 *>(p + 64);
+            };
+            bool valid = false;
+            int off = 0, yy = 0, xx = 0;
+            Ops o[3];
+            if (cw < ntiles) {
+                locate(cw, valid, off, yy, xx);
+                rd1(off, 0, o[0], 0); rd1(off, 0, o[0], 1);
+                rd1(off, 1, o[1], 0); rd1(off, 1, o[1], 1);
+            }
+            // One round = the wave's tile 4 r + cw: operand reads + matrix instructions, the round's barrier, the in-place epilogue.
+            // The layer's LAST round is peeled (FINAL): behind its matrix instructions the next layer's (or the next item's first
+            // layer's) weight fragments are requested into the registers the layer just finished with -- unconditionally, at one
+            // place in the program (requested inside the loop under a condition they cost 80 spilled registers); they land during
+            // the epilogue and the layer barrier.
+            const vu4 *wf_next = !last ? a.wfrag[it.grp][j + 1] : (item + G < n ? a.wfrag[chain_item(a, item + G).grp][0] : wf);
+            auto round = [&](int r, auto final_round) {
+                constexpr bool FINAL = decltype(final_round)::value;
+                const int tl = 4 * r + cw;
+                const bool active = tl < ntiles; // wave-uniform
+                f32x16 acc, accx;
+                bool valid2 = false;
+                int off2 = 0, yy2 = 0, xx2 = 0;
+#ifdef AUGCL_TUNING
+                { const unsigned long long t = __builtin_amdgcn_s_memtime(); c_layer += t - t_mark; t_mark = t; ++c_rounds; }
+#endif
+                if (active) {
+                    locate(tl + 4 < ntiles ? tl + 4 : tl, valid2, off2, yy2, xx2); // no next tile: re-read this one
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) { // accumulator seed = bias of rows 8 g4 + 4 h + (0..3)
+                        const vf4 b4 = *reinterpret_cast<const vf4 *>(lbias + 8 * g4 + 4 * h);
+                        acc[4 * g4] = b4[0]; acc[4 * g4 + 1] = b4[1]; acc[4 * g4 + 2] = b4[2]; acc[4 * g4 + 3] = b4[3];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) accx[q] = 0.0f;
+#define CH_MM(C_, A_, B_) C_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_, __builtin_bit_cast(f16x8, B_), C_, 0, 0, 0)
+#pragma unroll
+                    for (int i = 0; i < 18; ++i) {
+                        Ops &cur = o[i % 3];
+                        Ops &nn = o[(i + 2) % 3];
+                        const int noff = i < 16 ? off : off2, ni = i < 16 ? i + 2 : i - 16; // the operand two groups on (across the tile boundary)
+                        // smallest products first: wl' xh, wh xl' (cross), wh xh (main); one LDS read between matrix instructions
+                        CH_MM(accx, wl[i], cur.xh);
+                        __builtin_amdgcn_sched_barrier(0);
+                        rd1(noff, ni, nn, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        CH_MM(accx, wh[i], cur.xl);
+                        __builtin_amdgcn_sched_barrier(0);
+                        rd1(noff, ni, nn, 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        CH_MM(acc, wh[i], cur.xh);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#undef CH_MM
+                    // (a later tile's operands 0, 1 were read before this round's barrier: they lie in front of every pixel the
+                    // round writes -- a tile reads at and behind its own pixels, the round writes pixels of EARLIER tiles only)
+                }
+                if (FINAL) load_weights(wf_next);
+#ifdef AUGCL_TUNING
+                { const unsigned long long t = __builtin_amdgcn_s_memtime(); c_mma += t - t_mark; t_mark = t; }
+#endif
+                if (!last) __syncthreads(); // R: the round's operand reads are done
+#ifdef AUGCL_TUNING
+                { const unsigned long long t = __builtin_amdgcn_s_memtime(); c_wait += t - t_mark; t_mark = t; }
+#endif
+                if (active) {
+                    // rows in accumulator order: co = 0,1,2,3, 8,9,10,11, ... (+4 h)
+                    float v[16];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        float t = __builtin_fmaf(accx[q], 1.0f / 2048.0f, acc[q]) * un_in * c2;
+                        t = __int_as_float(max(__float_as_int(t), relu_floor));
+                        vmax = fmaxf(vmax, fabsf(t));
+                        v[q] = t;
+                    }
+                    if (!last) {
+                        if (valid) {
+                            char *dst = img + (yy * Wi + xx) * X2_SLOT + 8 * h;
+#pragma unroll
+                            for (int g4 = 0; g4 < 4; ++g4) { // channels 8 g4 + 4 h + (0..3): 8 bytes of the hi plane, 8 of the lo' plane
+                                uint32_t h0, l0, h1, l1_;
+                                split2h(v[4 * g4], v[4 * g4 + 1], h0, l0);
+                                split2h(v[4 * g4 + 2], v[4 * g4 + 3], h1, l1_);
+                                typedef uint32_t vu2 __attribute__((ext_vector_type(2)));
+                                *reinterpret_cast<vu2 *>(dst + 16 * g4) = vu2{h0, h1};
+                                *reinterpret_cast<vu2 *>(dst + 16 * g4 + 64) = vu2{l0, l1_};
+                            }
+                        }
+                    } else {
+                        const unsigned boff = valid ? (unsigned)((it.b * 32 * Hf + (it.y0 + yy)) * Wf + xx + 4 * h * chw) * 4u : kNoStore;
+#pragma unroll
+                        for (int q = 0; q < 16; ++q)
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[q]), rs_out, boff,
+                                                                  (unsigned)(((q & 3) + 8 * (q >> 2)) * chw) * 4u, 0);
+                    }
+                    valid = valid2; off = off2; yy = yy2; xx = xx2;
+                }
+#ifdef AUGCL_TUNING
+                { const unsigned long long t = __builtin_amdgcn_s_memtime(); c_epi += t - t_mark; t_mark = t; }
+#endif
+            };
+            for (int r = 0; r + 1 < rounds; ++r) round(r, std::false_type{});
+            round(rounds - 1, std::true_type{});
+            if (!last) {
+                // the item's maximum of this layer's output (scaled units): one LDS atomic per wave, read by all after the barrier
+                vmax = wave_max(vmax);
+                if (lane == 0) atomicMax(lred + j, __float_as_uint(vmax));
+                __syncthreads(); // L: the layer's output is in place
+                amax_true = __uint_as_float(__builtin_amdgcn_readfirstlane((int)lred[j])) * pow2f(-k_out);
+                k_in = k_out;
+            } else {
+                vmax_out[it.grp] = fmaxf(vmax_out[it.grp], vmax);
+            }
+        }
+        __syncthreads(); // F
+    }
+#ifdef AUGCL_TUNING
+    if (blockIdx.x == 0 && wave == 0 && lane == 0) {
+        g_chain_clk[0] = c_mma; g_chain_clk[1] = c_wait; g_chain_clk[2] = c_epi; g_chain_clk[3] = c_layer; g_chain_clk[4] = c_item;
+        g_chain_clk[5] = c_rounds;
+        g_chain_clk[6] = __builtin_amdgcn_s_memtime() - t_kernel;
+        g_chain_clk[7] = __builtin_amdgcn_s_memrealtime() - r_kernel;
+    }
+#endif
+    if (a.amax_out != nullptr) {
+        // ONE global atomic per workgroup and weight set: every compute wave adds its maximum in LDS and takes a ticket; the last
+        // one sends them on.  (The loaders are gone; lred[8..11] were zeroed by their last dump... they are not: zero them here.)
+        const float m0 = wave_max(vmax_out[0]), m1 = wave_max(vmax_out[1]);
+        if (lane == 0) {
+            atomicMax(lred + 8, __float_as_uint(m0));
+            atomicMax(lred + 9, __float_as_uint(m1));
+            if (atomicAdd(lred + 10, 1u) == 3u) {
+                atomicMax(a.amax_out, lred[8]);
+                if (a.dual) atomicMax(a.amax_out + 1, lred[9]);
+            }
+        }
+    }
+}
+
+} // namespace augcl
+
+using namespace augcl;
+
+namespace {
+
+int cu_count_chain()
+{
+    int dev = 0, v = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) v = n;
+    }
+    return v;
+}
+
+constexpr int kLdsBytes = 160 * 1024;
+
+} // namespace
+
+extern "C" {
+
+#ifdef AUGCL_TUNING
+int augcl_tuning_chain_read_clk(unsigned long long *out8)
+{
+    return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_chain_clk), 64) == hipSuccess ? AUGCL_OK : AUGCL_E_LAUNCH;
+}
+#endif
+
+// Plan of one launch: `nl` layers starting at a (Hi x Wi) input, final rows split in `parts` per image.
+// Returns the number of tile rounds of the longest item (the launch's critical path in units of ~1 us), or -1 if it does not fit.
+int augcl_internal_chain_rounds(int Hi, int Wi, int nl, int parts)
+{
+    if (nl < 1 || nl > CH_MAXL || parts < 1) return -1;
+    const int Hf = Hi - 2 * nl, Wf = Wi - 2 * nl;
+    if (Hf < 1 || Wf < 1 || parts > Hf) return -1;
+    const int rows_out = (Hf + parts - 1) / parts;
+    if ((parts - 1) * rows_out >= Hf) return -1; // an empty last part
+    const long npx = (long)(rows_out + 2 * nl) * Wi;
+    if (npx > 256L * CH_NU || npx < 4 || CH_HDR + npx * X2_SLOT > kLdsBytes) return -1;
+    int rounds = 0;
+    for (int j = 0; j < nl; ++j) {
+        const int npix = (rows_out + 2 * (nl - 1 - j)) * (Wi - 2 * (j + 1));
+        rounds += (((npix + 31) >> 5) + 3) >> 2;
+    }
+    return rounds;
+}
+
+// One chain launch.  wfrag[set][j] / bias[set][j]: the prepared fragments (k_x2_prep, mode 0) and biases of its layers; sets = 2:
+// images [B/2, B) use set 1.  +1: the shape is not covered.
+int augcl_internal_chain_forward(const float *in, float *out, const void *const *wfragA, const float *const *biasA,
+                                 const void *const *wfragB, const float *const *biasB, int nl, int B, int Hi, int Wi, int parts,
+                                 int relu_last, const float *amax_in, float *amax_out, augcl_stream_t stream)
+{
+    const char *name = "augcl_enc_stack_infer";
+    AUGCL_REQUIRE(in && out && wfragA && biasA && amax_in, "%s: null tensor", name);
+    if (B == 0) return AUGCL_OK;
+    if (augcl_internal_chain_rounds(Hi, Wi, nl, parts) < 0) return 1;
+    if ((size_t)B * 32 * Hi * Wi >= ((size_t)1 << 30) - 8) return 1;
+    AUGCL_REQUIRE(wfragB == nullptr || (B & 1) == 0, "%s: a two-weight-set batch must be even", name);
+    AUGCL_REQUIRE(aligned4(in) && aligned4(out), "%s: tensors must be 4-byte aligned", name);
+    ChainArgs a{};
+    a.in = in; a.out = out;
+    for (int j = 0; j < nl; ++j) {
+        a.wfrag[0][j] = reinterpret_cast<const vu4 *>(wfragA[j]);
+        a.bias[0][j] = biasA[j];
+        a.wfrag[1][j] = reinterpret_cast<const vu4 *>(wfragB ? wfragB[j] : wfragA[j]);
+        a.bias[1][j] = wfragB ? biasB[j] : biasA[j];
+        a.magic_w[j] = (uint32_t)(0x100000000ull / (unsigned)(Wi - 2 * (j + 1))) + 1u;
+    }
+    a.nl = nl; a.B = B; a.Hi = Hi; a.Wi = Wi; a.parts = parts;
+    const int Hf = Hi - 2 * nl;
+    a.rows_out = (Hf + parts - 1) / parts;
+    a.relu_last = relu_last;
+    a.dual = wfragB != nullptr;
+    a.n_items = B * parts;
+    a.magic_parts = (uint32_t)(0x100000000ull / (unsigned)parts) + 1u;
+    a.amax_in = reinterpret_cast<const uint32_t *>(amax_in);
+    a.amax_out = reinterpret_cast<uint32_t *>(amax_out);
+    const size_t lds = (size_t)CH_HDR + (size_t)(a.rows_out + 2 * nl) * Wi * X2_SLOT;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv32_chain), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return augcl::fail(AUGCL_E_LAUNCH, "%s: cannot set dynamic LDS %zu: %s", name, lds, hipGetErrorString(e));
+    const int cus = cu_count_chain();
+    const int grid = a.n_items < cus ? a.n_items : cus;
+    hipLaunchKernelGGL(k_conv32_chain, dim3(grid), dim3(512), lds, as_stream(stream), a);
+    return augcl::check_launch(name);
+}
+
+} // extern "C"

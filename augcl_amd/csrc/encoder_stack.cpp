@@ -270,6 +270,143 @@ int augcl_enc_stack_forward_dual(const float *x, const float *const *wA, const f
     return AUGCL_OK;
 }
 
+// ---- no-grad forward with the 32 -> 32 layers in CHAINS (encoder_chain.hip): the first layer's kernel, one weight-fragment
+// launch per weight set, then one launch per chain of up to six layers whose intermediates stay in LDS.
+int augcl_internal_chain_rounds(int Hi, int Wi, int nl, int parts);
+int augcl_internal_chain_forward(const float *in, float *out, const void *const *wfragA, const float *const *biasA,
+                                 const void *const *wfragB, const float *const *biasB, int nl, int B, int Hi, int Wi, int parts,
+                                 int relu_last, const float *amax_in, float *amax_out, augcl_stream_t stream);
+
+namespace {
+
+struct ChainPlan {
+    int n = 0;
+    int nl[32], parts[32];
+};
+
+// Fewest estimated microseconds over all ways to cut n32 layers (input h x w, `images` of them, `cus` workgroups at a time) into
+// chains: a launch costs ceil(items / cus) x (the longest item's tile rounds + ~2 for its staging) + ~8 for ramp and drain.
+// Small batches come out with many parts per image (more workgroups busy), large ones with the fewest that fit LDS.
+bool plan_chains(int h, int w, int n32, long images, int cus, ChainPlan &plan)
+{
+    if (n32 < 1 || n32 > 32) return false;
+    double best[33];
+    int bl[33], bp[33];
+    best[n32] = 0.0;
+    for (int s = n32 - 1; s >= 0; --s) {
+        best[s] = 1e30;
+        bl[s] = bp[s] = 0;
+        const int hs = h - 2 * s, ws = w - 2 * s;
+        for (int L = 1; L <= 6 && s + L <= n32; ++L) {
+            const int hf = hs - 2 * L;
+            for (int P = 1; P <= hf; ++P) {
+                const int r = augcl_internal_chain_rounds(hs, ws, L, P);
+                if (r < 0) continue;
+                const double cost = (double)((images * P + cus - 1) / cus) * (r + 2) + 8.0 + best[s + L];
+                if (cost < best[s]) { best[s] = cost; bl[s] = L; bp[s] = P; }
+            }
+        }
+        if (bl[s] == 0) return false;
+    }
+    plan.n = 0;
+    for (int s = 0; s < n32; s += bl[s]) {
+        plan.nl[plan.n] = bl[s];
+        plan.parts[plan.n] = bp[s];
+        ++plan.n;
+    }
+    return true;
+}
+
+int cu_count_stack()
+{
+    int dev = 0, v = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) v = n;
+    }
+    return v;
+}
+
+} // namespace
+
+size_t augcl_enc_stack_infer_scratch_bytes(int n_layers, int B_total, int C, int H, int W, int first_stride)
+{
+    (void)n_layers; (void)C;
+    if (B_total < 1 || H < 3 || W < 3 || first_stride < 1) return 0;
+    const size_t a0 = (size_t)B_total * 32 * out_hw(H, first_stride) * out_hw(W, first_stride) * sizeof(float);
+    return 2 * ((a0 + 255) & ~(size_t)255); // two buffers of the largest activation: the chains ping-pong between them
+}
+
+// x (B,C,H,W) raw f32; out ((wB ? 2 : 1) x B, 32, h, w) f32 NCHW: rows [0,B) from weight set A, [B,2B) from set B over the SAME
+// input.  amax: 2 x (n_layers + 1) floats of device scratch.  AUGCL_E_UNSUPPORTED: a shape the chains (or, with two weight
+// sets, the pipelined first-layer kernel) do not cover -- the caller runs augcl_enc_stack_forward[_dual].
+int augcl_enc_stack_infer(const float *x, const float *const *wA, const float *const *bA, const float *const *wB,
+                          const float *const *bB, float *out, void *scratch, size_t scratch_bytes, int n_layers, int B, int C,
+                          int H, int W, int first_stride, float scale, void *frag_ws, size_t frag_ws_bytes, float *amax,
+                          augcl_stream_t stream)
+{
+    const char *name = "augcl_enc_stack_infer";
+    AUGCL_REQUIRE(x && wA && bA && out && amax && n_layers >= 1 && B >= 1, "%s: bad argument", name);
+    AUGCL_REQUIRE((wB == nullptr) == (bB == nullptr), "%s: weight set B needs both arrays", name);
+    const int sets = wB ? 2 : 1, Bt = sets * B;
+    const int h1 = out_hw(H, first_stride), w1 = out_hw(W, first_stride);
+    AUGCL_REQUIRE(h1 >= 1 && w1 >= 1 && h1 - 2 * (n_layers - 1) >= 1 && w1 - 2 * (n_layers - 1) >= 1, "%s: image too small", name);
+    int rc;
+    ChainPlan plan;
+    if (n_layers >= 2) {
+        AUGCL_REQUIRE(n_layers <= 33, "%s: at most 33 layers", name);
+        if (!plan_chains(h1, w1, n_layers - 1, Bt, cu_count_stack(), plan))
+            return augcl::fail(AUGCL_E_UNSUPPORTED, "%s: no chain plan for a %d x %d input", name, h1, w1);
+        if ((rc = x2_require(name, n_layers, frag_ws, frag_ws_bytes, sets, amax)) != AUGCL_OK) return rc;
+        AUGCL_REQUIRE(scratch != nullptr && scratch_bytes >= augcl_enc_stack_infer_scratch_bytes(n_layers, Bt, C, H, W, first_stride),
+                      "%s: scratch smaller than augcl_enc_stack_infer_scratch_bytes", name);
+    }
+    const size_t half = n_layers >= 2 ? augcl_enc_stack_infer_scratch_bytes(n_layers, Bt, C, H, W, first_stride) / 2 : 0;
+    float *buf[2] = {reinterpret_cast<float *>(scratch), reinterpret_cast<float *>(reinterpret_cast<char *>(scratch) + half)};
+    // fragments of both sets (the first launch also zeroes the maxima: amax[2 c + set] = max |input of chain c| of that half)
+    const size_t block = augcl_enc_frag_workspace_bytes(1, 1), setB = (size_t)(n_layers - 1) * block;
+    if (n_layers >= 2) {
+        x3_prepare(wA, n_layers, 0, (char *)frag_ws, frag_ws_bytes, 0, stream, &rc, true, amax, 2 * (n_layers + 1));
+        if (rc != AUGCL_OK) return rc;
+        if (wB) {
+            x3_prepare(wB, n_layers, 0, (char *)frag_ws, frag_ws_bytes, setB, stream, &rc, true);
+            if (rc != AUGCL_OK) return rc;
+        }
+    }
+    // first layer (f32 MFMA, stride 2, x / scale fused): leaves max |a_0| per half
+    float *a0 = n_layers >= 2 ? buf[0] : out;
+    const int relu0 = n_layers >= 2;
+    rc = augcl::conv_first9_try(x, wA[0], bA[0], a0, Bt, C, H, W, first_stride, scale, relu0, false, (hipStream_t)stream, name,
+                                wB ? wB[0] : nullptr, wB ? bB[0] : nullptr, n_layers >= 2 ? amax : nullptr);
+    if (rc > 0) {
+        if (wB) return augcl::fail(AUGCL_E_UNSUPPORTED, "%s: first-layer shape (%d,%d,%d) stride %d not covered", name, C, H, W, first_stride);
+        rc = augcl_enc_conv_first_forward(x, wA[0], bA[0], a0, B, C, H, W, first_stride, scale, relu0, stream);
+        if (rc == AUGCL_OK && n_layers >= 2) rc = augcl_internal_amax_f32(a0, (size_t)B * 32 * h1 * w1, amax, stream);
+    }
+    if (rc != AUGCL_OK || n_layers < 2) return rc;
+    int layer = 1, h = h1, w = w1, cur = 0;
+    for (int c = 0; c < plan.n; ++c) {
+        const int nl = plan.nl[c];
+        const bool final_chain = c == plan.n - 1;
+        const void *fa[6], *fb[6];
+        for (int j = 0; j < nl; ++j) {
+            fa[j] = (char *)frag_ws + (size_t)(layer + j - 1) * block;
+            fb[j] = (char *)frag_ws + setB + (size_t)(layer + j - 1) * block;
+        }
+        float *dst = final_chain ? out : buf[cur ^ 1];
+        rc = augcl_internal_chain_forward(buf[cur], dst, fa, bA + layer, wB ? fb : nullptr, wB ? bB + layer : nullptr, nl, Bt, h, w,
+                                          plan.parts[c], final_chain ? 0 : 1, amax + 2 * c, final_chain ? nullptr : amax + 2 * (c + 1),
+                                          stream);
+        if (rc > 0) return augcl::fail(AUGCL_E_UNSUPPORTED, "%s: chain of %d layers at %d x %d not covered", name, nl, h, w);
+        if (rc != AUGCL_OK) return rc;
+        layer += nl;
+        h -= 2 * nl;
+        w -= 2 * nl;
+        cur ^= 1;
+    }
+    return AUGCL_OK;
+}
+
 // acts_in[i] = input of layer i (acts_in[0] = x raw f32; i >= 1: post-ReLU activation, f32 NCHW or bf16 NHWC);
 // grad_out = f32 NCHW gradient of the last layer's output; dz_a / dz_b = two scratch buffers, each large enough for
 // the largest activation (layer 0's output) in the mode's element type; dw[i] / db[i] receive the gradients.

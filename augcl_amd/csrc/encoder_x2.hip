@@ -23,67 +23,12 @@
 // Structure as in encoder_x3.hip: 4 loader + 4 compute waves, double-buffered pixel-major LDS tile (slot = hi | lo' x 32
 // channels + pad = 144 B), loaders two strips ahead, weights' fragments (hi and lo', 144 VGPRs) resident in the compute
 // waves' registers, operand reads two groups ahead of their MFMAs, pipelined epilogue (stores of tile i inside tile i + 1).
-#include "augcl_common.h"
+#include "encoder_x2_common.h"
 
 #include <algorithm>
 #include <type_traits>
 
 namespace augcl {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef uint32_t vu4 __attribute__((ext_vector_type(4)));
-typedef float vf4 __attribute__((ext_vector_type(4)));
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef short s16x8 __attribute__((ext_vector_type(8)));
-
-constexpr int X2_SLOT = 144;       // LDS bytes per pixel slot: 2 planes x 64 B + 16 B pad (36 p mod 64 dwords: 16 consecutive
-                                   // pixels x one 16-byte chunk fall into 16 distinct bank quads)
-constexpr int X2_NU = 2;           // loader rounds per strip: 256 lanes x X2_NU units of (4 pixels x 8 channels)
-constexpr int X2_ROWPAD = 224;     // forward: extra bytes per LDS tile row (14 chunks of 16 B: see k_conv32_x2's row pitch)
-constexpr int X2_HDR = 512;        // LDS in front of the tiles: +-bias (2 x 128 B), the maximum's two words, spare
-constexpr int X2_MAXTILE = 81664;  // bytes per tile buffer: 2 x this + X2_HDR <= 160 KiB
-constexpr int X2_FRAG_VU4 = 2 * 18 * 64; // 16-byte entries per layer block, then one entry whose first word is the weights' exponent
-constexpr int X2_BLOCK_BYTES = 55296;    // stride of the per-layer blocks in frag_ws (= the split-bf16 kernels' block: one size function)
-
-__device__ __forceinline__ int acc_row_h(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
-
-// k with amax 2^k in [2^14, 2^15) (amax = 1.m 2^(e - 127)); zero / tiny / huge / non-finite maxima clamp to k in [-46, 74]
-__host__ __device__ __forceinline__ int scale_exp(uint32_t amax_bits)
-{
-    int e = (int)((amax_bits >> 23) & 0xffu);
-    e = e < 67 ? 67 : e > 187 ? 187 : e;
-    return 141 - e;
-}
-__device__ __forceinline__ float pow2f(int k) { return __uint_as_float((uint32_t)(127 + k) << 23); } // -126 <= k <= 127
-
-// two floats (already scaled) -> their f16 (hi, lo') pairs: hi + lo' 2^-11 == the float to 2^-24
-__device__ __forceinline__ void split2h(float a, float b, uint32_t &hi, uint32_t &lo)
-{
-    const f16x2 h = __builtin_convertvector(f32x2{a, b}, f16x2); // RNE
-    const float ra = (a - (float)h[0]) * 2048.0f, rb = (b - (float)h[1]) * 2048.0f; // residuals are exact; 2^11 lifts them to f16's range
-    const f16x2 l = __builtin_convertvector(f32x2{ra, rb}, f16x2);
-    hi = __builtin_bit_cast(uint32_t, h);
-    lo = __builtin_bit_cast(uint32_t, l);
-}
-// ... with the residual left unscaled (backward-weights: all three products share one accumulator; elements below 2^-16 of
-// the tensor's maximum keep an ABSOLUTE error of 2^-40 of the maximum, which is what a sum over every pixel needs)
-__device__ __forceinline__ void split2u(float a, float b, uint32_t &hi, uint32_t &lo)
-{
-    const f16x2 h = __builtin_convertvector(f32x2{a, b}, f16x2);
-    const f16x2 l = __builtin_convertvector(f32x2{a - (float)h[0], b - (float)h[1]}, f16x2);
-    hi = __builtin_bit_cast(uint32_t, h);
-    lo = __builtin_bit_cast(uint32_t, l);
-}
-
-__device__ __forceinline__ float wave_max(float v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
-}
 
 struct ConvX2Args {
     const float *in;     // forward: a_{l-1} (post-ReLU) (B,32,Hi,Wi);  bwd-data: dZ_l
@@ -758,11 +703,11 @@ struct PrepX2Args {
 
 __global__ __launch_bounds__(256) void k_x2_prep(PrepX2Args a)
 {
-    __shared__ uint32_t red;
+    __shared__ uint32_t red, red_l1[2];
     const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
     const int i = 4 * blockIdx.x + (threadIdx.x >> 6), t = i >> 1, s = i & 1; // one operand per wave (18 = 4 x 4 + 2)
     const float *w = a.w[blockIdx.y];
-    if (threadIdx.x == 0) red = 0u;
+    if (threadIdx.x == 0) red = red_l1[0] = red_l1[1] = 0u;
     __syncthreads();
     float m = 0.0f;
     const vf4 *w4 = reinterpret_cast<const vf4 *>(w);
@@ -773,7 +718,36 @@ __global__ __launch_bounds__(256) void k_x2_prep(PrepX2Args a)
     }
     m = wave_max(m);
     if (lane == 0) atomicMax(&red, __float_as_uint(m));
+    if (blockIdx.x == 4) {
+        // (the block with two idle waves) the weights' largest row / column sums of absolute values: with max |input| they bound
+        // max |output| of the layer BEFORE it is computed (forward: |y[co]| <= sum_{ci,t} |w[co][ci][t]| max|x| + |b[co]|;
+        // backward-data: |dx[ci]| <= sum_{co,t} |w[co][ci][t]| max|dz|) -- the scale under which encoder_chain.hip stores an
+        // intermediate that never leaves LDS.  8 threads per row / column, 36 weights each, fixed order.
+        const int rc = threadIdx.x >> 3, part = threadIdx.x & 7;
+        float sr = 0.0f, sc = 0.0f;
+#pragma unroll 4
+        for (int e = 0; e < 36; ++e) {
+            sr += fabsf(w[rc * 288 + part * 36 + e]);
+            sc += fabsf(w[(4 * part + e / 9) * 288 + rc * 9 + e % 9]);
+        }
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+            sr += __shfl_xor(sr, o, 64);
+            sc += __shfl_xor(sc, o, 64);
+        }
+        sr = wave_max(sr);
+        sc = wave_max(sc);
+        if (lane == 0) {
+            atomicMax(&red_l1[0], __float_as_uint(sr));
+            atomicMax(&red_l1[1], __float_as_uint(sc));
+        }
+    }
     __syncthreads();
+    if (blockIdx.x == 4 && threadIdx.x == 0) {
+        uint32_t *tail = reinterpret_cast<uint32_t *>(a.out + (size_t)blockIdx.y * X2_BLOCK_BYTES + (size_t)X2_FRAG_VU4 * 16);
+        tail[1] = red_l1[0]; // (block 0 writes word 0, the exponent)
+        tail[2] = red_l1[1];
+    }
     if (i >= 18) return;
     const int k_w = scale_exp(red);
     const float sw = pow2f(k_w);
@@ -795,7 +769,7 @@ __global__ __launch_bounds__(256) void k_x2_prep(PrepX2Args a)
     vu4 *o = reinterpret_cast<vu4 *>(a.out + (size_t)blockIdx.y * X2_BLOCK_BYTES);
     o[i * 64 + lane] = fh;
     o[(18 + i) * 64 + lane] = fl;
-    if (i == 0 && lane == 0) o[X2_FRAG_VU4] = vu4{(uint32_t)k_w, 0u, 0u, 0u};
+    if (i == 0 && lane == 0) reinterpret_cast<uint32_t *>(o + X2_FRAG_VU4)[0] = (uint32_t)k_w; // words 1, 2: block 4 (the L1 sums)
     if (i == 1 && blockIdx.y == 0 && a.zero != nullptr)
         for (int j = lane; j < a.n_zero; j += 64) a.zero[j] = 0u;
 }

@@ -153,6 +153,53 @@ def _ptr_array(ptrs):
     return (_lib.ctypes.c_void_p * len(ptrs))(*ptrs)
 
 
+_CHAINS = True  # (A/B switch) no-grad passes of precision "f32" through augcl_enc_stack_infer: LDS-resident layer chains
+_infer_ws = {}
+
+
+def _infer_scratch(dev, n_layers, b_total, C, H, W, first_stride):
+    """scratch of augcl_enc_stack_infer (two buffers of the first layer's output + the maxima behind them): one tensor per
+    (device, size), never replaced, so captured hipGraphs may keep its address"""
+    lib = _lib.load()
+    need = lib.augcl_enc_stack_infer_scratch_bytes(int(n_layers), int(b_total), int(C), int(H), int(W), int(first_stride))
+    key = (dev, need)
+    t = _infer_ws.get(key)
+    if t is None:
+        if dev.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            raise _lib.AugclError("no-grad conv-stack scratch requested for the first time inside a hipGraph capture; run one "
+                                  "eager pass of this shape first")
+        t = _infer_ws[key] = torch.empty(need + 4 * _AMAX * 2, dtype=torch.uint8, device=dev)
+    return t, need
+
+
+def conv_stack_infer(x, weights_a, biases_a, weights_b, biases_b, first_stride, input_scale):
+    """No-grad forward of one conv stack (weights_b is None) or of two stacks with identical shapes over the SAME input,
+    f16-pair arithmetic, 32 -> 32 layers as LDS-resident chains (augcl_enc_stack_infer).  Returns (B or 2B, 32, h, w) f32 --
+    rows [0,B) from set A, [B,2B) from set B -- or None when the shape is not covered."""
+    n_layers = len(weights_a)
+    B, C, H, W = x.shape
+    if not _CHAINS or not x.is_contiguous() or x.dtype != torch.float32 or 2 * (n_layers + 1) > 2 * _AMAX:
+        return None
+    dev = x.device
+    sets = 1 if weights_b is None else 2
+    h, w_ = _out_hw(H, first_stride), _out_hw(W, first_stride)
+    h, w_ = h - 2 * (n_layers - 1), w_ - 2 * (n_layers - 1)
+    if h < 1 or w_ < 1:
+        return None
+    out = torch.empty((sets * B, 32, h, w_), dtype=torch.float32, device=dev)
+    ws, need = _infer_scratch(dev, n_layers, sets * B, C, H, W, first_stride)
+    fws = _frag_ws(dev, max(n_layers - 1, 1), sets)
+    d = lambda ts: _ptr_array([t.detach().data_ptr() for t in ts])  # noqa: E731
+    rc = _lib.load().augcl_enc_stack_infer(
+        x.data_ptr(), d(weights_a), d(biases_a), d(weights_b) if sets == 2 else None, d(biases_b) if sets == 2 else None,
+        out.data_ptr(), ws.data_ptr(), need, n_layers, B, C, H, W, first_stride, input_scale, fws.data_ptr(), fws.numel(),
+        ws.data_ptr() + need, _lib.current_stream(dev))
+    if rc == _lib.AUGCL_E_UNSUPPORTED:
+        return None
+    _lib.check(rc, "augcl_enc_stack_infer")
+    return out
+
+
 def conv_stack_dual(x, weights_a, biases_a, weights_b, biases_b, first_stride, input_scale, precision):
     """Two conv stacks with the same shapes (different weights) over the SAME input, no gradients: one launch per layer
     for both (augcl_enc_stack_forward_dual).  Returns a (2B,32,h,w) f32 tensor -- rows [0,B) from set A, [B,2B) from
@@ -161,6 +208,10 @@ def conv_stack_dual(x, weights_a, biases_a, weights_b, biases_b, first_stride, i
     B, C, H, W = x.shape
     if n_layers < 2 or C != 9 or W != 84 or first_stride != 2 or not x.is_contiguous():
         return None
+    if precision == "f32":
+        out = conv_stack_infer(x, weights_a, biases_a, weights_b, biases_b, first_stride, input_scale)
+        if out is not None:
+            return out
     dev = x.device
     bf16 = precision == "bf16"
     adt = torch.bfloat16 if bf16 else torch.float32
@@ -205,6 +256,10 @@ class ConvStackFn(torch.autograd.Function):
             wsz.append(wsz[-1] - 2)
         numel = [B * 32 * h * w_ for h, w_ in zip(hs, wsz)]
         need_grad = any(t.requires_grad for t in wb)
+        if not need_grad and precision == "f32":  # nothing is kept for a backward pass: the layers run as LDS-resident chains
+            out = conv_stack_infer(x, weights, biases, None, None, first_stride, input_scale)
+            if out is not None:
+                return out
         out = torch.empty((B, 32, hs[-1], wsz[-1]), dtype=torch.float32, device=dev)
         al = 8  # elements: keeps every slice 16-byte aligned in both element types
         tail = _AMAX if precision == "f32" else 0  # the per-tensor maxima live behind the activations (the backward reads them)

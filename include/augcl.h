@@ -36,7 +36,8 @@
 extern "C" {
 #endif
 
-#define AUGCL_ABI_VERSION 3 /* 2: the whole-stack entry points take a weight-fragment workspace; 3: ... and the per-tensor maxima of precision 3 */
+#define AUGCL_ABI_VERSION 4 /* 2: the whole-stack entry points take a weight-fragment workspace; 3: ... and the per-tensor maxima of precision 3;
+                             * 4: augcl_enc_stack_infer (no-grad forward with LDS-resident layer chains) */
 
 #define AUGCL_OK 0
 #define AUGCL_E_INVALID (-1)   /* bad argument (null pointer, bad shape, misalignment) */
@@ -398,6 +399,26 @@ int augcl_enc_stack_forward_dual(const float *x, const float *const *wA, const f
                                  const float *const *bB, void *const *acts_out, int n_layers, int B, int C, int H, int W,
                                  int first_stride, float scale, int precision, void *frag_ws, size_t frag_ws_bytes,
                                  float *amax, augcl_stream_t stream);
+
+/* The NO-GRAD forward of the whole stack -- SAC.calculate_target_Q's two passes (src/algorithms/sac.py:94-101; wB / bB != NULL:
+ * both encoders over the same input, out = (2B,32,h,w) with rows [0,B) from set A and [B,2B) from set B), the actor step's
+ * detached pass (sac.py:119-122) and acting (sac.py:73-92; wB = bB = NULL, out = (B,32,h,w)) -- with the f16-pair arithmetic of
+ * precision 3 and the 32 -> 32 layers run in CHAINS of up to six layers per launch whose intermediate activations never leave
+ * LDS (csrc/encoder_chain.hip): the chain's input (its rows of one image, or of a part of one, plus two halo rows per layer) is
+ * staged once into a pixel-major f16 (hi | lo') image and every layer overwrites it in place; an intermediate is stored under a
+ * power of two taken from an a-priori bound of that work item's values (the weights' largest absolute row sum x the item's
+ * exact input maximum + the largest bias), so no tensor-wide maximum is needed inside a chain and nothing can overflow.  Same
+ * accuracy class as augcl_enc_stack_forward(precision 3) -- float32-accurate products, ~1e-7 relative L2 per layer against
+ * float64 -- but not bit-identical to it (other scales).  Nothing is kept for a backward pass.
+ * scratch: augcl_enc_stack_infer_scratch_bytes(...) bytes, 256-byte aligned (B_total = B x weight sets); frag_ws as above with
+ * the number of weight sets; amax: 2 x (n_layers + 1) floats of device scratch.
+ * AUGCL_E_UNSUPPORTED: a shape the chains (or, with two weight sets, the pipelined first-layer kernel) do not cover -- run
+ * augcl_enc_stack_forward / augcl_enc_stack_forward_dual instead. */
+size_t augcl_enc_stack_infer_scratch_bytes(int n_layers, int B_total, int C, int H, int W, int first_stride);
+int augcl_enc_stack_infer(const float *x, const float *const *wA, const float *const *bA, const float *const *wB,
+                          const float *const *bB, float *out, void *scratch, size_t scratch_bytes, int n_layers, int B, int C,
+                          int H, int W, int first_stride, float scale, void *frag_ws, size_t frag_ws_bytes, float *amax,
+                          augcl_stream_t stream);
 
 /* ---- device-resident replay sampling: ReplayBuffer.sample -> tensor_buffer_samples / _encode_obses /
  * LazyFrames._force (src/utils.py:206-214, 234-240, 272-280, 293-299).  `frames` is a uint8 ring of RGB frames

@@ -1,0 +1,166 @@
+"""The no-grad conv stack as LDS-resident layer chains (augcl_enc_stack_infer, csrc/encoder_chain.hip) -- the path of
+SAC.calculate_target_Q's two passes, the actor step's detached pass and acting (src/algorithms/sac.py:73-101, 119-122;
+src/algorithms/modules.py:145-165) -- against float64 ATen convolutions of the same stack and against the per-layer f16-pair
+kernels.  Tolerances are relative to the output's largest magnitude (float32 arithmetic: 1e-5 is north_star's bound, the
+chains sit at ~1e-6 like the per-layer kernels)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _stack(seed, n_layers, C=9, wscale=None, bscale=0.05, dev=None):
+    rs = np.random.RandomState(seed)
+    ws, bs = [], []
+    for i in range(n_layers):
+        cin = C if i == 0 else 32
+        s = wscale if wscale is not None else float(np.sqrt(2.0 / (cin * 9)))  # He: activations keep their scale
+        ws.append(torch.from_numpy((rs.standard_normal((32, cin, 3, 3)) * s).astype(np.float32)).to(dev))
+        bs.append(torch.from_numpy((rs.standard_normal(32) * bscale).astype(np.float32)).to(dev))
+    return ws, bs
+
+
+def _ref64(x, ws, bs, stride, scale):
+    y = x.double() / scale
+    for i, (w, b) in enumerate(zip(ws, bs)):
+        y = F.conv2d(y, w.double(), b.double(), stride=stride if i == 0 else 1)
+        if i < len(ws) - 1:
+            y = torch.relu(y)
+    return y
+
+
+def _rel(a, b):
+    return float((a.double() - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("B,n_layers", [(1, 11), (2, 11), (3, 2), (5, 5), (8, 11), (33, 8), (64, 11), (256, 11), (300, 11)])
+def test_infer_single_stack_against_float64(cuda, B, n_layers):
+    from augcl_amd import encoder_hip
+    x = torch.from_numpy(np.random.RandomState(B).randint(0, 256, (B, 9, 84, 84)).astype(np.float32)).to(cuda)
+    ws, bs = _stack(10 + n_layers, n_layers, dev=cuda)
+    out = encoder_hip.conv_stack_infer(x, ws, bs, None, None, 2, 255.0)
+    assert out is not None
+    want = _ref64(x, ws, bs, 2, 255.0)
+    assert out.shape == want.shape
+    assert _rel(out, want) <= 3e-6
+    # the same pass through the per-layer f16-pair kernels (what a gradient-carrying forward runs): both float32-accurate
+    encoder_hip._CHAINS = False
+    try:
+        with torch.no_grad():
+            layerwise = encoder_hip.ConvStackFn.apply(x, 2, 255.0, "f32", n_layers, *ws, *bs)
+    finally:
+        encoder_hip._CHAINS = True
+    assert _rel(layerwise, want) <= 3e-6
+    assert _rel(out, layerwise.double()) <= 3e-6
+
+
+@pytest.mark.parametrize("B", [1, 4, 37, 256])
+def test_infer_two_weight_sets_equal_two_single_passes(cuda, B):
+    """out[:B] / out[B:] of the two-set call = the single-set calls with each set.  The plan (parts per image) may differ
+    between a B-image and a 2B-image launch, and with it the items' scales: equal to float32 rounding, not bit for bit."""
+    from augcl_amd import encoder_hip
+    x = torch.from_numpy(np.random.RandomState(7 + B).randint(0, 256, (B, 9, 84, 84)).astype(np.float32)).to(cuda)
+    (wa, ba), (wb, bb) = _stack(1, 11, dev=cuda), _stack(2, 11, dev=cuda)
+    both = encoder_hip.conv_stack_infer(x, wa, ba, wb, bb, 2, 255.0)
+    assert both is not None and both.shape[0] == 2 * B
+    for half, (w, b) in ((both[:B], (wa, ba)), (both[B:], (wb, bb))):
+        one = encoder_hip.conv_stack_infer(x, w, b, None, None, 2, 255.0)
+        want = _ref64(x, w, b, 2, 255.0)
+        assert _rel(half, want) <= 3e-6 and _rel(one, want) <= 3e-6
+        assert _rel(half, one.double()) <= 2e-6
+
+
+def test_infer_is_reproducible_and_batch_position_free(cuda):
+    """Two calls give the same bits; an image's result does not depend on which other images share the launch as long as
+    the plan is the same (scales inside a chain are per work item; the chain's INPUT scale is the tensor's maximum, so the
+    companions are given the same maximum here)."""
+    from augcl_amd import encoder_hip
+    rs = np.random.RandomState(3)
+    x = torch.from_numpy(rs.randint(0, 256, (512, 9, 84, 84)).astype(np.float32)).to(cuda)
+    x[:, :, 0, 0] = 255.0  # every image holds the batch maximum
+    ws, bs = _stack(5, 11, dev=cuda)
+    a = encoder_hip.conv_stack_infer(x, ws, bs, None, None, 2, 255.0)
+    b = encoder_hip.conv_stack_infer(x, ws, bs, None, None, 2, 255.0)
+    assert torch.equal(a, b)
+    perm = torch.from_numpy(rs.permutation(512)).to(cuda)
+    c = encoder_hip.conv_stack_infer(x[perm].contiguous(), ws, bs, None, None, 2, 255.0)
+    # the first layer's output maximum (the chains' input scale) is a batch quantity: equal here up to its power of two
+    assert _rel(c, a[perm].double()) <= 1e-6
+
+
+@pytest.mark.parametrize("H,W,n_layers", [(84, 84, 11), (100, 100, 11), (64, 64, 6), (50, 70, 4), (36, 84, 3), (84, 40, 9)])
+def test_infer_other_frame_sizes(cuda, H, W, n_layers):
+    """Frame sizes the training stack never sees (the chain planner cuts them differently; the first layer takes its generic
+    kernel when the pipelined one does not cover the shape)."""
+    from augcl_amd import encoder_hip
+    B = 6
+    x = torch.from_numpy(np.random.RandomState(H + W).randint(0, 256, (B, 9, H, W)).astype(np.float32)).to(cuda)
+    ws, bs = _stack(H, n_layers, dev=cuda)
+    out = encoder_hip.conv_stack_infer(x, ws, bs, None, None, 2, 255.0)
+    want = _ref64(x, ws, bs, 2, 255.0)
+    if out is None:
+        pytest.skip("shape not covered by the chains (the caller falls back to the per-layer kernels)")
+    assert out.shape == want.shape and _rel(out, want) <= 3e-6
+
+
+@pytest.mark.parametrize("scale_x,scale_w", [(1.0, 1.0), (3e4, 1e-3), (1e-6, 30.0)])
+def test_infer_magnitudes_and_outlier_image(cuda, scale_x, scale_w):
+    """Activations / weights far from O(1), and ONE image 2^12 brighter than its companions: the chain's input scale is the
+    tensor's maximum, so the dim images sit 2^12 below it -- inside the f16 pairs' full-accuracy range; every image is
+    compared on its own scale."""
+    from augcl_amd import encoder_hip
+    B = 9
+    rs = np.random.RandomState(11)
+    x = torch.from_numpy(rs.randint(0, 256, (B, 9, 84, 84)).astype(np.float32)).to(cuda) * scale_x
+    x[4] *= 4096.0
+    ws, bs = _stack(21, 11, dev=cuda, bscale=0.0)
+    ws = [w * scale_w if i == 0 else w for i, w in enumerate(ws)]
+    out = encoder_hip.conv_stack_infer(x, ws, bs, None, None, 2, 255.0)
+    want = _ref64(x, ws, bs, 2, 255.0)
+    for i in range(B):
+        assert _rel(out[i], want[i]) <= 5e-6, i
+
+
+@pytest.mark.parametrize("B,Hi,Wi,nl,parts", [(3, 41, 41, 4, 2), (2, 33, 33, 6, 1), (4, 41, 41, 1, 1), (5, 23, 23, 1, 3), (2, 20, 37, 3, 2),
+                                              (1, 30, 12, 5, 4), (7, 13, 13, 5, 3), (2, 9, 80, 2, 5), (260, 33, 33, 6, 1),
+                                              (2, 41, 41, 2, 37), (1, 15, 15, 6, 3)])
+def test_chain_launch_on_odd_shapes(cuda, B, Hi, Wi, nl, parts):
+    """One chain launch through its (internal) entry point: layer counts 1..6, parts that do not divide the rows, wide and
+    narrow rows, a batch that is not a multiple of the grid, one-row parts -- against float64 convolutions."""
+    from augcl_amd import _lib
+    L = _lib.load()
+    if L.augcl_internal_chain_rounds(Hi, Wi, nl, parts) < 0:
+        pytest.skip("plan does not fit LDS")
+    g = torch.Generator(device=cuda).manual_seed(B * 1000 + Hi * 10 + Wi + nl)
+    x = torch.relu(torch.randn(B, 32, Hi, Wi, device=cuda, generator=g))
+    ws = [torch.randn(32, 32, 3, 3, device=cuda, generator=g) * 0.083 for _ in range(nl)]
+    bs = [torch.randn(32, device=cuda, generator=g) * 0.1 for _ in range(nl)]
+    st = ctypes.c_void_p(_lib.current_stream(cuda))
+    fb = L.augcl_enc_frag_workspace_bytes(1, 1)
+    frag = torch.empty(nl * fb, dtype=torch.uint8, device=cuda)
+    warr = (ctypes.c_void_p * nl)(*[w.data_ptr() for w in ws])
+    assert L.augcl_internal_x2_prep_weights(warr, nl, 0, ctypes.c_void_p(frag.data_ptr()), None, 0, st) == 0
+    am = torch.zeros(4, device=cuda)
+    am[0] = x.abs().max()
+    out = torch.full((B, 32, Hi - 2 * nl, Wi - 2 * nl), float("nan"), device=cuda)
+    fa = (ctypes.c_void_p * nl)(*[frag.data_ptr() + j * fb for j in range(nl)])
+    ba = (ctypes.c_void_p * nl)(*[b.data_ptr() for b in bs])
+    L.augcl_internal_chain_forward.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_int] * 6 + [ctypes.c_void_p] * 3
+    for relu_last in (0, 1):
+        am[2:] = 0
+        rc = L.augcl_internal_chain_forward(x.data_ptr(), out.data_ptr(), fa, ba, None, None, nl, B, Hi, Wi, parts, relu_last,
+                                            am.data_ptr(), am.data_ptr() + 8, st)
+        assert rc == 0, L.augcl_last_error()
+        y = x.double()
+        for j in range(nl):
+            y = F.conv2d(y, ws[j].double(), bs[j].double())
+            if j < nl - 1 or relu_last:
+                y = torch.relu(y)
+        assert not torch.isnan(out).any()
+        assert _rel(out, y) <= 3e-6
+        # the launch leaves max |out| for a following chain
+        assert abs(float(am[2]) - float(out.abs().max())) <= 1e-6 * float(out.abs().max())
