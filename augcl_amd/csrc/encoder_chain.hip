@@ -36,7 +36,7 @@ namespace augcl {
 
 constexpr int CH_MAXL = 6;    // layers per launch
 constexpr int CH_NU = 5;      // loader rounds per item: 256 lanes x CH_NU units of (4 pixels x 8 channels) = 1280 pixels
-constexpr int CH_HDR = 1024;  // LDS in front of the image: 4 x 128 B bias seeds (one copy per compute wave), the maxima
+constexpr int CH_HDR = 1280;  // LDS in front of the image: 4 x 128 B bias seeds (one copy per compute wave), the maxima, 4 dump slots
 
 struct ChainArgs {
     const float *in;              // (B,32,Hi,Wi) f32 NCHW: input of the chain's first layer (post-ReLU activations)
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(512, 2) void k_conv32_chain(ChainArgs a)
                 }
             }
         };
-        auto split = [&](int item) { // in place: d[u][2e], d[u][2e+1] (channels 2e, 2e+1 of 4 pixels) -> their hi dwords in d[u][2e], lo' in d[u][2e+1]
+        auto split = [&](int item) { // in place: d[u][2e], d[u][2e+1] (channels 2e, 2e+1 of 4 pixels) -> their hi dwords in d[u][2e], (unscaled) lo in d[u][2e+1]
             const ChainItem it = chain_item(a, item);
             const float s = pow2f(scale_exp(__builtin_amdgcn_readfirstlane((int)a.amax_in[it.grp])));
 #pragma unroll
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(512, 2) void k_conv32_chain(ChainArgs a)
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             uint32_t th, tl;
-                            split2h(__uint_as_float(d[u][2 * e][j]) * s, __uint_as_float(d[u][2 * e + 1][j]) * s, th, tl);
+                            split2u(__uint_as_float(d[u][2 * e][j]) * s, __uint_as_float(d[u][2 * e + 1][j]) * s, th, tl);
                             d[u][2 * e][j] = th; d[u][2 * e + 1][j] = tl;
                         }
                 }
@@ -179,8 +179,12 @@ __global__ __launch_bounds__(512, 2) void k_conv32_chain(ChainArgs a)
         return;
     }
 
-    // ---- compute waves.  Operand i = (tap t = i / 2, channel half s = i & 1); A fragment: W[row l31][k = 16 s + 8 h + j][t], hi and lo'
-    // parts in registers for one layer; the next layer's are requested as soon as the layer's last matrix instruction is out.
+    // ---- compute waves.  Operand i = (tap t = i / 2, channel half s = i & 1); A fragment: W[row l31][k = 16 s + 8 h + j][t], hi and
+    // (unscaled) lo parts in registers for one layer; the next layer's are requested as soon as the layer's last matrix instruction is out.
+    // All three products of a group (wl xh, wh xl, wh xh) go into ONE accumulator -- the residuals are unscaled here, unlike
+    // encoder_x2.hip's, because a chain's scales are per work item (no outlier image can push another one's values down f16's
+    // range) -- which leaves room for a SECOND accumulator set: a tile's epilogue (un-scale, ReLU, maximum, split, in-place store)
+    // is spread over the gaps of the NEXT tile's 54 matrix instructions, where a lone wave's vector instructions are free.
     f16x8 wh[18], wl[18];
     auto load_weights = [&](const vu4 *wf) {
 #pragma unroll
@@ -190,6 +194,7 @@ __global__ __launch_bounds__(512, 2) void k_conv32_chain(ChainArgs a)
         }
     };
     float *lbias = reinterpret_cast<float *>(ldsc) + 32 * cw; // this wave's copy of the layer's bias seeds (accumulator scale)
+    char *dump_slot = ldsc + 576 + 160 * cw;                  // 144 bytes nobody reads: where a lane without a pixel "stores"
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)((unsigned)(a.B * 32 * Hf * Wf) * 4u), 0x00020000);
     constexpr unsigned kNoStore = 0xfffffff0u;
     const int chw = Hf * Wf;
@@ -200,6 +205,7 @@ __global__ __launch_bounds__(512, 2) void k_conv32_chain(ChainArgs a)
     unsigned long long t_mark = t_kernel;
 #endif
     if (first < n) load_weights(a.wfrag[chain_item(a, first).grp][0]);
+    typedef uint32_t vu2 __attribute__((ext_vector_type(2)));
 
     for (int item = first; item < n; item += G) {
         const ChainItem it = chain_item(a, item);
@@ -209,8 +215,10 @@ __global__ __launch_bounds__(512, 2) void k_conv32_chain(ChainArgs a)
 #endif
         int k_in = scale_exp(__builtin_amdgcn_readfirstlane((int)a.amax_in[it.grp]));
         float amax_true = __uint_as_float(__builtin_amdgcn_readfirstlane((int)a.amax_in[it.grp])); // an upper bound of this item's max |x|
-        for (int j = 0; j < nl; ++j) {
-            const bool last = j == nl - 1;
+        // one layer of the chain; `last` (compile time: the epilogue slices sit between matrix instructions, where a scalar branch
+        // per slice would cost more than the slice) = the chain's last layer, which stores float32 to `out` instead of in place
+        auto layer = [&](int j, auto last_tag) {
+            constexpr bool last = decltype(last_tag)::value;
             const int Wout = Wi - 2 * (j + 1), nrow = it.ny + 2 * (nl - 1 - j);
             const int npix = nrow * Wout, ntiles = (npix + 31) >> 5, rounds = (ntiles + 3) >> 2;
             const uint32_t magic = a.magic_w[j];
@@ -229,6 +237,7 @@ __global__ __launch_bounds__(512, 2) void k_conv32_chain(ChainArgs a)
             const float un_in = pow2f(-k_in), c2 = pow2f(k_out - k_w); // two exact factors (their product may leave float32's range)
             const int relu_floor = __builtin_amdgcn_readfirstlane((!last || a.relu_last) ? 0 : (int)0x80000000);
             float vmax = 0.0f;
+            const vu4 *wf_next = !last ? a.wfrag[it.grp][j + 1] : (item + G < n ? a.wfrag[chain_item(a, item + G).grp][0] : wf);
 
             auto locate = [&](int tl, bool &valid_, int &off_, int &yy_, int &xx_) {
                 int m_ = tl * 32 + l31;
@@ -247,6 +256,45 @@ __global__ __launch_bounds__(512, 2) void k_conv32_chain(ChainArgs a)
                 if (part == 0) o.xh = *reinterpret_cast<const vu4 *>(p);
                 else o.xl = *reinterpret_cast<const vu4 *>(p + 64);
             };
+            // the previous tile of this wave: raw accumulators + where its results go (an LDS slot, or a byte offset of `out`)
+            f32x16 prev;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) prev[q] = 0.0f;
+            char *pdst = dump_slot;
+            unsigned pboff = kNoStore;
+            bool pending = false;
+            float tv[2]; // the pair being finished
+            uint32_t ph[2], pl[2]; // a finished group of four channels: hi / lo dwords
+            // one value of the previous tile: un-scale, ReLU, maximum; values come in pairs (channels c, c + 1) which are split into
+            // f16 (hi, lo) dwords; two pairs = the 8 + 8 bytes a lane stores per group of four channels
+            auto epi_value = [&](int q) {
+                float t = prev[q] * un_in * c2;
+                t = __int_as_float(max(__float_as_int(t), relu_floor));
+                vmax = fmaxf(vmax, fabsf(t));
+                if (last) {
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t), rs_out, pboff,
+                                                          (unsigned)(((q & 3) + 8 * (q >> 2)) * chw) * 4u, 0);
+                } else {
+                    tv[q & 1] = t;
+                }
+            };
+            auto epi_pair = [&](int q) { // q odd: values q - 1, q are final
+                if (!last) split2u(tv[0], tv[1], ph[(q >> 1) & 1], pl[(q >> 1) & 1]);
+            };
+            auto epi_store = [&](int q) { // q % 4 == 3: channels 8 (q / 4) + 4 h + (0..3) of the pixel
+                if (!last) {
+                    *reinterpret_cast<vu2 *>(pdst + 16 * (q >> 2)) = vu2{ph[0], ph[1]};
+                    *reinterpret_cast<vu2 *>(pdst + 16 * (q >> 2) + 64) = vu2{pl[0], pl[1]};
+                }
+            };
+            auto epilogue_now = [&]() { // the same, not hidden (a layer's last tile; a wave that has run out of tiles)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    epi_value(q);
+                    if (q & 1) epi_pair(q);
+                    if ((q & 3) == 3) epi_store(q);
+                }
+            };
             bool valid = false;
             int off = 0, yy = 0, xx = 0;
             Ops o[3];
@@ -255,52 +303,61 @@ __global__ __launch_bounds__(512, 2) void k_conv32_chain(ChainArgs a)
                 rd1(off, 0, o[0], 0); rd1(off, 0, o[0], 1);
                 rd1(off, 1, o[1], 0); rd1(off, 1, o[1], 1);
             }
-            // One round = the wave's tile 4 r + cw: operand reads + matrix instructions, the round's barrier, the in-place epilogue.
-            // The layer's LAST round is peeled (FINAL): behind its matrix instructions the next layer's (or the next item's first
-            // layer's) weight fragments are requested into the registers the layer just finished with -- unconditionally, at one
-            // place in the program (requested inside the loop under a condition they cost 80 spilled registers); they land during
-            // the epilogue and the layer barrier.
-            const vu4 *wf_next = !last ? a.wfrag[it.grp][j + 1] : (item + G < n ? a.wfrag[chain_item(a, item + G).grp][0] : wf);
+            // One round = the wave's tile 4 r + cw: operand reads + matrix instructions (+ the previous tile's epilogue in their gaps),
+            // then the round's barrier.  The previous tile's in-place stores are behind the barrier of ITS round, as they must be, and
+            // in front of every later read (a tile reads at and behind its own pixels).  The layer's LAST round is peeled (FINAL):
+            // behind its matrix instructions the next layer's (or the next item's first layer's) weight fragments are requested
+            // into the registers the layer just finished with -- unconditionally, at one place in the program (requested inside
+            // the loop under a condition they cost 80 spilled registers); they land during the last epilogue and the layer barrier.
             auto round = [&](int r, auto final_round) {
                 constexpr bool FINAL = decltype(final_round)::value;
                 const int tl = 4 * r + cw;
                 const bool active = tl < ntiles; // wave-uniform
-                f32x16 acc, accx;
-                bool valid2 = false;
-                int off2 = 0, yy2 = 0, xx2 = 0;
 #ifdef AUGCL_TUNING
                 { const unsigned long long t = __builtin_amdgcn_s_memtime(); c_layer += t - t_mark; t_mark = t; ++c_rounds; }
 #endif
                 if (active) {
+                    bool valid2;
+                    int off2, yy2, xx2;
                     locate(tl + 4 < ntiles ? tl + 4 : tl, valid2, off2, yy2, xx2); // no next tile: re-read this one
+                    f32x16 acc;
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4) { // accumulator seed = bias of rows 8 g4 + 4 h + (0..3)
                         const vf4 b4 = *reinterpret_cast<const vf4 *>(lbias + 8 * g4 + 4 * h);
                         acc[4 * g4] = b4[0]; acc[4 * g4 + 1] = b4[1]; acc[4 * g4 + 2] = b4[2]; acc[4 * g4 + 3] = b4[3];
                     }
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) accx[q] = 0.0f;
-#define CH_MM(C_, A_, B_) C_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_, __builtin_bit_cast(f16x8, B_), C_, 0, 0, 0)
+#define CH_MM(A_, B_) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_, __builtin_bit_cast(f16x8, B_), acc, 0, 0, 0)
 #pragma unroll
                     for (int i = 0; i < 18; ++i) {
                         Ops &cur = o[i % 3];
                         Ops &nn = o[(i + 2) % 3];
                         const int noff = i < 16 ? off : off2, ni = i < 16 ? i + 2 : i - 16; // the operand two groups on (across the tile boundary)
-                        // smallest products first: wl' xh, wh xl' (cross), wh xh (main); one LDS read between matrix instructions
-                        CH_MM(accx, wl[i], cur.xh);
+                        // smallest products first: wl xh, wh xl (cross), wh xh (main); between them one LDS read and a slice of the
+                        // previous tile's epilogue
+                        CH_MM(wl[i], cur.xh);
                         __builtin_amdgcn_sched_barrier(0);
                         rd1(noff, ni, nn, 0);
+                        if (i < 16) epi_value(i);
                         __builtin_amdgcn_sched_barrier(0);
-                        CH_MM(accx, wh[i], cur.xl);
+                        CH_MM(wh[i], cur.xl);
                         __builtin_amdgcn_sched_barrier(0);
                         rd1(noff, ni, nn, 1);
+                        if (i < 16 && (i & 1)) epi_pair(i);
                         __builtin_amdgcn_sched_barrier(0);
-                        CH_MM(acc, wh[i], cur.xh);
+                        CH_MM(wh[i], cur.xh);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (i < 16 && (i & 3) == 3) epi_store(i);
                         __builtin_amdgcn_sched_barrier(0);
                     }
 #undef CH_MM
-                    // (a later tile's operands 0, 1 were read before this round's barrier: they lie in front of every pixel the
-                    // round writes -- a tile reads at and behind its own pixels, the round writes pixels of EARLIER tiles only)
+                    prev = acc;
+                    pdst = valid ? img + (yy * Wi + xx) * X2_SLOT + 8 * h : dump_slot;
+                    pboff = valid ? (unsigned)((it.b * 32 * Hf + (it.y0 + yy)) * Wf + xx + 4 * h * chw) * 4u : kNoStore;
+                    pending = true;
+                    valid = valid2; off = off2; yy = yy2; xx = xx2;
+                } else if (pending) { // out of tiles: finish the last one (its round's barrier is behind us)
+                    epilogue_now();
+                    pending = false;
                 }
                 if (FINAL) load_weights(wf_next);
 #ifdef AUGCL_TUNING
@@ -310,44 +367,13 @@ __global__ __launch_bounds__(512, 2) void k_conv32_chain(ChainArgs a)
 #ifdef AUGCL_TUNING
                 { const unsigned long long t = __builtin_amdgcn_s_memtime(); c_wait += t - t_mark; t_mark = t; }
 #endif
-                if (active) {
-                    // rows in accumulator order: co = 0,1,2,3, 8,9,10,11, ... (+4 h)
-                    float v[16];
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        float t = __builtin_fmaf(accx[q], 1.0f / 2048.0f, acc[q]) * un_in * c2;
-                        t = __int_as_float(max(__float_as_int(t), relu_floor));
-                        vmax = fmaxf(vmax, fabsf(t));
-                        v[q] = t;
-                    }
-                    if (!last) {
-                        if (valid) {
-                            char *dst = img + (yy * Wi + xx) * X2_SLOT + 8 * h;
-#pragma unroll
-                            for (int g4 = 0; g4 < 4; ++g4) { // channels 8 g4 + 4 h + (0..3): 8 bytes of the hi plane, 8 of the lo' plane
-                                uint32_t h0, l0, h1, l1_;
-                                split2h(v[4 * g4], v[4 * g4 + 1], h0, l0);
-                                split2h(v[4 * g4 + 2], v[4 * g4 + 3], h1, l1_);
-                                typedef uint32_t vu2 __attribute__((ext_vector_type(2)));
-                                *reinterpret_cast<vu2 *>(dst + 16 * g4) = vu2{h0, h1};
-                                *reinterpret_cast<vu2 *>(dst + 16 * g4 + 64) = vu2{l0, l1_};
-                            }
-                        }
-                    } else {
-                        const unsigned boff = valid ? (unsigned)((it.b * 32 * Hf + (it.y0 + yy)) * Wf + xx + 4 * h * chw) * 4u : kNoStore;
-#pragma unroll
-                        for (int q = 0; q < 16; ++q)
-                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[q]), rs_out, boff,
-                                                                  (unsigned)(((q & 3) + 8 * (q >> 2)) * chw) * 4u, 0);
-                    }
-                    valid = valid2; off = off2; yy = yy2; xx = xx2;
-                }
-#ifdef AUGCL_TUNING
-                { const unsigned long long t = __builtin_amdgcn_s_memtime(); c_epi += t - t_mark; t_mark = t; }
-#endif
             };
             for (int r = 0; r + 1 < rounds; ++r) round(r, std::false_type{});
             round(rounds - 1, std::true_type{});
+            if (pending) epilogue_now(); // the wave's last tile of the layer (behind its round's barrier)
+#ifdef AUGCL_TUNING
+            { const unsigned long long t = __builtin_amdgcn_s_memtime(); c_epi += t - t_mark; t_mark = t; }
+#endif
             if (!last) {
                 // the item's maximum of this layer's output (scaled units): one LDS atomic per wave, read by all after the barrier
                 vmax = wave_max(vmax);
@@ -358,7 +384,9 @@ __global__ __launch_bounds__(512, 2) void k_conv32_chain(ChainArgs a)
             } else {
                 vmax_out[it.grp] = fmaxf(vmax_out[it.grp], vmax);
             }
-        }
+        };
+        for (int j = 0; j + 1 < nl; ++j) layer(j, std::false_type{});
+        layer(nl - 1, std::true_type{});
         __syncthreads(); // F
     }
 #ifdef AUGCL_TUNING

@@ -366,10 +366,10 @@ int augcl_enc_stack_infer(const float *x, const float *const *wA, const float *c
     // fragments of both sets (the first launch also zeroes the maxima: amax[2 c + set] = max |input of chain c| of that half)
     const size_t block = augcl_enc_frag_workspace_bytes(1, 1), setB = (size_t)(n_layers - 1) * block;
     if (n_layers >= 2) {
-        x3_prepare(wA, n_layers, 0, (char *)frag_ws, frag_ws_bytes, 0, stream, &rc, true, amax, 2 * (n_layers + 1));
+        x3_prepare(wA, n_layers, 2, (char *)frag_ws, frag_ws_bytes, 0, stream, &rc, true, amax, 2 * (n_layers + 1));
         if (rc != AUGCL_OK) return rc;
         if (wB) {
-            x3_prepare(wB, n_layers, 0, (char *)frag_ws, frag_ws_bytes, setB, stream, &rc, true);
+            x3_prepare(wB, n_layers, 2, (char *)frag_ws, frag_ws_bytes, setB, stream, &rc, true);
             if (rc != AUGCL_OK) return rc;
         }
     }

@@ -696,7 +696,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad32_x2(WgX2Args a)
 struct PrepX2Args {
     const float *w[32]; // (32,32,3,3) weights of the layers to prepare
     char *out;          // [n] blocks of X2_BLOCK_BYTES
-    int mode;           // 0: forward fragments, 1: backward-data (transposed, flipped taps)
+    int mode;           // bit 0: 0 forward fragments, 1 backward-data (transposed, flipped taps); bit 1: residuals unscaled
     uint32_t *zero;     // the pass's per-tensor maxima: zeroed here (one launch fewer than a memset), or null
     int n_zero;
 };
@@ -755,7 +755,7 @@ __global__ __launch_bounds__(256) void k_x2_prep(PrepX2Args a)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         float v0, v1;
-        if (a.mode == 0) { // W[co = l31][ci = k][t]
+        if ((a.mode & 1) == 0) { // W[co = l31][ci = k][t]
             v0 = w[l31 * 288 + (16 * s + 8 * h + 2 * e) * 9 + t];
             v1 = w[l31 * 288 + (16 * s + 8 * h + 2 * e + 1) * 9 + t];
         } else {           // W'[ci = l31][co = k][t] = W[co][ci][8 - t]
@@ -763,7 +763,8 @@ __global__ __launch_bounds__(256) void k_x2_prep(PrepX2Args a)
             v1 = w[(16 * s + 8 * h + 2 * e + 1) * 288 + l31 * 9 + (8 - t)];
         }
         uint32_t th, tl;
-        split2h(v0 * sw, v1 * sw, th, tl);
+        if (a.mode & 2) split2u(v0 * sw, v1 * sw, th, tl); // residual unscaled: every product of a group into ONE accumulator (encoder_chain.hip)
+        else split2h(v0 * sw, v1 * sw, th, tl);
         fh[e] = th; fl[e] = tl;
     }
     vu4 *o = reinterpret_cast<vu4 *>(a.out + (size_t)blockIdx.y * X2_BLOCK_BYTES);
@@ -896,7 +897,7 @@ int augcl_internal_x2_prep_weights(const float *const *w, int n, int mode, void 
                                    augcl_stream_t stream)
 {
     const char *name = "augcl_internal_x2_prep_weights";
-    AUGCL_REQUIRE(w && out && n >= 1 && n <= 32 && (mode == 0 || mode == 1) && aligned16(out), "%s: bad argument", name);
+    AUGCL_REQUIRE(w && out && n >= 1 && n <= 32 && mode >= 0 && mode <= 3 && aligned16(out), "%s: bad argument", name);
     static_assert((X2_FRAG_VU4 + 1) * 16 <= X2_BLOCK_BYTES, "fragment block");
     PrepX2Args a{};
     for (int i = 0; i < n; ++i) {

@@ -143,7 +143,7 @@ def test_chain_launch_on_odd_shapes(cuda, B, Hi, Wi, nl, parts):
     fb = L.augcl_enc_frag_workspace_bytes(1, 1)
     frag = torch.empty(nl * fb, dtype=torch.uint8, device=cuda)
     warr = (ctypes.c_void_p * nl)(*[w.data_ptr() for w in ws])
-    assert L.augcl_internal_x2_prep_weights(warr, nl, 0, ctypes.c_void_p(frag.data_ptr()), None, 0, st) == 0
+    assert L.augcl_internal_x2_prep_weights(warr, nl, 2, ctypes.c_void_p(frag.data_ptr()), None, 0, st) == 0  # mode 2: forward fragments, unscaled residuals
     am = torch.zeros(4, device=cuda)
     am[0] = x.abs().max()
     out = torch.full((B, 32, Hi - 2 * nl, Wi - 2 * nl), float("nan"), device=cuda)

@@ -20,7 +20,7 @@ for (Hi, nl, parts) in ((41, 4, 2), (33, 6, 1), (41, 1, 1), (41, 2, 1), (33, 1, 
     bs = [torch.randn(32, device=dev) * 0.1 for _ in range(nl)]
     frag = torch.empty(nl * fb, dtype=torch.uint8, device=dev)
     warr = (ctypes.c_void_p * nl)(*[w.data_ptr() for w in ws])
-    assert L.augcl_internal_x2_prep_weights(warr, nl, 0, ctypes.c_void_p(frag.data_ptr()), None, 0, st) == 0
+    assert L.augcl_internal_x2_prep_weights(warr, nl, 2, ctypes.c_void_p(frag.data_ptr()), None, 0, st) == 0  # mode 2: forward fragments, unscaled residuals
     am = torch.zeros(4, device=dev); am[0] = x.abs().max()
     out = torch.empty(B, 32, Hi - 2 * nl, Hi - 2 * nl, device=dev)
     fa = (ctypes.c_void_p * nl)(*[frag.data_ptr() + j * fb for j in range(nl)])
