@@ -178,11 +178,47 @@ class SAC(object):
             return head_ops.q_loss(q1, q2, target_Q)[0]
         return F.mse_loss(q1, target_Q) + F.mse_loss(q2, target_Q)
 
+    # ---- logged scalars: ONE device tensor, one collective, one host sync per update() ------------------------------------------
+    # The reference hands every scalar to L.log as a device tensor and its Logger calls .item() on each (src/logger.py:138-141):
+    # 3-7 device syncs per update.  Here update() COLLECTS what its sub-steps log (same keys, same values, same order),
+    # packs the values into one float64 vector on the device (one concatenation launch), averages that vector over the ranks with
+    # ONE all-reduce under data parallelism, copies it to the host ONCE and then calls L.log(key, float, step).  Sub-steps called
+    # on their own (update_critic(..., L, step) from a test) log immediately, as before.
+    _log_items = None
+
     def _log(self, L, key, value, step):
-        if L is not None:
-            if self._reducer is not None and torch.is_tensor(value):
-                value = self._reducer.mean_scalar(value)
-            L.log(key, value, step)
+        if L is None:
+            return
+        if self._log_items is not None:  # inside update(): collected, emitted together at its end
+            self._log_items.append((key, value))
+            return
+        if self._reducer is not None and torch.is_tensor(value):
+            value = self._reducer.mean_scalar(value)
+        L.log(key, value, step)
+
+    def _pack_logs(self):
+        """(keys, float64 device vector of the collected values, averaged over the ranks) -- part of a captured graph in
+        hipGraph mode.  Values are 0-dim tensors (or python numbers); float32 -> float64 is exact."""
+        items, self._log_items = self._log_items, None
+        if not items:
+            return (), None
+        keys = tuple(k for k, _ in items)
+        vals = [v.detach().reshape(1) if torch.is_tensor(v) else torch.tensor([float(v)], device=self.device) for _, v in items]
+        f32 = [v for v in vals if v.dtype == torch.float32]
+        if len(f32) == len(vals):
+            vec = torch.cat(vals).to(torch.float64)           # one concatenation launch + one widening
+        else:                                                 # (the temperature's loss / value are float64 like log_alpha)
+            vec = torch.cat([v.to(torch.float64) for v in vals])
+        if self._reducer is not None and self._reducer.world > 1:
+            self._reducer.allreduce_mean_(vec)                # ONE collective for all of the update's scalars
+        return keys, vec
+
+    @staticmethod
+    def _emit_logs(L, keys, vec, step):
+        if L is None or vec is None:
+            return
+        for k, v in zip(keys, vec.tolist()):                  # ONE device-to-host copy (and sync) per update()
+            L.log(k, v, step)
 
     def _cuts(self, critic, begin=True):
         """Data parallel only: collect (begin) / hand over the CNN features of a critic's gradient-carrying passes, the
@@ -279,7 +315,18 @@ class SAC(object):
         do_target = step % self.critic_target_update_freq == 0
         if self._graph is not None:
             return self._graph_update(batch, L, step, do_actor, do_target)
-        self._learn(self._front_end(*batch), L, step, do_actor, do_target)
+        keys, vec = self._learn_logged(self._front_end(*batch), L, step, do_actor, do_target)
+        self._emit_logs(L, keys, vec, step)
+
+    def _learn_logged(self, t, L, step, do_actor, do_target):
+        """_learn with its logged scalars collected and packed: returns (keys, device vector) -- ((), None) without a logger"""
+        self._log_items = [] if L is not None else None
+        try:
+            self._learn(t, L, step, do_actor, do_target)
+        except BaseException:
+            self._log_items = None
+            raise
+        return self._pack_logs() if L is not None else ((), None)
 
     # ---- hipGraph mode ---------------------------------------------------------------------------------------
     def _optimizers(self):
@@ -322,7 +369,8 @@ class SAC(object):
         G = self._graph
         if G["seen"] < G["warmup"]:
             G["seen"] += 1
-            return self._learn(self._front_end(*batch), L, step, do_actor, do_target)
+            keys, vec = self._learn_logged(self._front_end(*batch), L, step, do_actor, do_target)
+            return self._emit_logs(L, keys, vec, step)
         if G["static"] is not None and tuple(batch[1].shape) != G["shapes"]:
             G.update(graphs={}, static=None, pool=None)  # another batch size: drop the graphs (and their memory pool)
         t = self._front_end(*batch, out=G["static"])
@@ -338,26 +386,23 @@ class SAC(object):
             d.copy_(s_)
         key = (bool(do_actor), bool(do_target), L is not None)
         if key not in G["graphs"]:
-            sink = _LogSink()
             g = torch.cuda.CUDAGraph()
             torch.cuda.synchronize()
-            with torch.cuda.graph(g, pool=G["pool"]):
-                self._learn(G["static"], sink if L is not None else None, step, do_actor, do_target)
+            with torch.cuda.graph(g, pool=G["pool"]):  # the packed log vector (and its all-reduce) is part of the graph
+                packed = self._learn_logged(G["static"], _CAPTURE_LOGGER if L is not None else None, step, do_actor, do_target)
             if G["pool"] is None:
                 G["pool"] = g.pool()
-            G["graphs"][key] = (g, sink)
-        g, sink = G["graphs"][key]
+            G["graphs"][key] = (g, packed)
+        g, (keys, vec) = G["graphs"][key]
         g.replay()
-        if L is not None:
-            for k, v in sink.items:
-                L.log(k, v, step)
+        self._emit_logs(L, keys, vec, step)
 
 
-class _LogSink:
-    """Stands in for the Logger while a graph is captured: remembers the (static) tensors that were logged."""
+class _CaptureLogger:
+    """Stands in for the Logger while a graph is captured (the scalars are collected by the agent, nothing is logged here)."""
 
-    def __init__(self):
-        self.items = []
+    def log(self, key, value, step, n=1):
+        raise RuntimeError("nothing logs directly inside a captured update()")
 
-    def log(self, key, value, step):
-        self.items.append((key, value))
+
+_CAPTURE_LOGGER = _CaptureLogger()

@@ -50,13 +50,89 @@ def _ring_replay(dev, B, A, transitions=3000, seed=0):
     return buf
 
 
-class _NullLogger:
+class _ReferenceLikeLogger:
+    """What the reference's Logger.log does with a value on the hot path (src/logger.py:138-141): a tensor is turned into a host
+    float with .item() -- one device sync per logged scalar -- then accumulated per key (its AverageMeter).  The agent here hands
+    over host floats (one packed copy per update()), so the .item() branch is not taken; it is kept so that the timing includes
+    it if an algorithm ever logs a tensor again."""
+
+    def __init__(self):
+        self.sums, self.counts, self.item_calls = {}, {}, 0
+
     def log(self, key, value, step, n=1):
-        pass
+        if type(value) is torch.Tensor:
+            value = value.item()
+            self.item_calls += 1
+        self.sums[key] = self.sums.get(key, 0.0) + value * n
+        self.counts[key] = self.counts.get(key, 0) + n
+
+
+def _densify_conv_weights(agent, seed=1234):
+    """Mid-training-like conv weights: the reference initialises every conv filter delta-orthogonal (src/algorithms/modules.py:
+    52-66: only the centre tap of each 3x3 filter is non-zero, biases 0), which is what a FRESH agent times; a trained network's
+    filters are dense.  He-scaled normal weights (std = sqrt(2 / fan_in)) and small biases, written in place into every conv stack
+    of the agent (actor / critic share one; the target has its own copy; AugCL's weak critic too)."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    done = set()
+    for m in agent._cnn_modules():
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Conv2d) and id(mod.weight) not in done:
+                done.add(id(mod.weight))
+                fan_in = mod.weight.shape[1] * 9
+                with torch.no_grad():
+                    mod.weight.copy_((torch.randn(mod.weight.shape, generator=g) * (2.0 / fan_in) ** 0.5).to(mod.weight.device))
+                    mod.bias.copy_((torch.randn(mod.bias.shape, generator=g) * 0.05).to(mod.bias.device))
+    return len(done)
+
+
+class _PowerSampler:
+    """Shader clock / board power while a leg runs (a background thread polling `rocm-smi` as a child process: reads sysfs, does
+    not touch the GPU queues).  Best effort: None where the tool or the fields are missing."""
+
+    def __init__(self, period=0.25):
+        import threading
+        self.period, self.rows, self._stop = period, [], threading.Event()
+        self._t = threading.Thread(target=self._loop, daemon=True)
+
+    def _loop(self):
+        import json
+        import subprocess
+        while not self._stop.is_set():
+            try:
+                out = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--json"], capture_output=True, text=True, timeout=5).stdout
+                card = next(iter(json.loads(out).values()))
+                sclk = next((v for k, v in card.items() if k.lower().startswith("sclk clock speed")), None)
+                power = next((v for k, v in card.items() if "power" in k.lower() and "(w)" in k.lower()), None)
+                mhz = float(str(sclk).strip("()").lower().replace("mhz", "")) if sclk is not None else None
+                self.rows.append((mhz, float(power) if power is not None else None))
+            except Exception:  # noqa: BLE001 -- a sampler must never take the bench down
+                pass
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        self._t.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop.set()
+        self._t.join(timeout=10)
+
+    def summary(self):
+        mhz = sorted(r[0] for r in self.rows if r[0])
+        w = sorted(r[1] for r in self.rows if r[1])
+        med = lambda v: v[len(v) // 2] if v else None  # noqa: E731
+        return {"samples": len(self.rows), "sclk_MHz_median": med(mhz), "sclk_MHz_min": mhz[0] if mhz else None,
+                "power_W_median": med(w), "power_W_max": w[-1] if w else None}
 
 
 def run(dev, dist, world, rank, steps=20, warmup=4, B=256, A=6, algo="svea", data_aug="conv", precision="f32", graph=False,
-        min_s=0.5, replay="synthetic"):
+        min_s=0.5, replay="synthetic", weights="init", logger=False, power=False):
+    """weights: "init" = a fresh agent (the reference's delta-orthogonal conv filters), "dense" = He-scaled dense filters
+    (_densify_conv_weights); logger: time update(buf, L, step) with a reference-like Logger instead of L = None; power: sample
+    sclk / board power during the timed region.  algo "augcl" = the strong phase after the curriculum hand-off
+    (src/algorithms/augcl.py:16-27: a non_naive_rad agent's critic aliased as the weak critic)."""
+    from . import augmentations
     from . import dist as apdist
     from . import encoder_ops
     from . import utils as au
@@ -73,16 +149,28 @@ def run(dev, dist, world, rank, steps=20, warmup=4, B=256, A=6, algo="svea", dat
     # replicas are made identical by the parameter broadcast at construction; everything random AFTER that differs per
     # rank (actor noise from torch's generator; augmentation parameters are keyed by the global sample index)
     apdist.seed_all(0, rank)
+    if "overlay" in data_aug:
+        augmentations.set_overlay_source(augmentations.SyntheticOverlaySource(seed=7))
     agent = make_agent((9, 84, 84), (A,), au.dotdict(algorithm=algo, data_aug=data_aug, aug_params=None, **hp))
+    if algo == "augcl":
+        prev = make_agent((9, 84, 84), (A,), au.dotdict(algorithm="non_naive_rad", data_aug="shift", aug_params=None, **hp))
+        agent.load_pretrained_agent(prev)
+    if weights == "dense":
+        _densify_conv_weights(agent)
+    elif weights != "init":
+        raise ValueError("weights must be 'init' or 'dense'")
     if graph:  # replay the learning part of update() as captured hipGraphs (SAC.enable_hip_graphs)
         agent.enable_hip_graphs()
         warmup = max(warmup, 8)  # 3 eager updates, then one capture per (actor step?, target step?) variant
     buf = _SyntheticReplay(dev, B, A, seed=100 + rank) if replay == "synthetic" else _ring_replay(dev, B, A, seed=100 + rank)
-    L = None  # no logging inside the timed region (the reference's Logger syncs per scalar)
+    L = _ReferenceLikeLogger() if logger else None  # (default: no logging inside the timed region)
     for s in range(warmup):
         agent.update(buf, L, s)
     torch.cuda.synchronize()
     walls, step0 = [], warmup
+    sampler = _PowerSampler() if (power and rank == 0) else None
+    if sampler is not None:
+        sampler.__enter__()
     while True:  # blocks of exactly `steps` updates between barrier + synchronize, until min_s seconds are timed
         if dist is not None:
             dist.barrier()
@@ -103,6 +191,8 @@ def run(dev, dist, world, rank, steps=20, warmup=4, B=256, A=6, algo="svea", dat
         step0 += steps
         if sum(walls) >= min_s or len(walls) >= 200:
             break
+    if sampler is not None:
+        sampler.__exit__()
     wall = sorted(walls)[len(walls) // 2]
     encoder_ops.set_precision("f32")
     flops = 432e9 * (B / 256)  # ALGORITHMIC: ~1.69 GFLOP per sample per average step of the reference's update
@@ -115,7 +205,9 @@ def run(dev, dist, world, rank, steps=20, warmup=4, B=256, A=6, algo="svea", dat
             "approx_TFLOP/s_per_gpu": flops * steps / wall / 1e12, "algorithmic_TFLOP/s": flops * steps / wall / 1e12,
             "executed_TFLOP/s": flops_exec["total"] * steps / wall / 1e12, "executed_GFLOP_per_update": flops_exec["total"] / 1e9,
             "executed_conv32_GFLOP_per_update": flops_exec["conv32"] / 1e9, "encoder_backend": "hip",
-            "hip_graph": bool(graph), "world": world}
+            "hip_graph": bool(graph), "world": world, "conv_weights": weights, "with_logger": bool(logger),
+            "logger_item_calls": (L.item_calls if L is not None else None),
+            "clock_power": sampler.summary() if sampler is not None else None}
 
 
 def executed_flops_per_update(B, A, n_layers=11, hidden=1024, proj=100):

@@ -501,6 +501,26 @@ def main():
                 # sample + shift + conv as one pass over the ring; next_obs gathered straight into the graph's static input)
                 res["sac"]["from_uint8_replay_ring_ms_per_update"] = bench_update.run(
                     dev, dist, world, rank, steps=max(10, n_upd // 2), precision="f32", graph=True, min_s=0.2, replay="ring")["ms_per_update"]
+                # the same update() on DENSE conv filters (He-scaled; a fresh agent's are delta-orthogonal: 8 of 9 taps exactly zero,
+                # src/algorithms/modules.py:52-66 -- dense operands cost the matrix pipe more power) with the shader clock / board power
+                # sampled during both, and with a reference-like Logger in the loop (src/logger.py:138-141) instead of L = None
+                init_p = bench_update.run(dev, dist, world, rank, steps=n_upd, precision="f32", graph=True, min_s=2.0, power=True)
+                dense = bench_update.run(dev, dist, world, rank, steps=n_upd, precision="f32", graph=True, min_s=2.0, power=True,
+                                         weights="dense")
+                res["sac"]["delta_init_vs_dense_weights"] = {
+                    "delta_init": {"ms_per_update": init_p["ms_per_update"], **(init_p["clock_power"] or {})},
+                    "dense": {"ms_per_update": dense["ms_per_update"], **(dense["clock_power"] or {})}}
+                lg = bench_update.run(dev, dist, world, rank, steps=n_upd, precision="f32", graph=True, min_s=0.5, logger=True)
+                res["sac"]["with_logger_ms_per_update"] = lg["ms_per_update"]
+                res["sac"]["with_logger_item_calls"] = lg["logger_item_calls"]
+                if dist is None:
+                    # what each data-parallel rank of config 4 (AugCL conv-overlay, global batch 1024) will run: update() at the
+                    # per-rank batches of 1 / 2 / 4 / 8 ranks on ONE GPU -- no collective here; DESIGN.md section 6 turns these
+                    # into the scaling ceiling the first 8-GPU run is to be checked against
+                    res["sac"]["augcl_conv_overlay_ms_per_update_by_batch"] = {
+                        str(b_): bench_update.run(dev, None, 1, 0, steps=max(10, n_upd // 4), B=b_, algo="augcl", data_aug="conv-overlay",
+                                                  precision="f32", graph=True, min_s=0.3)["ms_per_update"]
+                        for b_ in (1024, 512, 256, 128)}
             res["sac"]["select_action_us"] = bench_update.action_latency(dev)  # batch-1 acting, eager vs captured graph
         except Exception as e:  # noqa: BLE001 -- the headline above is measured: report the failure, do not lose the line
             import traceback

@@ -197,3 +197,73 @@ def test_two_groups_two_steps_overlapped_exchange_matches_single_process():
         assert base == 4 * rank  # rank r's first sample in the global batch (augmentations.set_sample_base)
     np.testing.assert_array_equal(res[0][1], res[1][1])  # replicas stay bit-identical
     assert res[0][3] != res[1][3]  # ... while their noise streams differ (dist.seed_all: seed + rank)
+
+
+class _RecordingLogger:
+    def __init__(self):
+        self.rows = []
+
+    def log(self, key, value, step, n=1):
+        assert isinstance(value, float), f"{key}: the logger is handed host floats, not device tensors ({type(value)})"
+        self.rows.append((key, value, step))
+
+
+def _worker_logs(rank, world, port, q):
+    """The host logic of SAC.update()'s logging on CPU tensors: the real SAC._log / _learn_logged / _pack_logs / _emit_logs on a
+    bare object (building an agent needs the GPU), a _learn that logs what SVEA + the actor step log, the real GradReducer."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    red = apdist.init_from_env(backend="gloo")
+    from augcl_amd.algorithms.sac import SAC
+    calls = []
+    real = dist.all_reduce
+
+    def counting_all_reduce(t, *a, **k):
+        calls.append(tuple(t.shape))
+        return real(t, *a, **k)
+
+    dist.all_reduce = counting_all_reduce
+    agent = SAC.__new__(SAC)
+    agent.device, agent._reducer, agent._graph = torch.device("cpu"), red, None
+    keys = ["train_critic/shift_loss", "train_critic/aug_loss", "train_critic/loss", "train_actor/loss",
+            "train_actor/mean_entropy", "train_alpha/loss", "train_alpha/value"]
+
+    def learn(t, L, step, do_actor, do_target):
+        for i, k in enumerate(keys if do_actor else keys[:3]):
+            v = torch.tensor(float(10 * rank + i + step), dtype=torch.float64 if "alpha" in k else torch.float32)
+            agent._log(L, k, v, step)
+
+    agent._learn = learn
+    L = _RecordingLogger()
+    for step, do_actor in ((0, True), (1, False)):
+        ks, vec = agent._learn_logged(None, L, step, do_actor, False)
+        agent._emit_logs(L, ks, vec, step)
+    none_keys, none_vec = agent._learn_logged(None, None, 2, True, False)  # no logger: nothing packed, nothing exchanged
+    q.put((rank, L.rows, calls, none_keys, none_vec))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_logged_scalars_one_collective_and_host_floats_per_update():
+    """the <= 7 logged scalars of an update() travel as ONE vector -- one all-reduce under data parallelism, one
+    device-to-host copy -- and reach L.log(key, value, step) as floats under the reference's keys (src/algorithms/sac.py:113,
+    130-131, 142-143; svea.py:57-60), each the mean over the ranks' shard values."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_logs, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, rows, calls, none_keys, none_vec in res:
+        assert calls == [(7,), (3,)], calls  # exactly one scalar all-reduce per update(), none without a logger
+        assert none_keys == () and none_vec is None
+        assert [k for k, _, s in rows if s == 0] == ["train_critic/shift_loss", "train_critic/aug_loss", "train_critic/loss",
+                                                     "train_actor/loss", "train_actor/mean_entropy", "train_alpha/loss",
+                                                     "train_alpha/value"]
+        for i, (k, v, s) in enumerate(r for r in rows if r[2] == 0):
+            assert v == pytest.approx((0 + i + 10 + i) / 2.0)  # mean of rank 0's i and rank 1's 10 + i
+        assert [round(v, 6) for _, v, s in rows if s == 1] == [6.0, 7.0, 8.0]
+    assert res[0][1] == res[1][1]  # both ranks log the same numbers
