@@ -197,15 +197,17 @@ class SAC(object):
         L.log(key, value, step)
 
     def _pack_logs(self):
-        """(keys, float64 device vector of the collected values, averaged over the ranks) -- part of a captured graph in
-        hipGraph mode.  Values are 0-dim tensors (or python numbers); float32 -> float64 is exact."""
+        """(keys, float64 device vector of the collected TENSOR values, averaged over the ranks) -- part of a captured graph in
+        hipGraph mode.  A key whose value is a python number (DrQ's variances at K = M = 1: the constant 0) carries it in `keys`
+        as (name, number): no host-to-device copy, which a capturing stream would refuse.  float32 -> float64 is exact."""
         items, self._log_items = self._log_items, None
         if not items:
             return (), None
-        keys = tuple(k for k, _ in items)
-        vals = [v.detach().reshape(1) if torch.is_tensor(v) else torch.tensor([float(v)], device=self.device) for _, v in items]
-        f32 = [v for v in vals if v.dtype == torch.float32]
-        if len(f32) == len(vals):
+        keys = tuple(k if torch.is_tensor(v) else (k, float(v)) for k, v in items)
+        vals = [v.detach().reshape(1) for _, v in items if torch.is_tensor(v)]
+        if not vals:
+            return keys, None
+        if all(v.dtype == torch.float32 for v in vals):
             vec = torch.cat(vals).to(torch.float64)           # one concatenation launch + one widening
         else:                                                 # (the temperature's loss / value are float64 like log_alpha)
             vec = torch.cat([v.to(torch.float64) for v in vals])
@@ -215,10 +217,14 @@ class SAC(object):
 
     @staticmethod
     def _emit_logs(L, keys, vec, step):
-        if L is None or vec is None:
+        if L is None or not keys:
             return
-        for k, v in zip(keys, vec.tolist()):                  # ONE device-to-host copy (and sync) per update()
-            L.log(k, v, step)
+        host = iter(vec.tolist()) if vec is not None else iter(())  # ONE device-to-host copy (and sync) per update()
+        for k in keys:
+            if isinstance(k, tuple):
+                L.log(k[0], k[1], step)
+            else:
+                L.log(k, next(host), step)
 
     def _cuts(self, critic, begin=True):
         """Data parallel only: collect (begin) / hand over the CNN features of a critic's gradient-carrying passes, the
