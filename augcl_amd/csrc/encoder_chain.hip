@@ -120,9 +120,24 @@ __global__ __launch_bounds__(512, 2) void k_conv32_chain(ChainArgs a)
                 }
             }
         };
-        auto split = [&](int item) { // in place: d[u][2e], d[u][2e+1] (channels 2e, 2e+1 of 4 pixels) -> their hi dwords in d[u][2e], (unscaled) lo in d[u][2e+1]
-            const ChainItem it = chain_item(a, item);
-            const float s = pow2f(scale_exp(__builtin_amdgcn_readfirstlane((int)a.amax_in[it.grp])));
+        uint32_t amax_bits = 0u; // max |x| of the staged item (float bits): its scale, handed to the compute waves with the image
+        auto item_max = [&]() {  // this wave's share of it, into lred[12] (zeroed at the previous dump)
+            float m = 0.0f;
+#pragma unroll
+            for (int u = 0; u < CH_NU; ++u) {
+                if (256 * u < npx) {
+#pragma unroll
+                    for (int c = 0; c < 8; c += 2)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            m = fmaxf(m, fmaxf(fabsf(__uint_as_float(d[u][c][j])), fabsf(__uint_as_float(d[u][c + 1][j]))));
+                }
+            }
+            m = wave_max(m);
+            if (lane == 0) atomicMax(lred + 12, __float_as_uint(m));
+        };
+        auto split = [&]() { // in place: d[u][2e], d[u][2e+1] (channels 2e, 2e+1 of 4 pixels) -> their hi dwords in d[u][2e], (unscaled) lo in d[u][2e+1]
+            const float s = pow2f(scale_exp(amax_bits));
 #pragma unroll
             for (int u = 0; u < CH_NU; ++u) {
                 if (256 * u < npx) {
@@ -150,11 +165,25 @@ __global__ __launch_bounds__(512, 2) void k_conv32_chain(ChainArgs a)
                     }
                 }
             }
-            if (lt < 16) lred[lt] = 0u; // the item's maxima: every read of the previous item's is behind us (barrier F)
-        };
+            if (lt < 16) lred[lt] = lt == 13 ? amax_bits : 0u; // the item's maxima start at zero (every read of the previous item's is
+        };                                                      // behind us: barrier F); [13] = the image's own maximum
+        // The staged item's scale is ITS OWN maximum (not the tensor's: an outlier image elsewhere in the batch must not push this
+        // one's values down f16's range -- the residuals are unscaled here): every loader wave adds its share to an LDS word, a
+        // workgroup barrier later all four read the total.  The first item pays two barriers of its own (P0, P1: the compute waves
+        // execute them too); later items use two of the barriers the compute waves go through anyway.  A one-layer chain has no
+        // such barriers: its items are scaled by the tensor's maximum (amax_in), like encoder_x2.hip's.
+        const bool own_max = nl >= 2;
+        if (lt < 16) lred[lt] = 0u;
+        __syncthreads(); // P0
         if (first < n) {
             issue(first);
-            split(first);
+            if (own_max) item_max();
+        }
+        __syncthreads(); // P1
+        if (first < n) {
+            amax_bits = own_max ? (uint32_t)__builtin_amdgcn_readfirstlane((int)lred[12])
+                                : (uint32_t)__builtin_amdgcn_readfirstlane((int)a.amax_in[chain_item(a, first).grp]);
+            split();
             dump();
         }
         for (int item = first; item < n; item += G) {
@@ -164,15 +193,20 @@ __global__ __launch_bounds__(512, 2) void k_conv32_chain(ChainArgs a)
             const int ny = chain_item(a, item).ny;
             int nb = 0; // the compute waves' barriers inside this item: one per round and one per layer, last layer excepted
             for (int j = 0; j + 1 < nl; ++j) nb += chain_rounds(a, j, ny) + 1;
-            bool done = nxt >= n;
+            const bool have = nxt < n;
+            const int at = nb >= 2 ? nb / 2 : 0; // half way: the loads issued at the item's start have long landed
             for (int i = 0; i < nb; ++i) {
-                if (!done && 2 * i >= nb) { // half way: the loads issued at the item's start have long landed
-                    split(nxt);
-                    done = true;
+                if (have && own_max && i + 1 == at) item_max(); // (nb >= 2 whenever nl >= 2)
+                if (have && own_max && i == at) {
+                    amax_bits = (uint32_t)__builtin_amdgcn_readfirstlane((int)lred[12]);
+                    split();
                 }
                 __syncthreads();
             }
-            if (!done) split(nxt);
+            if (have && !own_max) {
+                amax_bits = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.amax_in[chain_item(a, nxt).grp]);
+                split();
+            }
             __syncthreads(); // F: every read of the image is done
             if (nxt < n) dump();
         }
@@ -193,6 +227,14 @@ __global__ __launch_bounds__(512, 2) void k_conv32_chain(ChainArgs a)
             wl[i] = __builtin_bit_cast(f16x8, wf[(18 + i) * 64 + lane]);
         }
     };
+    uint32_t nx_kw = 0u, nx_l1 = 0u; // the coming layer's weight exponent / largest absolute row sum (float bits) ...
+    float nx_bv = 0.0f;              // ... and bias (lane c < 32: channel c)
+    auto load_consts = [&](const vu4 *wf, const float *bsrc) {
+        const uint32_t *tail = reinterpret_cast<const uint32_t *>(wf + X2_FRAG_VU4);
+        nx_kw = tail[0];
+        nx_l1 = tail[1];
+        nx_bv = (bsrc && lane < 32) ? bsrc[lane] : 0.0f;
+    };
     float *lbias = reinterpret_cast<float *>(ldsc) + 32 * cw; // this wave's copy of the layer's bias seeds (accumulator scale)
     char *dump_slot = ldsc + 576 + 160 * cw;                  // 144 bytes nobody reads: where a lane without a pixel "stores"
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)((unsigned)(a.B * 32 * Hf * Wf) * 4u), 0x00020000);
@@ -204,7 +246,13 @@ __global__ __launch_bounds__(512, 2) void k_conv32_chain(ChainArgs a)
     const unsigned long long t_kernel = __builtin_amdgcn_s_memtime(), r_kernel = __builtin_amdgcn_s_memrealtime();
     unsigned long long t_mark = t_kernel;
 #endif
-    if (first < n) load_weights(a.wfrag[chain_item(a, first).grp][0]);
+    if (first < n) {
+        const int g0 = chain_item(a, first).grp;
+        load_weights(a.wfrag[g0][0]);
+        load_consts(a.wfrag[g0][0], a.bias[g0][0]);
+    }
+    __syncthreads(); // P0
+    __syncthreads(); // P1 (the loaders agree on the first item's maximum between the two)
     typedef uint32_t vu2 __attribute__((ext_vector_type(2)));
 
     for (int item = first; item < n; item += G) {
@@ -213,8 +261,9 @@ __global__ __launch_bounds__(512, 2) void k_conv32_chain(ChainArgs a)
 #ifdef AUGCL_TUNING
         { const unsigned long long t = __builtin_amdgcn_s_memtime(); c_item += t - t_mark; t_mark = t; }
 #endif
-        int k_in = scale_exp(__builtin_amdgcn_readfirstlane((int)a.amax_in[it.grp]));
-        float amax_true = __uint_as_float(__builtin_amdgcn_readfirstlane((int)a.amax_in[it.grp])); // an upper bound of this item's max |x|
+        const uint32_t ain = (uint32_t)__builtin_amdgcn_readfirstlane((int)lred[13]); // left by the loaders with the image
+        int k_in = scale_exp(ain);
+        float amax_true = __uint_as_float(ain); // max |x| of this item (one-layer chains: of the tensor)
         // one layer of the chain; `last` (compile time: the epilogue slices sit between matrix instructions, where a scalar branch
         // per slice would cost more than the slice) = the chain's last layer, which stores float32 to `out` instead of in place
         auto layer = [&](int j, auto last_tag) {
@@ -223,21 +272,23 @@ __global__ __launch_bounds__(512, 2) void k_conv32_chain(ChainArgs a)
             const int npix = nrow * Wout, ntiles = (npix + 31) >> 5, rounds = (ntiles + 3) >> 2;
             const uint32_t magic = a.magic_w[j];
             const vu4 *wf = a.wfrag[it.grp][j];
-            const uint32_t *tail = reinterpret_cast<const uint32_t *>(wf + X2_FRAG_VU4);
-            const int k_w = __builtin_amdgcn_readfirstlane((int)tail[0]);
-            const float l1 = __uint_as_float(__builtin_amdgcn_readfirstlane((int)tail[1]));
-            const float *bsrc = a.bias[it.grp][j];
+            // the layer's constants (weights' exponent, their largest row sum, the bias) were requested together with its weight
+            // fragments, a layer ago: nothing global is waited for between two layers
+            const int k_w = __builtin_amdgcn_readfirstlane((int)nx_kw);
+            const float l1 = __uint_as_float(__builtin_amdgcn_readfirstlane((int)nx_l1));
             // bias seeds and their maximum (this wave's own LDS copy: no barrier between the layers' bias traffic)
-            float bv = (bsrc && lane < 32) ? bsrc[lane] : 0.0f;
+            const float bv = nx_bv;
             const float bmax = wave_max(fabsf(bv));
             if (lane < 32) lbias[lane] = bv * pow2f(k_in) * pow2f(k_w);
             // the scale of what this layer stores: 0 for the chain's output (float32), else from the a-priori bound of the item
             int k_out = 0;
             if (!last) k_out = scale_exp(__float_as_uint((l1 * amax_true + bmax) * 1.001f));
-            const float un_in = pow2f(-k_in), c2 = pow2f(k_out - k_w); // two exact factors (their product may leave float32's range)
             const int relu_floor = __builtin_amdgcn_readfirstlane((!last || a.relu_last) ? 0 : (int)0x80000000);
             float vmax = 0.0f;
-            const vu4 *wf_next = !last ? a.wfrag[it.grp][j + 1] : (item + G < n ? a.wfrag[chain_item(a, item + G).grp][0] : wf);
+            const int grp_next = !last ? it.grp : (item + G < n ? chain_item(a, item + G).grp : it.grp);
+            const int j_next = !last ? j + 1 : (item + G < n ? 0 : j);
+            const vu4 *wf_next = a.wfrag[grp_next][j_next];
+            const float *b_next = a.bias[grp_next][j_next];
 
             auto locate = [&](int tl, bool &valid_, int &off_, int &yy_, int &xx_) {
                 int m_ = tl * 32 + l31;
@@ -263,37 +314,61 @@ __global__ __launch_bounds__(512, 2) void k_conv32_chain(ChainArgs a)
             char *pdst = dump_slot;
             unsigned pboff = kNoStore;
             bool pending = false;
-            float tv[2]; // the pair being finished
-            uint32_t ph[2], pl[2]; // a finished group of four channels: hi / lo dwords
-            // one value of the previous tile: un-scale, ReLU, maximum; values come in pairs (channels c, c + 1) which are split into
-            // f16 (hi, lo) dwords; two pairs = the 8 + 8 bytes a lane stores per group of four channels
-            auto epi_value = [&](int q) {
-                float t = prev[q] * un_in * c2;
-                t = __int_as_float(max(__float_as_int(t), relu_floor));
-                vmax = fmaxf(vmax, fabsf(t));
+            // The previous tile's epilogue as a SOFTWARE PIPELINE over the 54 gaps between the current tile's matrix instructions
+            // (slot g = 3 i + {0, 1, 2} behind the three instructions of operand group i): a lone wave's vector instruction is free
+            // in a gap only while it does not wait for the one just before it (a dependent instruction issues ~7 cycles later, an
+            // independent one 4: three dependent ones plus the group's LDS read overran the 32-cycle gap -- +400 cycles per tile in
+            // the first version).  So every slot holds instructions whose inputs are at least one slot old:
+            //   3q      s_q = prev_q 2^kk                      (v_ldexp_f32: the un-scale and the next layer's scale in one, any kk)
+            //   3q + 1  t_q = max(s_q, 0 | -inf)               (ReLU as an integer maximum)           [chain's last layer: 3q + 2 store]
+            //   3q + 2  (q odd)  hi = f16x2(t_{q-1}, t_q),  vmax = max(vmax, t_{q-1}, t_q)
+            //   3q + 3  f = f32(hi)   3q + 4  r = t - f   3q + 5  lo = f16x2(r)   3q + 6 (q % 4 == 3)  the two 8-byte LDS stores
+            float sv[16], tvv[16];
+            uint32_t hi2[8], lo2[8];
+            float f0[8], f1[8];
+            const int kk = k_out - k_in - k_w; // |kk| <= 194: ldexp takes it in one step, two float factors could not
+            auto epi_slot = [&](int g) {
+                const int q = g / 3, ph = g % 3;
+                if (ph == 0 && q < 16) sv[q] = __builtin_amdgcn_ldexpf(prev[q], kk);
+                if (ph == 1 && q < 16) tvv[q] = __int_as_float(max(__float_as_int(sv[q]), relu_floor));
                 if (last) {
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t), rs_out, pboff,
-                                                          (unsigned)(((q & 3) + 8 * (q >> 2)) * chw) * 4u, 0);
-                } else {
-                    tv[q & 1] = t;
+                    if (ph == 2 && q < 16) {
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, tvv[q]), rs_out, pboff,
+                                                              (unsigned)(((q & 3) + 8 * (q >> 2)) * chw) * 4u, 0);
+                        if (q & 1) vmax = fmaxf(vmax, fmaxf(fabsf(tvv[q - 1]), fabsf(tvv[q])));
+                    }
+                    return;
                 }
-            };
-            auto epi_pair = [&](int q) { // q odd: values q - 1, q are final
-                if (!last) split2u(tv[0], tv[1], ph[(q >> 1) & 1], pl[(q >> 1) & 1]);
-            };
-            auto epi_store = [&](int q) { // q % 4 == 3: channels 8 (q / 4) + 4 h + (0..3) of the pixel
-                if (!last) {
-                    *reinterpret_cast<vu2 *>(pdst + 16 * (q >> 2)) = vu2{ph[0], ph[1]};
-                    *reinterpret_cast<vu2 *>(pdst + 16 * (q >> 2) + 64) = vu2{pl[0], pl[1]};
+                // pair p = (2p, 2p + 1) completes at slot 3 (2p + 1) + 1
+                if (ph == 2 && (q & 1) && q < 16) {
+                    const int p_ = q >> 1;
+                    hi2[p_] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{tvv[q - 1], tvv[q]}, f16x2));
+                    vmax = fmaxf(vmax, fmaxf(tvv[q - 1], tvv[q])); // post-ReLU: non-negative
+                }
+                if (ph == 0 && q >= 2 && !(q & 1) && q <= 16) { // 3 (q-1) + 3
+                    const int p_ = (q - 2) >> 1;
+                    const f16x2 hv = __builtin_bit_cast(f16x2, hi2[p_]);
+                    f0[p_] = (float)hv[0];
+                    f1[p_] = (float)hv[1];
+                }
+                if (ph == 1 && q >= 2 && !(q & 1) && q <= 16) {
+                    const int p_ = (q - 2) >> 1;
+                    f0[p_] = tvv[2 * p_] - f0[p_];
+                    f1[p_] = tvv[2 * p_ + 1] - f1[p_];
+                }
+                if (ph == 2 && q >= 2 && !(q & 1) && q <= 16) {
+                    const int p_ = (q - 2) >> 1;
+                    lo2[p_] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{f0[p_], f1[p_]}, f16x2));
+                }
+                if (ph == 0 && q >= 5 && (q & 3) == 1 && q <= 17) { // group g4 = (q - 5) / 4 of four channels: pairs 2 g4, 2 g4 + 1 are split
+                    const int g4 = (q - 5) >> 2;
+                    *reinterpret_cast<vu2 *>(pdst + 16 * g4) = vu2{hi2[2 * g4], hi2[2 * g4 + 1]};
+                    *reinterpret_cast<vu2 *>(pdst + 16 * g4 + 64) = vu2{lo2[2 * g4], lo2[2 * g4 + 1]};
                 }
             };
             auto epilogue_now = [&]() { // the same, not hidden (a layer's last tile; a wave that has run out of tiles)
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    epi_value(q);
-                    if (q & 1) epi_pair(q);
-                    if ((q & 3) == 3) epi_store(q);
-                }
+                for (int g = 0; g < 54; ++g) epi_slot(g);
             };
             bool valid = false;
             int off = 0, yy = 0, xx = 0;
@@ -320,13 +395,18 @@ __global__ __launch_bounds__(512, 2) void k_conv32_chain(ChainArgs a)
                     bool valid2;
                     int off2, yy2, xx2;
                     locate(tl + 4 < ntiles ? tl + 4 : tl, valid2, off2, yy2, xx2); // no next tile: re-read this one
-                    f32x16 acc;
+                    f32x16 acc, acc2;
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4) { // accumulator seed = bias of rows 8 g4 + 4 h + (0..3)
                         const vf4 b4 = *reinterpret_cast<const vf4 *>(lbias + 8 * g4 + 4 * h);
                         acc[4 * g4] = b4[0]; acc[4 * g4 + 1] = b4[1]; acc[4 * g4 + 2] = b4[2]; acc[4 * g4 + 3] = b4[3];
                     }
+                    // TWO accumulators taken in turn (their sum is the tile): one chain of 54 dependent matrix instructions ran at ~44
+                    // cycles per instruction, two interleaved chains issue at the pipe's 32-36
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) acc2[q] = 0.0f;
 #define CH_MM(A_, B_) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_, __builtin_bit_cast(f16x8, B_), acc, 0, 0, 0)
+#define CH_MM2(A_, B_) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_, __builtin_bit_cast(f16x8, B_), acc2, 0, 0, 0)
 #pragma unroll
                     for (int i = 0; i < 18; ++i) {
                         Ops &cur = o[i % 3];
@@ -334,23 +414,24 @@ __global__ __launch_bounds__(512, 2) void k_conv32_chain(ChainArgs a)
                         const int noff = i < 16 ? off : off2, ni = i < 16 ? i + 2 : i - 16; // the operand two groups on (across the tile boundary)
                         // smallest products first: wl xh, wh xl (cross), wh xh (main); between them one LDS read and a slice of the
                         // previous tile's epilogue
-                        CH_MM(wl[i], cur.xh);
+                        if (i & 1) CH_MM2(wl[i], cur.xh); else CH_MM(wl[i], cur.xh);
                         __builtin_amdgcn_sched_barrier(0);
                         rd1(noff, ni, nn, 0);
-                        if (i < 16) epi_value(i);
+                        epi_slot(3 * i);
                         __builtin_amdgcn_sched_barrier(0);
-                        CH_MM(wh[i], cur.xl);
+                        if (i & 1) CH_MM(wh[i], cur.xl); else CH_MM2(wh[i], cur.xl);
                         __builtin_amdgcn_sched_barrier(0);
                         rd1(noff, ni, nn, 1);
-                        if (i < 16 && (i & 1)) epi_pair(i);
+                        epi_slot(3 * i + 1);
                         __builtin_amdgcn_sched_barrier(0);
-                        CH_MM(wh[i], cur.xh);
+                        if (i & 1) CH_MM2(wh[i], cur.xh); else CH_MM(wh[i], cur.xh);
                         __builtin_amdgcn_sched_barrier(0);
-                        if (i < 16 && (i & 3) == 3) epi_store(i);
+                        epi_slot(3 * i + 2);
                         __builtin_amdgcn_sched_barrier(0);
                     }
 #undef CH_MM
-                    prev = acc;
+#undef CH_MM2
+                    prev = acc + acc2;
                     pdst = valid ? img + (yy * Wi + xx) * X2_SLOT + 8 * h : dump_slot;
                     pboff = valid ? (unsigned)((it.b * 32 * Hf + (it.y0 + yy)) * Wf + xx + 4 * h * chw) * 4u : kNoStore;
                     pending = true;
@@ -359,7 +440,10 @@ __global__ __launch_bounds__(512, 2) void k_conv32_chain(ChainArgs a)
                     epilogue_now();
                     pending = false;
                 }
-                if (FINAL) load_weights(wf_next);
+                if (FINAL) {
+                    load_weights(wf_next);
+                    load_consts(wf_next, b_next);
+                }
 #ifdef AUGCL_TUNING
                 { const unsigned long long t = __builtin_amdgcn_s_memtime(); c_mma += t - t_mark; t_mark = t; }
 #endif

@@ -70,8 +70,15 @@ __global__ __launch_bounds__(512, 2) void k_conv_first9(First9Args a)
     const int rows_in_max = 2 * a.RT + 1;
     const int bufwords = (rows_in_max + 1) * ROWF; // + one slack row block (the K pad reads into it)
     float *lbias = ldsf + 2 * bufwords;
-    const int grp = a.dual ? (int)(blockIdx.x & 1) : 0, nhalf = a.n_items >> 1;
-    const int first = a.dual ? grp * nhalf + (int)(blockIdx.x >> 1) : xcd_slot((int)blockIdx.x, (int)gridDim.x);
+    // two weight sets: both halves read the SAME input image, so the two workgroups of an input sit on ONE XCD (workgroup i
+    // runs on XCD i % 8), next to each other in dispatch order -- i and i + 8 -- and the second read of the image hits in that
+    // XCD's L2 (with even / odd workgroups taking the halves, the two readers sat on different XCDs and the image crossed
+    // the fabric twice: PMC FETCH 1.17x the algorithmic bytes).  Grids that are not a multiple of 16 keep the even / odd map.
+    const bool pair_xcd = a.dual && (gridDim.x & 15) == 0;
+    const int grp = a.dual ? (pair_xcd ? (int)((blockIdx.x >> 3) & 1) : (int)(blockIdx.x & 1)) : 0, nhalf = a.n_items >> 1;
+    // (... and XCD x takes the contiguous slots [x G/16, (x + 1) G/16): neighbouring strips, which share a halo row, too)
+    const int worker = pair_xcd ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 4) + (int)(blockIdx.x >> 4) : (int)(blockIdx.x >> 1);
+    const int first = a.dual ? grp * nhalf + worker : xcd_slot((int)blockIdx.x, (int)gridDim.x);
     const int NG = a.dual ? (int)(gridDim.x >> 1) : (int)gridDim.x;
     const int n = a.dual ? (grp + 1) * nhalf : a.n_items;
 

@@ -83,8 +83,14 @@ __global__ __launch_bounds__(512, 2) void k_conv32_x2(ConvX2Args a)
     const int bufbytes = tilepix * X2_SLOT + (MODE ? 0 : (a.RT + 2) * X2_ROWPAD);
     float *lbias = reinterpret_cast<float *>(ldsx);        // [0..32) +bias s_in s_w, [32..64) the same negated
     char *tiles = ldsx + X2_HDR;
-    const int grp = a.dual ? (int)(blockIdx.x & 1) : 0, nhalf = a.n_items >> 1;
-    const int first = a.dual ? grp * nhalf + (int)(blockIdx.x >> 1) : xcd_slot((int)blockIdx.x, (int)gridDim.x);
+    // two weight sets: the halves' items are dealt so that NEIGHBOURING strips of an image run on one XCD here too (workgroup i
+    // sits on XCD i % 8; with even / odd workgroups taking the halves and slot = i / 2, consecutive strips landed on different
+    // XCDs and their two shared halo rows were fetched twice: PMC FETCH 1.157x the algorithmic bytes where the one-set launch,
+    // which uses xcd_slot, reads 1.000x).  Grids that are not a multiple of 16 keep the even / odd map.
+    const bool dual16 = a.dual && (gridDim.x & 15) == 0;
+    const int grp = a.dual ? (dual16 ? (int)((blockIdx.x >> 3) & 1) : (int)(blockIdx.x & 1)) : 0, nhalf = a.n_items >> 1;
+    const int dslot = dual16 ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 4) + (int)(blockIdx.x >> 4) : (int)(blockIdx.x >> 1);
+    const int first = a.dual ? grp * nhalf + dslot : xcd_slot((int)blockIdx.x, (int)gridDim.x);
     const int NG = a.dual ? (int)(gridDim.x >> 1) : (int)gridDim.x;
     const int n = a.dual ? (grp + 1) * nhalf : a.n_items;
     const vu4 *const wfrag = grp ? a.wfrag2 : a.wfrag;

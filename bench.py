@@ -439,9 +439,9 @@ def main():
         # update() replayed from captured hipGraphs (SAC.enable_hip_graphs); the eager figure beside it.
         # With several ranks the graphs contain the gradient all-reduce: checked by a pre-flight first.
         use_graph = dist is None or (args.dp_graph and not args.rehearse_one_gpu and graph_collectives_ok(dist, dev, torch))
-        busy = load_profile_json("r03_mfma_busy.json")
-        hbm16 = load_profile_json("r03_bf16_conv_hbm.json")
-        hbm32 = load_profile_json("r03_f32_conv_hbm.json")
+        busy = load_profile_json("r04_mfma_busy.json")
+        hbm16 = load_profile_json("r04_bf16_conv_hbm.json")
+        hbm32 = load_profile_json("r04_f32_conv_hbm.json")
 
         def leg(precision):
             """Both execution modes of update(); the faster one is the reported figure, the other sits beside it
@@ -466,7 +466,7 @@ def main():
                 if hb and hb / HBM_PEAK_GBS > mf["frac"]:
                     best["roofline"] = {"bound": "hbm (conv kernels of the f32 path: f32 NCHW activations in and out)", "achieved": hb,
                                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hb / HBM_PEAK_GBS,
-                                        "source": "profiles/r03_f32_conv_hbm.json (algorithmic bytes of every conv launch / its rocprofv3 "
+                                        "source": "profiles/r04_f32_conv_hbm.json (algorithmic bytes of every conv launch / its rocprofv3 "
                                                   "duration, time-weighted)", "mfma_f16": mf}
                 else:
                     best["roofline"] = {"bound": "mfma_f16 (f32-accurate products: 3 f16 MFMAs per product group)", **mf}
@@ -478,11 +478,11 @@ def main():
                 best["roofline"] = {"bound": "hbm (conv kernels; heads and optimiser stay f32)", "achieved": h.get("conv_GBps_time_weighted"),
                                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                     "frac": (h.get("conv_GBps_time_weighted") / HBM_PEAK_GBS) if h.get("conv_GBps_time_weighted") else None,
-                                    "source": "profiles/r03_bf16_conv_hbm.json (algorithmic bytes of every conv launch / its rocprofv3 "
+                                    "source": "profiles/r04_bf16_conv_hbm.json (algorithmic bytes of every conv launch / its rocprofv3 "
                                               "duration, time-weighted)" if h else None}
             b_ = busy.get(precision) if not busy.get("stale_profile") else None
             best["roofline"]["mfma_busy"] = b_
-            best["roofline"]["mfma_busy_source"] = ("profiles/r03_mfma_busy.json (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES per conv "
+            best["roofline"]["mfma_busy_source"] = ("profiles/r04_mfma_busy.json (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES per conv "
                                                     "kernel / launch duration x 2.4 GHz x 1024 SIMDs, time-weighted)") if b_ else None
             if busy.get("stale_profile") or hbm16.get("stale_profile") or hbm32.get("stale_profile"):
                 best["roofline"]["stale_profile"] = True

@@ -243,6 +243,47 @@ def test_encoder_against_f64_referee(cuda, monkeypatch, B, init, precision):
     assert rep["bwd_free"]["hip_pooled"] <= 1e-2, rep["bwd_free"]
 
 
+def test_stack_with_one_outlier_sample_against_f64_referee(cuda, monkeypatch):
+    """One image of the batch 2^20 brighter than its companions (its activations set every per-tensor scale of the f16-pair
+    kernels, the others sit 2^20 below the tensors' maxima) and its incoming gradient 2^-20 of theirs (so that every sample
+    still carries a comparable share of dW): the whole stack, forward per sample on each sample's own scale -- the
+    gradient-carrying per-layer kernels and the no-grad layer chains -- and dW / db with the gates of the HIP run forced, against
+    the float64 referee.  (Single layers on degenerate inputs: test_encoder_gpu.py; the numerical method's range limits:
+    test_f16_pair_numerics.py.)"""
+    monkeypatch.setattr(encoder_ops, "PRECISION", "f32")
+    B, k = 8, 3
+    _, cs = make_states("he", 6, 11)
+    ids = so.conv_layer_ids(11)
+    ws = [cs[f"encoder.shared_cnn.layers.{i}.weight"] for i in ids]
+    bs = [torch.zeros_like(cs[f"encoder.shared_cnn.layers.{i}.bias"]) for i in ids]  # no bias: a sample's activations scale with its image
+    rs = np.random.RandomState(77)
+    x = torch.from_numpy(rs.randint(0, 256, (B, 9, 84, 84)).astype(np.float32))
+    gout = torch.from_numpy(rs.standard_normal((B, 32, 21, 21)).astype(np.float32))
+    x[k] *= 2.0 ** 20
+    gout[k] *= 2.0 ** -20
+    rdev = ref_device(cuda)
+    out64, pre64, _, _ = ref_run(x, ws, bs, gout, torch.float64, device=rdev)
+    xd, gd = x.to(cuda), gout.to(cuda)
+    wg = [w.to(cuda).clone().requires_grad_(True) for w in ws]
+    bg = [b.to(cuda).clone().requires_grad_(True) for b in bs]
+    out = encoder_ops.conv_stack(xd, wg, bg, first_stride=2, input_scale=255.0)
+    (out * gd).sum().backward()
+    with torch.no_grad():
+        chain = encoder_ops.conv_stack(xd, [w.detach() for w in wg], [b.detach() for b in bg], first_stride=2, input_scale=255.0)
+    torch.cuda.synchronize()
+    rep = {"per_sample_fwd": [rel_l2(out[i].detach(), out64[i]) for i in range(B)],
+           "per_sample_fwd_chains": [rel_l2(chain[i], out64[i]) for i in range(B)]}
+    assert max(rep["per_sample_fwd"]) <= STRICT and max(rep["per_sample_fwd_chains"]) <= STRICT, rep
+    # the gates of the HIP run (its stored post-ReLU maps are not returned by the autograd node: recompute them through the C ABI)
+    acts = hip_forward(xd, [w.detach() for w in wg], [b.detach() for b in bg])
+    gates_hip = [(a > 0).cpu() for a in acts[:-1]]
+    _, _, dw64g, db64g = ref_run(x, ws, bs, gout, torch.float64, gates=gates_hip, device=rdev)
+    rep["dW"] = [rel_l2(a.grad, b) for a, b in zip(wg, dw64g)]
+    rep["db"] = [rel_l2(a.grad, b) for a, b in zip(bg, db64g)]
+    dump("encoder_outlier_sample_B8_he_f32", rep)
+    assert max(rep["dW"] + rep["db"]) <= STRICT, rep
+
+
 def test_bf16_encoder_against_f64_referee(cuda):
     """The bf16 PERFORMANCE mode of the conv stack (BASELINE config 2's bf16 leg; not the parity path) at the config's batch
     size, He-scaled weights, against the float64 referee: every layer's stored activation (bf16 NHWC) and, with the gates of

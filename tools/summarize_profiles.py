@@ -127,24 +127,31 @@ if "f32" in busy or "bf16" in busy:
 HS = [41 - 2 * i for i in range(11)]  # output size of layer i (input of layer i + 1)
 
 
-def conv_mix(elem, gate_bits=False):
+def conv_mix(elem, gate_bits=False, chains=False):
     """{kernel-name fragment: (launches per update, algorithmic bytes per update)} for activations of `elem` bytes;
-    gate_bits: backward-data reads one 32-bit word per pixel (the forward pass's gate bits) instead of the layer input"""
+    gate_bits: backward-data reads one 32-bit word per pixel (the forward pass's gate bits) instead of the layer input;
+    chains (round 4, f32 path): the no-grad passes (dual forward over 2 x 256 images, the actor step's pass over 256 every second
+    update) run as two chain launches each (layers 1-4: 41 -> 33, layers 5-10: 33 -> 21; csrc/encoder_chain.hip) whose
+    algorithmic bytes are the chain's input and output only"""
     px = lambda n: 32 * n * n  # noqa: E731
     fwd = bwd = wg = 0.0
+    nograd = 0.0 if chains else (512 + 0.5 * 256)
     for i in range(1, 11):
         hi, ho = HS[i - 1], HS[i]
         o_el = 4 if (i == 10) else elem  # the last layer always writes f32
-        fwd += (512 + 512 + 0.5 * 256) * (px(hi) * elem + px(ho) * o_el)
+        fwd += (512 + nograd) * (px(hi) * elem + px(ho) * o_el)
         gate = hi * hi * 4 if gate_bits else px(hi) * elem
         bwd += 512 * (px(ho) * elem + gate + px(hi) * elem)    # dZ in, gate in, dX out
         wg += 512 * (px(hi) * elem + px(ho) * elem)
     first = (256 + 512 + 0.5 * 256) * (9 * 84 * 84 * 4) + (512 + 512 + 0.5 * 256) * px(41) * elem  # dual launch reads x once
     wfirst = 512 * (9 * 84 * 84 * 4 + px(41) * elem)
-    return {"fwd": (25, fwd), "bwd": (10, bwd), "wgrad": (10, wg), "first": (2.5, first), "wfirst": (1, wfirst)}
+    mix = {"fwd": (10 if chains else 25, fwd), "bwd": (10, bwd), "wgrad": (10, wg), "first": (2.5, first), "wfirst": (1, wfirst)}
+    if chains:
+        mix["chain"] = (3, (512 + 0.5 * 256) * 4 * (px(41) + 2 * px(33) + px(21)))
+    return mix
 
 
-KERNEL_ROLE = [("k_conv32_x2<0", "fwd"), ("k_conv32_x2<1", "bwd"), ("k_wgrad32_x2", "wgrad"), ("k_conv32_x3<0", "fwd"), ("k_conv32_x3<1", "bwd"), ("k_wgrad32_x3", "wgrad"), ("k_conv32_bf16<0", "fwd"),
+KERNEL_ROLE = [("k_conv32_chain", "chain"), ("k_conv32_x2<0", "fwd"), ("k_conv32_x2<1", "bwd"), ("k_wgrad32_x2", "wgrad"), ("k_conv32_x3<0", "fwd"), ("k_conv32_x3<1", "bwd"), ("k_wgrad32_x3", "wgrad"), ("k_conv32_bf16<0", "fwd"),
                ("k_conv32_bf16<1", "bwd"), ("k_wgrad32_bf16", "wgrad"), ("k_conv_first9", "first"), ("k_wgrad_first", "wfirst"),
                ("k_conv32<0", "fwd"), ("k_conv32<1", "bwd"), ("k_wgrad32<", "wgrad")]
 
@@ -173,8 +180,8 @@ upd = {"round": tag, "source_hash": SRC_HASH, "note": "conv encoder kernels insi
 for prec, elem in (("f32", 4), ("bf16", 2)):
     if not os.path.exists(G(f"update_{prec}.csv")):
         continue
-    mix = conv_mix(elem, gate_bits=(prec == "f32"))
     times = kernel_times(G(f"update_{prec}.csv"))
+    mix = conv_mix(elem, gate_bits=(prec == "f32"), chains=any("k_conv32_chain" in n for n in times))
     fetch = json.load(open(G(f"ufetch_{prec}.json"))) if os.path.exists(G(f"ufetch_{prec}.json")) else {}
     write = json.load(open(G(f"uwrite_{prec}.json"))) if os.path.exists(G(f"uwrite_{prec}.json")) else {}
 
