@@ -66,3 +66,33 @@ def test_ops_fail_loudly_without_gpu_tensor():
         aug.random_shift(x)
     with pytest.raises(_lib.AugclError):
         aug.random_conv(x)
+
+
+def test_chain_planner_and_infer_argument_checks():
+    """Host side of augcl_enc_stack_infer (csrc/encoder_chain.hip, encoder_stack.cpp): what a chain launch fits (160 KiB of LDS,
+    1280 staged pixels), tile rounds of the longest item, scratch size, argument checks -- no launch, no GPU."""
+    lib = _lib.load()
+    rounds = lib.augcl_internal_chain_rounds
+    # the training stack's two chains: layers 1-4 on half images (25 input rows of 41 pixels), layers 5-10 on whole 33 x 33 images
+    assert rounds(41, 41, 4, 2) == 8 + 7 + 6 + 5 and rounds(33, 33, 6, 1) == 8 + 7 + 6 + 5 + 5 + 4
+    assert rounds(41, 41, 4, 1) == -1 and rounds(41, 41, 1, 1) == -1   # a whole 41 x 41 image does not fit LDS
+    assert rounds(33, 33, 7, 1) == -1 and rounds(33, 33, 0, 1) == -1   # at most six layers, at least one
+    assert rounds(13, 13, 6, 1) == 1 + 1 + 1 + 1 + 1 + 1               # 1 x 1 output: one tile per layer
+    assert rounds(13, 13, 6, 2) == -1                                   # more parts than output rows
+    assert rounds(21, 21, 2, 9) == 2 and rounds(21, 21, 2, 12) == -1    # 17 rows in parts of 2: nine parts hold them, twelve leave empty ones
+    assert rounds(9, 400, 1, 7) == -1                                   # 3 input rows of 400 pixels: more than 1280 staged pixels
+    # more parts = shorter items (what the planner trades against halo recomputation for small batches)
+    assert rounds(41, 41, 4, 33) < rounds(41, 41, 4, 11) < rounds(41, 41, 4, 3) < rounds(41, 41, 4, 2)
+    sz = lib.augcl_enc_stack_infer_scratch_bytes
+    assert sz(11, 512, 9, 84, 84, 2) == 2 * 512 * 32 * 41 * 41 * 4 and sz(11, 0, 9, 84, 84, 2) == 0
+    assert sz(11, 3, 9, 84, 84, 2) % 512 == 0                           # two 256-byte aligned buffers
+    p = ctypes.c_void_p
+    one = (p * 11)(*([1 << 20] * 11))
+    assert lib.augcl_enc_stack_infer(None, one, one, None, None, 16, 16, 0, 11, 4, 9, 84, 84, 2, 255.0, 16, 0, 16, None) == -1
+    assert lib.augcl_enc_stack_infer(16, one, one, one, None, 16, 16, 0, 11, 4, 9, 84, 84, 2, 255.0, 16, 0, 16, None) == -1
+    assert b"weight set B" in lib.augcl_last_error()
+    assert lib.augcl_enc_stack_infer(16, one, one, None, None, 16, 16, 0, 11, 4, 9, 20, 20, 2, 255.0, 16, 0, 16, None) == -1
+    assert b"too small" in lib.augcl_last_error()
+    # frag_ws too small for ten 32 -> 32 layers: refused before anything is launched
+    assert lib.augcl_enc_stack_infer(16, one, one, None, None, 16, 16, 1 << 30, 11, 4, 9, 84, 84, 2, 255.0, 16, 64, 16, None) == -1
+    assert b"frag_ws" in lib.augcl_last_error()

@@ -1,12 +1,12 @@
 #!/bin/bash
-# The rocprofv3 passes behind profiles/ -- run ON the GPU box from the repo root:  bash tools/profile_round.sh r3
-# then, back in the container:  python tools/summarize_profiles.py r3   (copies / condenses gpurun_out/r3_* into profiles/).
+# The rocprofv3 passes behind profiles/ -- run ON the GPU box from the repo root:  bash tools/profile_round.sh r4
+# then, back in the container:  python tools/summarize_profiles.py r4   (copies / condenses gpurun_out/r3_* into profiles/).
 # One counter group per pass (MI355X_MICROARCH.md); --pmc is never combined with the hip / sys traces; every raw
 # trace directory is condensed on the box (tools/prof_summary.py, tools/pmc_summary.py) and deleted.
 # The hash of the source tree the binary was built from goes next to the results: bench.py only quotes counters whose
 # hash matches the tree it runs on.
 set -e
-R=${1:-r3}
+R=${1:-r4}
 ROOT=$(pwd)
 cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
 O=gpurun_out
