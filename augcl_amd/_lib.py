@@ -128,7 +128,7 @@ _SIGS = {
     "augcl_enc_stack_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P, _SZ, _I, _I, _I, _I, _I, _I, _F, _I, _I, _P, _SZ, _P, _P, _P, _P],
     "augcl_enc_stack_forward_dual": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P, _SZ, _P, _P],
     "augcl_enc_stack_infer_scratch_bytes": [_I, _I, _I, _I, _I, _I],
-    "augcl_enc_stack_infer": [_P, _P, _P, _P, _P, _P, _P, _SZ, _I, _I, _I, _I, _I, _I, _F, _P, _SZ, _P, _P],
+    "augcl_enc_stack_infer": [_P, _P, _P, _P, _P, _P, _P, _SZ, _I, _I, _I, _I, _I, _I, _F, _I, _P, _SZ, _P, _P],
     "augcl_replay_gather": [_P, _P, _P, _I, _I, _I, _I, _P],
     "augcl_enc_conv_first_forward": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
     "augcl_enc_conv32_forward": [_P, _P, _P, _P, _I, _I, _I, _I, _P],

@@ -496,6 +496,270 @@ __global__ __launch_bounds__(512, 2) void k_conv32_chain(ChainArgs a)
     }
 }
 
+
+// =========================================================================================================================
+// The same chain for the bf16 PERFORMANCE MODE (BASELINE config 2 "bf16"; csrc/encoder_bf16.hip): activations bf16 (f32's
+// exponent range: no scales, no maxima), one v_mfma_f32_32x32x16_bf16 per (tap, channel half) = 18 per tile, f32 accumulation,
+// every layer's output rounded to bf16 (RNE) exactly as the per-layer kernels store it.  A pixel slot is 64 + 16 bytes, so
+// a WHOLE 41 x 41 image (1681 slots = 131 KiB) is one work item: the encoder's ten 32 -> 32 layers run as ONE launch with no
+// halo, no recomputation, and nothing but the first layer's output and the last layer's written or read in HBM -- where
+// the per-layer bf16 kernels are HBM-paced (27 us of a launch for 6 us of matrix work).  The weights of a layer are 72
+// registers: the NEXT layer's are requested when a layer starts and are there when it ends.
+constexpr int CB_MAXL = 12;   // layers per launch
+constexpr int CB_NU = 28;     // loader rounds per item: 256 lanes x CB_NU chunks of 16 B = 1792 pixels
+constexpr int CB_SLOT = 80;   // LDS bytes per pixel: 32 bf16 + 16 B pad (20 p mod 64 dwords: conflict-free ds_read_b128 over 16 pixels)
+constexpr int CB_HDR = 1024;  // 4 x 128 B bias seeds (one copy per compute wave), 4 dump slots
+constexpr int CB_FRAG_BYTES = 18 * 64 * 16; // prepared bf16 fragments of one layer
+
+typedef __bf16 bf16x8c __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2c __attribute__((ext_vector_type(2)));
+typedef short s16x2c __attribute__((ext_vector_type(2)));
+
+struct ChainBfArgs {
+    const vu4 *in;                 // bf16 NHWC (B,Hi,Wi,32) as 16-byte chunks (4 per pixel)
+    void *out;                     // f32 NCHW (B,32,Hf,Wf) when out_f32, else bf16 NHWC (B,Hf,Wf,32)
+    const float *bias[2][CB_MAXL]; // [weight set][layer] (32) or null
+    const vu4 *wfrag[2][CB_MAXL];  // k_bf16_prep: [18 operands][64 lanes] x 16 B
+    int nl, B, Hi, Wi, parts, rows_out, relu_last, dual, n_items, out_f32;
+    uint32_t magic_w[CB_MAXL];     // floor(2^32 / width of layer j's output) + 1
+    uint32_t magic_parts;
+};
+
+__device__ __forceinline__ ChainItem chain_bf_item(const ChainBfArgs &a, int item)
+{
+    ChainItem it;
+    it.b = a.parts == 1 ? item : (int)__umulhi((uint32_t)item, a.magic_parts);
+    const int p = item - it.b * a.parts;
+    it.y0 = p * a.rows_out;
+    it.ny = min(a.rows_out, a.Hi - 2 * a.nl - it.y0);
+    it.grp = (a.dual && it.b >= (a.B >> 1)) ? 1 : 0;
+    return it;
+}
+
+// bf16 fragments of n 32 -> 32 layers: lane l of operand i = (tap t = i / 2, channel half s = i & 1) holds W[co = l & 31][ci = 16 s + 8 (l >> 5) + j][t]
+struct PrepBfArgs {
+    const float *w[32];
+    char *out;     // [n] blocks of `stride` bytes
+    int stride;
+};
+
+__global__ __launch_bounds__(256) void k_bf16_prep(PrepBfArgs a)
+{
+    const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
+    const int i = 4 * blockIdx.x + (threadIdx.x >> 6), t = i >> 1, s = i & 1;
+    if (i >= 18) return;
+    const float *w = a.w[blockIdx.y];
+    bf16x8c f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = (__bf16)w[l31 * 288 + (16 * s + 8 * h + j) * 9 + t];
+    reinterpret_cast<vu4 *>(a.out + (size_t)blockIdx.y * a.stride)[i * 64 + lane] = __builtin_bit_cast(vu4, f);
+}
+
+template <bool OUT_F32>
+__global__ __launch_bounds__(512, 2) void k_conv32_chain_bf16(ChainBfArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char ldsb[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = wave >= 4;
+    const int cw = wave & 3;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int Wi = a.Wi, nl = a.nl;
+    const int Hf = a.Hi - 2 * nl, Wf = Wi - 2 * nl;
+    char *img = ldsb + CB_HDR;
+    const int G = (int)gridDim.x, n = a.n_items, first = xcd_slot((int)blockIdx.x, G);
+    const int rowb = Wi * CB_SLOT;
+    auto rounds_of = [&](int j, int ny) {
+        const int npix = (ny + 2 * (nl - 1 - j)) * (Wi - 2 * (j + 1));
+        return (((npix + 31) >> 5) + 3) >> 2;
+    };
+
+    if (loader) {
+        // the NEXT item's input (its rows of every pixel's 64 bytes: one contiguous run) is fetched into registers while the compute
+        // waves work and dumped into the image between the item's last and the next item's first barrier
+        const int lt = cw * 64 + lane;
+        vu4 d[CB_NU];
+        int nchunk = 0;
+        auto issue = [&](int item) {
+            const ChainItem it = chain_bf_item(a, item);
+            nchunk = (it.ny + 2 * nl) * Wi * 4;
+            const vu4 *src = a.in + ((size_t)(it.b * a.Hi + it.y0) * Wi) * 4;
+#pragma unroll
+            for (int u = 0; u < CB_NU; ++u)
+                if (256 * u < nchunk) d[u] = src[min(u * 256 + lt, nchunk - 1)]; // (wave-uniform test; idempotent tail)
+        };
+        auto dump = [&]() {
+#pragma unroll
+            for (int u = 0; u < CB_NU; ++u)
+                if (256 * u < nchunk) {
+                    const int q = min(u * 256 + lt, nchunk - 1);
+                    *reinterpret_cast<vu4 *>(img + (q >> 2) * CB_SLOT + (q & 3) * 16) = d[u];
+                }
+        };
+        if (first < n) {
+            issue(first);
+            dump();
+        }
+        for (int item = first; item < n; item += G) {
+            __syncthreads(); // A: the image is ready
+            const int nxt = item + G;
+            if (nxt < n) issue(nxt);
+            const int ny = chain_bf_item(a, item).ny;
+            int nb = 0;
+            for (int j = 0; j + 1 < nl; ++j) nb += rounds_of(j, ny) + 1;
+            for (int i = 0; i < nb; ++i) __syncthreads();
+            __syncthreads(); // F: every read of the image is done
+            if (nxt < n) dump();
+        }
+        return;
+    }
+
+    // ---- compute waves
+    bf16x8c wc[18], wn[18]; // this layer's fragments / the next layer's (in flight while this one computes)
+    auto load_next = [&](const vu4 *wf) {
+#pragma unroll
+        for (int i = 0; i < 18; ++i) wn[i] = __builtin_bit_cast(bf16x8c, wf[i * 64 + lane]);
+    };
+    float nx_bv = 0.0f;
+    float *lbias = reinterpret_cast<float *>(ldsb) + 32 * cw;
+    char *dump_slot = ldsb + 512 + 96 * cw;
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
+        a.out, 0, (int)((unsigned)(a.B * 32 * Hf * Wf) * (OUT_F32 ? 4u : 2u)), 0x00020000);
+    constexpr unsigned kNoStore = 0xfffffff0u;
+    const int chw = Hf * Wf;
+    typedef uint32_t vu2 __attribute__((ext_vector_type(2)));
+    if (first < n) {
+        const int g0 = chain_bf_item(a, first).grp;
+        load_next(a.wfrag[g0][0]);
+        nx_bv = (a.bias[g0][0] && lane < 32) ? a.bias[g0][0][lane] : 0.0f;
+    }
+
+    for (int item = first; item < n; item += G) {
+        const ChainItem it = chain_bf_item(a, item);
+        __syncthreads(); // A
+        auto layer = [&](int j, auto last_tag) {
+            constexpr bool last = decltype(last_tag)::value;
+            const int Wout = Wi - 2 * (j + 1), nrow = it.ny + 2 * (nl - 1 - j);
+            const int npix = nrow * Wout, ntiles = (npix + 31) >> 5, rounds = (ntiles + 3) >> 2;
+            const uint32_t magic = a.magic_w[j];
+#pragma unroll
+            for (int i = 0; i < 18; ++i) wc[i] = wn[i];
+            if (lane < 32) lbias[lane] = nx_bv;
+            { // request the next layer's (the next item's first layer's) fragments and bias: a whole layer to arrive in
+                const int gn = !last ? it.grp : (item + G < n ? chain_bf_item(a, item + G).grp : it.grp);
+                const int jn = !last ? j + 1 : 0;
+                load_next(a.wfrag[gn][jn]);
+                nx_bv = (a.bias[gn][jn] && lane < 32) ? a.bias[gn][jn][lane] : 0.0f;
+            }
+            const bool relu = !last || a.relu_last;
+            const int relu_floor = __builtin_amdgcn_readfirstlane(relu ? 0 : (int)0x80000000);
+            const short relu16 = (short)__builtin_amdgcn_readfirstlane(relu ? 0 : -32768);
+
+            auto locate = [&](int tl, bool &valid_, int &off_, int &yy_, int &xx_) {
+                int m_ = tl * 32 + l31;
+                valid_ = m_ < npix;
+                if (!valid_) m_ = npix - 1;
+                yy_ = (int)__umulhi((uint32_t)m_, magic);
+                xx_ = m_ - yy_ * Wout;
+                off_ = (yy_ * Wi + xx_) * CB_SLOT + h * 16;
+            };
+            auto rd = [&](int off_, int i) { // operand i = (tap i / 2, channel half i & 1): row base + immediate
+                const int t = i >> 1;
+                return *reinterpret_cast<const vu4 *>(img + off_ + (t / 3) * rowb + ((t % 3) * CB_SLOT + (i & 1) * 32));
+            };
+            f32x16 prev;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) prev[q] = 0.0f;
+            char *pdst = dump_slot;
+            unsigned pboff = kNoStore;
+            bool pending = false;
+            uint32_t pk[8];
+            // the previous tile's epilogue, one slice per matrix-instruction gap (18 of them): pair p = channels (2p, 2p + 1) of
+            // the lane's 16 is converted in gap 2p (f32 pair -> packed bf16, RNE), gets its ReLU in gap 2p + 1 (packed signed
+            // 16-bit maximum with 0) and is stored with its neighbour pair (8 bytes) two gaps later
+            auto epi_slot = [&](int g) {
+                if (last && OUT_F32) {
+                    if (g < 16) {
+                        const float t = __int_as_float(max(__float_as_int(prev[g]), relu_floor));
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t), rs_out, pboff,
+                                                              (unsigned)(((g & 3) + 8 * (g >> 2)) * chw) * 4u, 0);
+                    }
+                    return;
+                }
+                if (g < 16 && !(g & 1)) {
+                    typedef float f32x2c __attribute__((ext_vector_type(2)));
+                    pk[g >> 1] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2c{prev[g], prev[g + 1]}, bf16x2c));
+                }
+                if (g < 16 && (g & 1))
+                    pk[g >> 1] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2c, pk[g >> 1]), s16x2c{relu16, relu16}));
+                if (g >= 5 && (g & 3) == 1 && g <= 17) { // channels 8 g4 + 4 h + (0..3): pairs 2 g4, 2 g4 + 1
+                    const int g4 = (g - 5) >> 2;
+                    if (last) // bf16 NHWC out: 8 bytes at pixel * 64 + 16 g4 + 8 h
+                        __builtin_amdgcn_raw_buffer_store_b64(vu2{pk[2 * g4], pk[2 * g4 + 1]}, rs_out, pboff, (unsigned)(16 * g4), 0);
+                    else
+                        *reinterpret_cast<vu2 *>(pdst + 16 * g4) = vu2{pk[2 * g4], pk[2 * g4 + 1]};
+                }
+            };
+            auto epilogue_now = [&]() {
+#pragma unroll
+                for (int g = 0; g < 18; ++g) epi_slot(g);
+            };
+            bool valid = false;
+            int off = 0, yy = 0, xx = 0;
+            constexpr int AH = 6; // operand reads run six matrix instructions ahead of their use, across tile boundaries
+            vu4 raw[AH];
+            if (cw < ntiles) {
+                locate(cw, valid, off, yy, xx);
+#pragma unroll
+                for (int i = 0; i < AH; ++i) raw[i] = rd(off, i);
+            }
+            for (int r = 0; r < rounds; ++r) {
+                const int tl = 4 * r + cw;
+                if (tl < ntiles) { // wave-uniform
+                    bool valid2;
+                    int off2, yy2, xx2;
+                    locate(tl + 4 < ntiles ? tl + 4 : tl, valid2, off2, yy2, xx2); // no next tile: re-read this one
+                    f32x16 acc;
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const vf4 b4 = *reinterpret_cast<const vf4 *>(lbias + 8 * g4 + 4 * h);
+                        acc[4 * g4] = b4[0]; acc[4 * g4 + 1] = b4[1]; acc[4 * g4 + 2] = b4[2]; acc[4 * g4 + 3] = b4[3];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 18; ++i) {
+                        const vu4 cur = raw[i % AH];
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[i], __builtin_bit_cast(bf16x8c, cur), acc, 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        raw[i % AH] = i + AH < 18 ? rd(off, i + AH) : rd(off2, i + AH - 18);
+                        epi_slot(i);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    prev = acc;
+                    if (last) {
+                        pdst = dump_slot;
+                        pboff = !valid ? kNoStore
+                                : OUT_F32 ? (unsigned)((it.b * 32 * Hf + (it.y0 + yy)) * Wf + xx + 4 * h * chw) * 4u
+                                          : (unsigned)(((it.b * Hf + it.y0 + yy) * Wf + xx) * 64 + 8 * h);
+                    } else {
+                        pdst = valid ? img + (yy * Wi + xx) * CB_SLOT + 8 * h : dump_slot;
+                    }
+                    pending = true;
+                    valid = valid2; off = off2; yy = yy2; xx = xx2;
+                } else if (pending) { // out of tiles: finish the last one (its round's barrier is behind us)
+                    epilogue_now();
+                    pending = false;
+                }
+                if (!last) __syncthreads(); // R: the round's operand reads are done
+            }
+            if (pending) epilogue_now();
+            if (!last) __syncthreads(); // L: the layer's output is in place
+        };
+        for (int j = 0; j + 1 < nl; ++j) layer(j, std::false_type{});
+        layer(nl - 1, std::true_type{});
+        __syncthreads(); // F
+    }
+}
+
 } // namespace augcl
 
 using namespace augcl;
@@ -581,6 +845,85 @@ int augcl_internal_chain_forward(const float *in, float *out, const void *const 
     const int cus = cu_count_chain();
     const int grid = a.n_items < cus ? a.n_items : cus;
     hipLaunchKernelGGL(k_conv32_chain, dim3(grid), dim3(512), lds, as_stream(stream), a);
+    return augcl::check_launch(name);
+}
+
+// ---- bf16 performance mode (k_conv32_chain_bf16) ----
+int augcl_internal_chain_bf16_rounds(int Hi, int Wi, int nl, int parts)
+{
+    if (nl < 1 || nl > CB_MAXL || parts < 1) return -1;
+    const int Hf = Hi - 2 * nl, Wf = Wi - 2 * nl;
+    if (Hf < 1 || Wf < 1 || parts > Hf) return -1;
+    const int rows_out = (Hf + parts - 1) / parts;
+    if ((parts - 1) * rows_out >= Hf) return -1;
+    const long npx = (long)(rows_out + 2 * nl) * Wi;
+    if (npx > 64L * CB_NU || npx < 1 || CB_HDR + npx * CB_SLOT > kLdsBytes) return -1;
+    int rounds = 0;
+    for (int j = 0; j < nl; ++j) {
+        const int npix = (rows_out + 2 * (nl - 1 - j)) * (Wi - 2 * (j + 1));
+        rounds += (((npix + 31) >> 5) + 3) >> 2;
+    }
+    return rounds;
+}
+
+// bf16 fragments of n (<= 32) 32 -> 32 layers into out, `stride` bytes apart (>= 18 KiB each)
+int augcl_internal_bf16_prep_weights(const float *const *w, int n, void *out, int stride, augcl_stream_t stream)
+{
+    const char *name = "augcl_internal_bf16_prep_weights";
+    AUGCL_REQUIRE(w && out && n >= 1 && n <= 32 && stride >= CB_FRAG_BYTES && (stride & 15) == 0 && aligned16(out), "%s: bad argument", name);
+    PrepBfArgs a{};
+    for (int i = 0; i < n; ++i) {
+        AUGCL_REQUIRE(w[i] != nullptr, "%s: null weight tensor", name);
+        a.w[i] = w[i];
+    }
+    a.out = reinterpret_cast<char *>(out);
+    a.stride = stride;
+    hipLaunchKernelGGL(k_bf16_prep, dim3(5, n), dim3(256), 0, as_stream(stream), a);
+    return augcl::check_launch(name);
+}
+
+int augcl_internal_chain_bf16_forward(const void *in_bf16_nhwc, void *out, const void *const *wfragA, const float *const *biasA,
+                                      const void *const *wfragB, const float *const *biasB, int nl, int B, int Hi, int Wi, int parts,
+                                      int relu_last, int out_f32_nchw, augcl_stream_t stream)
+{
+    const char *name = "augcl_enc_stack_infer";
+    AUGCL_REQUIRE(in_bf16_nhwc && out && wfragA && biasA, "%s: null tensor", name);
+    if (B == 0) return AUGCL_OK;
+    if (augcl_internal_chain_bf16_rounds(Hi, Wi, nl, parts) < 0) return 1;
+    if ((size_t)B * 32 * Hi * Wi >= ((size_t)1 << 30) - 8) return 1;
+    AUGCL_REQUIRE(wfragB == nullptr || (B & 1) == 0, "%s: a two-weight-set batch must be even", name);
+    AUGCL_REQUIRE(aligned16(in_bf16_nhwc) && aligned4(out), "%s: misaligned tensor", name);
+    ChainBfArgs a{};
+    a.in = reinterpret_cast<const vu4 *>(in_bf16_nhwc);
+    a.out = out;
+    for (int j = 0; j < nl; ++j) {
+        a.wfrag[0][j] = reinterpret_cast<const vu4 *>(wfragA[j]);
+        a.bias[0][j] = biasA[j];
+        a.wfrag[1][j] = reinterpret_cast<const vu4 *>(wfragB ? wfragB[j] : wfragA[j]);
+        a.bias[1][j] = wfragB ? biasB[j] : biasA[j];
+        a.magic_w[j] = (uint32_t)(0x100000000ull / (unsigned)(Wi - 2 * (j + 1))) + 1u;
+    }
+    a.nl = nl; a.B = B; a.Hi = Hi; a.Wi = Wi; a.parts = parts;
+    const int Hf = Hi - 2 * nl;
+    a.rows_out = (Hf + parts - 1) / parts;
+    a.relu_last = relu_last;
+    a.out_f32 = out_f32_nchw;
+    a.dual = wfragB != nullptr;
+    a.n_items = B * parts;
+    a.magic_parts = (uint32_t)(0x100000000ull / (unsigned)parts) + 1u;
+    const size_t lds = (size_t)CB_HDR + (size_t)(a.rows_out + 2 * nl) * Wi * CB_SLOT;
+    const int cus = cu_count_chain();
+    const int grid = a.n_items < cus ? a.n_items : cus;
+    hipError_t e;
+    if (out_f32_nchw) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv32_chain_bf16<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return augcl::fail(AUGCL_E_LAUNCH, "%s: cannot set dynamic LDS %zu: %s", name, lds, hipGetErrorString(e));
+        hipLaunchKernelGGL(k_conv32_chain_bf16<true>, dim3(grid), dim3(512), lds, as_stream(stream), a);
+    } else {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv32_chain_bf16<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return augcl::fail(AUGCL_E_LAUNCH, "%s: cannot set dynamic LDS %zu: %s", name, lds, hipGetErrorString(e));
+        hipLaunchKernelGGL(k_conv32_chain_bf16<false>, dim3(grid), dim3(512), lds, as_stream(stream), a);
+    }
     return augcl::check_launch(name);
 }
 

@@ -273,6 +273,11 @@ int augcl_enc_stack_forward_dual(const float *x, const float *const *wA, const f
 // ---- no-grad forward with the 32 -> 32 layers in CHAINS (encoder_chain.hip): the first layer's kernel, one weight-fragment
 // launch per weight set, then one launch per chain of up to six layers whose intermediates stay in LDS.
 int augcl_internal_chain_rounds(int Hi, int Wi, int nl, int parts);
+int augcl_internal_chain_bf16_rounds(int Hi, int Wi, int nl, int parts);
+int augcl_internal_bf16_prep_weights(const float *const *w, int n, void *out, int stride, augcl_stream_t stream);
+int augcl_internal_chain_bf16_forward(const void *in_bf16_nhwc, void *out, const void *const *wfragA, const float *const *biasA,
+                                      const void *const *wfragB, const float *const *biasB, int nl, int B, int Hi, int Wi, int parts,
+                                      int relu_last, int out_f32_nchw, augcl_stream_t stream);
 int augcl_internal_chain_forward(const float *in, float *out, const void *const *wfragA, const float *const *biasA,
                                  const void *const *wfragB, const float *const *biasB, int nl, int B, int Hi, int Wi, int parts,
                                  int relu_last, const float *amax_in, float *amax_out, augcl_stream_t stream);
@@ -287,7 +292,7 @@ struct ChainPlan {
 // Fewest estimated microseconds over all ways to cut n32 layers (input h x w, `images` of them, `cus` workgroups at a time) into
 // chains: a launch costs ceil(items / cus) x (the longest item's tile rounds + ~2 for its staging) + ~8 for ramp and drain.
 // Small batches come out with many parts per image (more workgroups busy), large ones with the fewest that fit LDS.
-bool plan_chains(int h, int w, int n32, long images, int cus, ChainPlan &plan)
+bool plan_chains(int h, int w, int n32, long images, int cus, ChainPlan &plan, int (*rounds_fn)(int, int, int, int), int max_l)
 {
     if (n32 < 1 || n32 > 32) return false;
     double best[33];
@@ -297,10 +302,10 @@ bool plan_chains(int h, int w, int n32, long images, int cus, ChainPlan &plan)
         best[s] = 1e30;
         bl[s] = bp[s] = 0;
         const int hs = h - 2 * s, ws = w - 2 * s;
-        for (int L = 1; L <= 6 && s + L <= n32; ++L) {
+        for (int L = 1; L <= max_l && s + L <= n32; ++L) {
             const int hf = hs - 2 * L;
             for (int P = 1; P <= hf; ++P) {
-                const int r = augcl_internal_chain_rounds(hs, ws, L, P);
+                const int r = rounds_fn(hs, ws, L, P);
                 if (r < 0) continue;
                 const double cost = (double)((images * P + cus - 1) / cus) * (r + 2) + 8.0 + best[s + L];
                 if (cost < best[s]) { best[s] = cost; bl[s] = L; bp[s] = P; }
@@ -342,11 +347,61 @@ size_t augcl_enc_stack_infer_scratch_bytes(int n_layers, int B_total, int C, int
 // sets, the pipelined first-layer kernel) do not cover -- the caller runs augcl_enc_stack_forward[_dual].
 int augcl_enc_stack_infer(const float *x, const float *const *wA, const float *const *bA, const float *const *wB,
                           const float *const *bB, float *out, void *scratch, size_t scratch_bytes, int n_layers, int B, int C,
-                          int H, int W, int first_stride, float scale, void *frag_ws, size_t frag_ws_bytes, float *amax,
-                          augcl_stream_t stream)
+                          int H, int W, int first_stride, float scale, int precision, void *frag_ws, size_t frag_ws_bytes,
+                          float *amax, augcl_stream_t stream)
 {
     const char *name = "augcl_enc_stack_infer";
-    AUGCL_REQUIRE(x && wA && bA && out && amax && n_layers >= 1 && B >= 1, "%s: bad argument", name);
+    AUGCL_REQUIRE(x && wA && bA && out && n_layers >= 1 && B >= 1, "%s: bad argument", name);
+    AUGCL_REQUIRE(precision == 3 || precision == 1, "%s: precision must be 3 (f16 pairs) or 1 (bf16 mode)", name);
+    if (precision == 1) {
+        // ---- bf16 performance mode: first layer (bf16 NHWC out), one fragment launch per weight set, the 32 -> 32 layers as chains
+        AUGCL_REQUIRE((wB == nullptr) == (bB == nullptr), "%s: weight set B needs both arrays", name);
+        AUGCL_REQUIRE(n_layers >= 2 && n_layers <= 33, "%s: bf16 mode needs 2..33 layers", name);
+        const int sets = wB ? 2 : 1, Bt = sets * B;
+        const int h1 = out_hw(H, first_stride), w1 = out_hw(W, first_stride);
+        AUGCL_REQUIRE(h1 >= 1 && w1 >= 1 && h1 - 2 * (n_layers - 1) >= 1 && w1 - 2 * (n_layers - 1) >= 1, "%s: image too small", name);
+        ChainPlan plan;
+        if (!plan_chains(h1, w1, n_layers - 1, Bt, cu_count_stack(), plan, augcl_internal_chain_bf16_rounds, 12))
+            return augcl::fail(AUGCL_E_UNSUPPORTED, "%s: no chain plan for a %d x %d input", name, h1, w1);
+        const size_t block = augcl_enc_frag_workspace_bytes(1, 1), setB = (size_t)(n_layers - 1) * block;
+        AUGCL_REQUIRE(frag_ws != nullptr && frag_ws_bytes >= augcl_enc_frag_workspace_bytes(n_layers - 1, sets),
+                      "%s: frag_ws of augcl_enc_frag_workspace_bytes(n_layers - 1, %d) bytes needed", name, sets);
+        AUGCL_REQUIRE(scratch != nullptr && scratch_bytes >= augcl_enc_stack_infer_scratch_bytes(n_layers, Bt, C, H, W, first_stride),
+                      "%s: scratch smaller than augcl_enc_stack_infer_scratch_bytes", name);
+        const size_t half = augcl_enc_stack_infer_scratch_bytes(n_layers, Bt, C, H, W, first_stride) / 2;
+        void *buf[2] = {scratch, reinterpret_cast<char *>(scratch) + half};
+        int rc = augcl_internal_bf16_prep_weights(wA + 1, n_layers - 1, frag_ws, (int)block, stream);
+        if (rc == AUGCL_OK && wB) rc = augcl_internal_bf16_prep_weights(wB + 1, n_layers - 1, (char *)frag_ws + setB, (int)block, stream);
+        if (rc != AUGCL_OK) return rc;
+        rc = augcl::conv_first9_try(x, wA[0], bA[0], buf[0], Bt, C, H, W, first_stride, scale, 1, true, (hipStream_t)stream, name,
+                                    wB ? wB[0] : nullptr, wB ? bB[0] : nullptr);
+        if (rc > 0) {
+            if (wB) return augcl::fail(AUGCL_E_UNSUPPORTED, "%s: first-layer shape (%d,%d,%d) stride %d not covered", name, C, H, W, first_stride);
+            rc = augcl_enc_bf16_conv_first_forward(x, wA[0], bA[0], buf[0], B, C, H, W, first_stride, scale, 1, stream);
+        }
+        if (rc != AUGCL_OK) return rc;
+        int layer = 1, h = h1, w = w1, cur = 0;
+        for (int c = 0; c < plan.n; ++c) {
+            const int nl = plan.nl[c];
+            const bool final_chain = c == plan.n - 1;
+            const void *fa[12], *fb[12];
+            for (int j = 0; j < nl; ++j) {
+                fa[j] = (char *)frag_ws + (size_t)(layer + j - 1) * block;
+                fb[j] = (char *)frag_ws + setB + (size_t)(layer + j - 1) * block;
+            }
+            rc = augcl_internal_chain_bf16_forward(buf[cur], final_chain ? (void *)out : buf[cur ^ 1], fa, bA + layer, wB ? fb : nullptr,
+                                                   wB ? bB + layer : nullptr, nl, Bt, h, w, plan.parts[c], final_chain ? 0 : 1,
+                                                   final_chain ? 1 : 0, stream);
+            if (rc > 0) return augcl::fail(AUGCL_E_UNSUPPORTED, "%s: chain of %d layers at %d x %d not covered", name, nl, h, w);
+            if (rc != AUGCL_OK) return rc;
+            layer += nl;
+            h -= 2 * nl;
+            w -= 2 * nl;
+            cur ^= 1;
+        }
+        return AUGCL_OK;
+    }
+    AUGCL_REQUIRE(amax != nullptr, "%s: precision 3 needs the amax scratch", name);
     AUGCL_REQUIRE((wB == nullptr) == (bB == nullptr), "%s: weight set B needs both arrays", name);
     const int sets = wB ? 2 : 1, Bt = sets * B;
     const int h1 = out_hw(H, first_stride), w1 = out_hw(W, first_stride);
@@ -355,7 +410,7 @@ int augcl_enc_stack_infer(const float *x, const float *const *wA, const float *c
     ChainPlan plan;
     if (n_layers >= 2) {
         AUGCL_REQUIRE(n_layers <= 33, "%s: at most 33 layers", name);
-        if (!plan_chains(h1, w1, n_layers - 1, Bt, cu_count_stack(), plan))
+        if (!plan_chains(h1, w1, n_layers - 1, Bt, cu_count_stack(), plan, augcl_internal_chain_rounds, 6))
             return augcl::fail(AUGCL_E_UNSUPPORTED, "%s: no chain plan for a %d x %d input", name, h1, w1);
         if ((rc = x2_require(name, n_layers, frag_ws, frag_ws_bytes, sets, amax)) != AUGCL_OK) return rc;
         AUGCL_REQUIRE(scratch != nullptr && scratch_bytes >= augcl_enc_stack_infer_scratch_bytes(n_layers, Bt, C, H, W, first_stride),

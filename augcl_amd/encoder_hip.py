@@ -172,13 +172,15 @@ def _infer_scratch(dev, n_layers, b_total, C, H, W, first_stride):
     return t, need
 
 
-def conv_stack_infer(x, weights_a, biases_a, weights_b, biases_b, first_stride, input_scale):
+def conv_stack_infer(x, weights_a, biases_a, weights_b, biases_b, first_stride, input_scale, precision="f32"):
     """No-grad forward of one conv stack (weights_b is None) or of two stacks with identical shapes over the SAME input,
     f16-pair arithmetic, 32 -> 32 layers as LDS-resident chains (augcl_enc_stack_infer).  Returns (B or 2B, 32, h, w) f32 --
     rows [0,B) from set A, [B,2B) from set B -- or None when the shape is not covered."""
     n_layers = len(weights_a)
     B, C, H, W = x.shape
     if not _CHAINS or not x.is_contiguous() or x.dtype != torch.float32 or 2 * (n_layers + 1) > 2 * _AMAX:
+        return None
+    if precision not in ("f32", "bf16") or (precision == "bf16" and n_layers < 2):
         return None
     dev = x.device
     sets = 1 if weights_b is None else 2
@@ -192,8 +194,8 @@ def conv_stack_infer(x, weights_a, biases_a, weights_b, biases_b, first_stride, 
     d = lambda ts: _ptr_array([t.detach().data_ptr() for t in ts])  # noqa: E731
     rc = _lib.load().augcl_enc_stack_infer(
         x.data_ptr(), d(weights_a), d(biases_a), d(weights_b) if sets == 2 else None, d(biases_b) if sets == 2 else None,
-        out.data_ptr(), ws.data_ptr(), need, n_layers, B, C, H, W, first_stride, input_scale, fws.data_ptr(), fws.numel(),
-        ws.data_ptr() + need, _lib.current_stream(dev))
+        out.data_ptr(), ws.data_ptr(), need, n_layers, B, C, H, W, first_stride, input_scale, PRECISION_CODE[precision],
+        fws.data_ptr(), fws.numel(), ws.data_ptr() + need, _lib.current_stream(dev))
     if rc == _lib.AUGCL_E_UNSUPPORTED:
         return None
     _lib.check(rc, "augcl_enc_stack_infer")
@@ -208,8 +210,8 @@ def conv_stack_dual(x, weights_a, biases_a, weights_b, biases_b, first_stride, i
     B, C, H, W = x.shape
     if n_layers < 2 or C != 9 or W != 84 or first_stride != 2 or not x.is_contiguous():
         return None
-    if precision == "f32":
-        out = conv_stack_infer(x, weights_a, biases_a, weights_b, biases_b, first_stride, input_scale)
+    if precision in ("f32", "bf16"):
+        out = conv_stack_infer(x, weights_a, biases_a, weights_b, biases_b, first_stride, input_scale, precision)
         if out is not None:
             return out
     dev = x.device
@@ -256,8 +258,8 @@ class ConvStackFn(torch.autograd.Function):
             wsz.append(wsz[-1] - 2)
         numel = [B * 32 * h * w_ for h, w_ in zip(hs, wsz)]
         need_grad = any(t.requires_grad for t in wb)
-        if not need_grad and precision == "f32":  # nothing is kept for a backward pass: the layers run as LDS-resident chains
-            out = conv_stack_infer(x, weights, biases, None, None, first_stride, input_scale)
+        if not need_grad and precision in ("f32", "bf16"):  # nothing is kept for a backward pass: the layers run as LDS-resident chains
+            out = conv_stack_infer(x, weights, biases, None, None, first_stride, input_scale, precision)
             if out is not None:
                 return out
         out = torch.empty((B, 32, hs[-1], wsz[-1]), dtype=torch.float32, device=dev)

@@ -410,15 +410,18 @@ int augcl_enc_stack_forward_dual(const float *x, const float *const *wA, const f
  * exact input maximum + the largest bias), so no tensor-wide maximum is needed inside a chain and nothing can overflow.  Same
  * accuracy class as augcl_enc_stack_forward(precision 3) -- float32-accurate products, ~1e-7 relative L2 per layer against
  * float64 -- but not bit-identical to it (other scales).  Nothing is kept for a backward pass.
+ * precision 3 = that; precision 1 = the bf16 performance mode as chains (bf16 activations need no scales: a whole 41 x 41 image
+ * is one work item and the ten 32 -> 32 layers of the training stack are ONE launch; every layer's output is rounded to bf16
+ * exactly as augcl_enc_stack_forward(precision 1) stores it).
  * scratch: augcl_enc_stack_infer_scratch_bytes(...) bytes, 256-byte aligned (B_total = B x weight sets); frag_ws as above with
- * the number of weight sets; amax: 2 x (n_layers + 1) floats of device scratch.
+ * the number of weight sets; amax (precision 3; may be NULL otherwise): 2 x (n_layers + 1) floats of device scratch.
  * AUGCL_E_UNSUPPORTED: a shape the chains (or, with two weight sets, the pipelined first-layer kernel) do not cover -- run
  * augcl_enc_stack_forward / augcl_enc_stack_forward_dual instead. */
 size_t augcl_enc_stack_infer_scratch_bytes(int n_layers, int B_total, int C, int H, int W, int first_stride);
 int augcl_enc_stack_infer(const float *x, const float *const *wA, const float *const *bA, const float *const *wB,
                           const float *const *bB, float *out, void *scratch, size_t scratch_bytes, int n_layers, int B, int C,
-                          int H, int W, int first_stride, float scale, void *frag_ws, size_t frag_ws_bytes, float *amax,
-                          augcl_stream_t stream);
+                          int H, int W, int first_stride, float scale, int precision, void *frag_ws, size_t frag_ws_bytes,
+                          float *amax, augcl_stream_t stream);
 
 /* ---- device-resident replay sampling: ReplayBuffer.sample -> tensor_buffer_samples / _encode_obses /
  * LazyFrames._force (src/utils.py:206-214, 234-240, 272-280, 293-299).  `frames` is a uint8 ring of RGB frames

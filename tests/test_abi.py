@@ -88,11 +88,18 @@ def test_chain_planner_and_infer_argument_checks():
     assert sz(11, 3, 9, 84, 84, 2) % 512 == 0                           # two 256-byte aligned buffers
     p = ctypes.c_void_p
     one = (p * 11)(*([1 << 20] * 11))
-    assert lib.augcl_enc_stack_infer(None, one, one, None, None, 16, 16, 0, 11, 4, 9, 84, 84, 2, 255.0, 16, 0, 16, None) == -1
-    assert lib.augcl_enc_stack_infer(16, one, one, one, None, 16, 16, 0, 11, 4, 9, 84, 84, 2, 255.0, 16, 0, 16, None) == -1
+    assert lib.augcl_enc_stack_infer(None, one, one, None, None, 16, 16, 0, 11, 4, 9, 84, 84, 2, 255.0, 3, 16, 0, 16, None) == -1
+    assert lib.augcl_enc_stack_infer(16, one, one, one, None, 16, 16, 0, 11, 4, 9, 84, 84, 2, 255.0, 3, 16, 0, 16, None) == -1
     assert b"weight set B" in lib.augcl_last_error()
-    assert lib.augcl_enc_stack_infer(16, one, one, None, None, 16, 16, 0, 11, 4, 9, 20, 20, 2, 255.0, 16, 0, 16, None) == -1
+    assert lib.augcl_enc_stack_infer(16, one, one, None, None, 16, 16, 0, 11, 4, 9, 20, 20, 2, 255.0, 3, 16, 0, 16, None) == -1
     assert b"too small" in lib.augcl_last_error()
     # frag_ws too small for ten 32 -> 32 layers: refused before anything is launched
-    assert lib.augcl_enc_stack_infer(16, one, one, None, None, 16, 16, 1 << 30, 11, 4, 9, 84, 84, 2, 255.0, 16, 64, 16, None) == -1
+    assert lib.augcl_enc_stack_infer(16, one, one, None, None, 16, 16, 1 << 30, 11, 4, 9, 84, 84, 2, 255.0, 3, 16, 64, 16, None) == -1
+    assert b"frag_ws" in lib.augcl_last_error()
+    assert lib.augcl_enc_stack_infer(16, one, one, None, None, 16, 16, 1 << 30, 11, 4, 9, 84, 84, 2, 255.0, 2, 16, 64, 16, None) == -1
+    assert b"precision" in lib.augcl_last_error()
+    # bf16 mode: 80-byte pixel slots -- a whole 41 x 41 image and all ten 32 -> 32 layers are one work item / one launch
+    rb = lib.augcl_internal_chain_bf16_rounds
+    assert rb(41, 41, 10, 1) == 12 + 11 + 10 + 9 + 8 + 7 + 6 + 5 + 5 + 4 and rb(41, 41, 13, 1) == -1 and rb(47, 47, 3, 1) == -1
+    assert lib.augcl_enc_stack_infer(16, one, one, None, None, 16, 16, 1 << 30, 11, 4, 9, 84, 84, 2, 255.0, 1, 16, 64, None, None) == -1
     assert b"frag_ws" in lib.augcl_last_error()

@@ -164,3 +164,52 @@ def test_chain_launch_on_odd_shapes(cuda, B, Hi, Wi, nl, parts):
         assert _rel(out, y) <= 3e-6
         # the launch leaves max |out| for a following chain
         assert abs(float(am[2]) - float(out.abs().max())) <= 1e-6 * float(out.abs().max())
+
+
+@pytest.mark.parametrize("B,n_layers,dual", [(1, 11, False), (3, 11, True), (8, 4, False), (64, 11, False), (256, 11, True), (300, 11, False)])
+def test_infer_bf16_mode_equals_the_per_layer_bf16_kernels(cuda, B, n_layers, dual):
+    """precision "bf16" (BASELINE config 2's bf16 leg; NOT the parity path): the chains round every layer's output to bf16
+    exactly where the per-layer kernels store bf16, with the same products in the same order -- the two paths agree to the bit,
+    and both sit at bf16 resolution from the float64 stack."""
+    from augcl_amd import encoder_hip, encoder_ops
+    x = torch.from_numpy(np.random.RandomState(B).randint(0, 256, (B, 9, 84, 84)).astype(np.float32)).to(cuda)
+    (wa, ba), (wb, bb) = _stack(31, n_layers, dev=cuda), _stack(32, n_layers, dev=cuda)
+    with torch.no_grad():
+        if dual:
+            out = encoder_hip.conv_stack_infer(x, wa, ba, wb, bb, 2, 255.0, "bf16")
+        else:
+            out = encoder_hip.conv_stack_infer(x, wa, ba, None, None, 2, 255.0, "bf16")
+        assert out is not None
+        encoder_hip._CHAINS = False
+        try:
+            if dual:
+                a_, b_ = encoder_ops.conv_stack_dual(x, wa, ba, wb, bb, precision="bf16")
+                layerwise = torch.cat([a_, b_])
+            else:
+                layerwise = encoder_ops.conv_stack(x, wa, ba, precision="bf16")
+        finally:
+            encoder_hip._CHAINS = True
+    assert out.shape == layerwise.shape
+    assert torch.equal(out, layerwise), float((out - layerwise).abs().max())
+    want = _ref64(x, wa, ba, 2, 255.0)
+    assert _rel(out[:B], want) <= 3e-2
+
+
+@pytest.mark.parametrize("H,W,n_layers", [(100, 100, 11), (64, 64, 6), (50, 70, 4), (120, 84, 12)])
+def test_infer_bf16_mode_other_frame_sizes(cuda, H, W, n_layers):
+    """Frames whose first-layer output does not fit LDS whole (the planner cuts parts / several chains, the chain boundary is
+    bf16 NHWC) against the per-layer bf16 kernels."""
+    from augcl_amd import encoder_hip, encoder_ops
+    B = 5
+    x = torch.from_numpy(np.random.RandomState(H + W).randint(0, 256, (B, 9, H, W)).astype(np.float32)).to(cuda)
+    ws, bs = _stack(H + 1, n_layers, dev=cuda)
+    with torch.no_grad():
+        out = encoder_hip.conv_stack_infer(x, ws, bs, None, None, 2, 255.0, "bf16")
+        if out is None:
+            pytest.skip("shape not covered by the chains")
+        encoder_hip._CHAINS = False
+        try:
+            layerwise = encoder_ops.conv_stack(x, ws, bs, precision="bf16")
+        finally:
+            encoder_hip._CHAINS = True
+    assert torch.equal(out, layerwise), float((out - layerwise).abs().max())

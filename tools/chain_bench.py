@@ -7,7 +7,8 @@ sys.path.insert(0, '.')
 from augcl_amd import encoder_hip, encoder_ops  # noqa: E402
 
 dev = torch.device('cuda:0')
-Bs = [int(a) for a in sys.argv[1:]] or [256, 512]
+prec = "bf16" if "bf16" in sys.argv[1:] else "f32"
+Bs = [int(a) for a in sys.argv[1:] if a.isdigit()] or [256, 512]
 
 
 def timeit(fn, n=20):
@@ -34,6 +35,7 @@ def stack(seed):
 
 
 (wa, ba), (wb, bb) = stack(1), stack(2)
+print("precision", prec)
 print("B     single: layerwise -> chains (us)     dual: layerwise -> chains (us)")
 for B in Bs:
     x = torch.randint(0, 256, (B, 9, 84, 84), device=dev).float()
@@ -43,9 +45,9 @@ for B in Bs:
             for chains in (False, True):
                 encoder_hip._CHAINS = chains
                 if dual:
-                    fn = lambda: encoder_ops.conv_stack_dual(x, wa, ba, wb, bb)  # noqa: E731
+                    fn = lambda: encoder_ops.conv_stack_dual(x, wa, ba, wb, bb, precision=prec)  # noqa: E731
                 else:
-                    fn = lambda: encoder_ops.conv_stack(x, wa, ba)  # noqa: E731
+                    fn = lambda: encoder_ops.conv_stack(x, wa, ba, precision=prec)  # noqa: E731
                 res.append(timeit(fn))
     encoder_hip._CHAINS = True
     print("%-5d %9.1f -> %7.1f                    %9.1f -> %7.1f" % (B, *res))
