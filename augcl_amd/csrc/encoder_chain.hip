@@ -520,6 +520,8 @@ struct ChainBfArgs {
     void *out;                     // f32 NCHW (B,32,Hf,Wf) when out_f32, else bf16 NHWC (B,Hf,Wf,32)
     const float *bias[2][CB_MAXL]; // [weight set][layer] (32) or null
     const vu4 *wfrag[2][CB_MAXL];  // k_bf16_prep: [18 operands][64 lanes] x 16 B
+    void *acts[CB_MAXL];           // gradient-carrying forward: acts[j] != null receives layer j's output (bf16 NHWC, every row
+                                   // once: a part stores the rows it owns) for the backward pass; j < nl - 1
     int nl, B, Hi, Wi, parts, rows_out, relu_last, dual, n_items, out_f32;
     uint32_t magic_w[CB_MAXL];     // floor(2^32 / width of layer j's output) + 1
     uint32_t magic_parts;
@@ -654,6 +656,14 @@ __global__ __launch_bounds__(512, 2) void k_conv32_chain_bf16(ChainBfArgs a)
             const bool relu = !last || a.relu_last;
             const int relu_floor = __builtin_amdgcn_readfirstlane(relu ? 0 : (int)0x80000000);
             const short relu16 = (short)__builtin_amdgcn_readfirstlane(relu ? 0 : -32768);
+            // a copy of the layer's output for the backward pass (bounded by its own size: a lane that owns no row names an offset
+            // beyond it and the store is dropped)
+            const int Hj = a.Hi - 2 * (j + 1);
+            void *keep = last ? nullptr : a.acts[j];
+            const __amdgpu_buffer_rsrc_t rs_keep = __builtin_amdgcn_make_buffer_rsrc(
+                keep ? keep : a.out, 0, keep ? (int)((unsigned)(a.B * Hj * Wout) * 64u) : 0, 0x00020000);
+            const bool last_part = it.y0 + it.ny >= Hf;
+            unsigned pkoff = kNoStore;
 
             auto locate = [&](int tl, bool &valid_, int &off_, int &yy_, int &xx_) {
                 int m_ = tl * 32 + l31;
@@ -696,8 +706,10 @@ __global__ __launch_bounds__(512, 2) void k_conv32_chain_bf16(ChainBfArgs a)
                     const int g4 = (g - 5) >> 2;
                     if (last) // bf16 NHWC out: 8 bytes at pixel * 64 + 16 g4 + 8 h
                         __builtin_amdgcn_raw_buffer_store_b64(vu2{pk[2 * g4], pk[2 * g4 + 1]}, rs_out, pboff, (unsigned)(16 * g4), 0);
-                    else
+                    else {
                         *reinterpret_cast<vu2 *>(pdst + 16 * g4) = vu2{pk[2 * g4], pk[2 * g4 + 1]};
+                        __builtin_amdgcn_raw_buffer_store_b64(vu2{pk[2 * g4], pk[2 * g4 + 1]}, rs_keep, pkoff, (unsigned)(16 * g4), 0);
+                    }
                 }
             };
             auto epilogue_now = [&]() {
@@ -742,6 +754,8 @@ __global__ __launch_bounds__(512, 2) void k_conv32_chain_bf16(ChainBfArgs a)
                                           : (unsigned)(((it.b * Hf + it.y0 + yy) * Wf + xx) * 64 + 8 * h);
                     } else {
                         pdst = valid ? img + (yy * Wi + xx) * CB_SLOT + 8 * h : dump_slot;
+                        // rows [y0, y0 + ny) of every layer belong to this part, the rows behind them to the next one (the last part: all)
+                        pkoff = (valid && (yy < it.ny || last_part)) ? (unsigned)(((it.b * Hj + it.y0 + yy) * Wout + xx) * 64 + 8 * h) : kNoStore;
                     }
                     pending = true;
                     valid = valid2; off = off2; yy = yy2; xx = xx2;
@@ -884,7 +898,8 @@ int augcl_internal_bf16_prep_weights(const float *const *w, int n, void *out, in
 
 int augcl_internal_chain_bf16_forward(const void *in_bf16_nhwc, void *out, const void *const *wfragA, const float *const *biasA,
                                       const void *const *wfragB, const float *const *biasB, int nl, int B, int Hi, int Wi, int parts,
-                                      int relu_last, int out_f32_nchw, augcl_stream_t stream)
+                                      int relu_last, int out_f32_nchw, void *const *acts_out /* nl - 1 buffers or null */,
+                                      augcl_stream_t stream)
 {
     const char *name = "augcl_enc_stack_infer";
     AUGCL_REQUIRE(in_bf16_nhwc && out && wfragA && biasA, "%s: null tensor", name);
@@ -902,6 +917,7 @@ int augcl_internal_chain_bf16_forward(const void *in_bf16_nhwc, void *out, const
         a.wfrag[1][j] = reinterpret_cast<const vu4 *>(wfragB ? wfragB[j] : wfragA[j]);
         a.bias[1][j] = wfragB ? biasB[j] : biasA[j];
         a.magic_w[j] = (uint32_t)(0x100000000ull / (unsigned)(Wi - 2 * (j + 1))) + 1u;
+        a.acts[j] = (acts_out && j + 1 < nl) ? acts_out[j] : nullptr;
     }
     a.nl = nl; a.B = B; a.Hi = Hi; a.Wi = Wi; a.parts = parts;
     const int Hf = Hi - 2 * nl;

@@ -121,6 +121,12 @@ int augcl_enc_x2_conv32_backward_weights(const float *act_prev, const float *dz,
     return augcl_enc_x3_conv32_backward_weights(act_prev, dz, dw, db, workspace, workspace_bytes, B, Hi, Wi, stream);
 }
 
+// bf16 mode's gradient-carrying forward with the 32 -> 32 layers as chains (encoder_chain.hip): AUGCL_OK when it ran, +1 when the
+// shape / workspace is not covered (the caller runs the per-layer kernels), negative on error.  Defined below the chain planner.
+static int bf16_forward_chained(const float *x, const float *const *w, const float *const *b, void *const *acts_out, int n_layers,
+                                int B, int C, int H, int W, int first_stride, float scale, void *frag_ws, size_t frag_ws_bytes,
+                                augcl_stream_t stream);
+
 // precision: 0 = f32 NCHW activations, f32 MFMA; 1 = bf16 NHWC activations (performance mode); 2 = f32 NCHW activations
 // with the 32 -> 32 layers on the split-bf16 kernels (float32-accurate products on the bf16 pipe); 3 = the same tensors with
 // the 32 -> 32 layers on the f16-pair kernels (float32-accurate, half the matrix instructions of 2: the parity path).
@@ -135,6 +141,10 @@ int augcl_enc_stack_forward(const float *x, const float *const *w, const float *
     AUGCL_REQUIRE(precision >= 0 && precision <= 3, "%s: precision must be 0, 1, 2 or 3", name);
     AUGCL_REQUIRE(precision != 1 || n_layers >= 2, "%s: bf16 mode needs >= 2 layers", name);
     int h = H, ww = W, rc;
+    if (precision == 1) { // the 32 -> 32 layers as LDS-resident chains that also store every layer's output for the backward pass
+        rc = bf16_forward_chained(x, w, b, acts_out, n_layers, B, C, H, W, first_stride, scale, frag_ws, frag_ws_bytes, stream);
+        if (rc <= 0) return rc;
+    }
     const void *cur = x;
     size_t fblock = 0;
     const bool x2 = precision == 3 && n_layers >= 2;
@@ -277,7 +287,7 @@ int augcl_internal_chain_bf16_rounds(int Hi, int Wi, int nl, int parts);
 int augcl_internal_bf16_prep_weights(const float *const *w, int n, void *out, int stride, augcl_stream_t stream);
 int augcl_internal_chain_bf16_forward(const void *in_bf16_nhwc, void *out, const void *const *wfragA, const float *const *biasA,
                                       const void *const *wfragB, const float *const *biasB, int nl, int B, int Hi, int Wi, int parts,
-                                      int relu_last, int out_f32_nchw, augcl_stream_t stream);
+                                      int relu_last, int out_f32_nchw, void *const *acts_out, augcl_stream_t stream);
 int augcl_internal_chain_forward(const float *in, float *out, const void *const *wfragA, const float *const *biasA,
                                  const void *const *wfragB, const float *const *biasB, int nl, int B, int Hi, int Wi, int parts,
                                  int relu_last, const float *amax_in, float *amax_out, augcl_stream_t stream);
@@ -333,6 +343,38 @@ int cu_count_stack()
 }
 
 } // namespace
+
+static int bf16_forward_chained(const float *x, const float *const *w, const float *const *b, void *const *acts_out, int n_layers,
+                                int B, int C, int H, int W, int first_stride, float scale, void *frag_ws, size_t frag_ws_bytes,
+                                augcl_stream_t stream)
+{
+    const char *name = "augcl_enc_stack_forward";
+    if (n_layers < 2 || n_layers > 33 || frag_ws == nullptr || frag_ws_bytes < augcl_enc_frag_workspace_bytes(n_layers - 1, 1)) return 1;
+    const int h1 = out_hw(H, first_stride), w1 = out_hw(W, first_stride);
+    ChainPlan plan;
+    if (!plan_chains(h1, w1, n_layers - 1, B, cu_count_stack(), plan, augcl_internal_chain_bf16_rounds, 12)) return 1;
+    const size_t block = augcl_enc_frag_workspace_bytes(1, 1);
+    int rc = augcl_internal_bf16_prep_weights(w + 1, n_layers - 1, frag_ws, (int)block, stream);
+    if (rc != AUGCL_OK) return rc;
+    rc = augcl_enc_bf16_conv_first_forward(x, w[0], b[0], acts_out[0], B, C, H, W, first_stride, scale, 1, stream);
+    if (rc != AUGCL_OK) return rc;
+    int layer = 1, h = h1, ww = w1;
+    for (int c = 0; c < plan.n; ++c) {
+        const int nl = plan.nl[c];
+        const bool final_chain = c == plan.n - 1;
+        const void *fa[12];
+        for (int j = 0; j < nl; ++j) fa[j] = (char *)frag_ws + (size_t)(layer + j - 1) * block;
+        // acts_out[layer + j] = output of the chain's layer j; its last layer's goes through the kernel's `out`
+        rc = augcl_internal_chain_bf16_forward(acts_out[layer - 1], acts_out[layer + nl - 1], fa, b + layer, nullptr, nullptr, nl, B, h, ww,
+                                               plan.parts[c], final_chain ? 0 : 1, final_chain ? 1 : 0, acts_out + layer, stream);
+        if (rc > 0) return augcl::fail(AUGCL_E_UNSUPPORTED, "%s: chain of %d layers at %d x %d not covered", name, nl, h, ww);
+        if (rc != AUGCL_OK) return rc;
+        layer += nl;
+        h -= 2 * nl;
+        ww -= 2 * nl;
+    }
+    return AUGCL_OK;
+}
 
 size_t augcl_enc_stack_infer_scratch_bytes(int n_layers, int B_total, int C, int H, int W, int first_stride)
 {
@@ -391,7 +433,7 @@ int augcl_enc_stack_infer(const float *x, const float *const *wA, const float *c
             }
             rc = augcl_internal_chain_bf16_forward(buf[cur], final_chain ? (void *)out : buf[cur ^ 1], fa, bA + layer, wB ? fb : nullptr,
                                                    wB ? bB + layer : nullptr, nl, Bt, h, w, plan.parts[c], final_chain ? 0 : 1,
-                                                   final_chain ? 1 : 0, stream);
+                                                   final_chain ? 1 : 0, nullptr, stream);
             if (rc > 0) return augcl::fail(AUGCL_E_UNSUPPORTED, "%s: chain of %d layers at %d x %d not covered", name, nl, h, w);
             if (rc != AUGCL_OK) return rc;
             layer += nl;

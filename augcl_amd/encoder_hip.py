@@ -290,7 +290,8 @@ class ConvStackFn(torch.autograd.Function):
             ptrs = [arena.data_ptr() + (i & 1) * big * arena.element_size() for i in range(n_layers - 1)]
         ptrs.append(out.data_ptr())
         amax = arena.data_ptr() + tot * 4 if tail else None
-        fws = _frag_ws(dev, n_layers - 1) if precision in _SPLIT and n_layers > 1 else None
+        # (bf16 mode: the chains' prepared bf16 fragments live in the same workspace; _CHAINS off = per-layer kernels, no workspace)
+        fws = _frag_ws(dev, n_layers - 1) if (precision in _SPLIT or (bf16 and _CHAINS)) and n_layers > 1 else None
         _lib.call("augcl_enc_stack_forward", x.data_ptr(), _ptr_array([t.data_ptr() for t in weights]),
                   _ptr_array([t.data_ptr() for t in biases]), _ptr_array(ptrs), n_layers, B, C, H, W, first_stride,
                   input_scale, PRECISION_CODE[precision], _lib.ptr(fws), fws.numel() if fws is not None else 0, amax, bits,

@@ -213,3 +213,30 @@ def test_infer_bf16_mode_other_frame_sizes(cuda, H, W, n_layers):
         finally:
             encoder_hip._CHAINS = True
     assert torch.equal(out, layerwise), float((out - layerwise).abs().max())
+
+
+@pytest.mark.parametrize("B,H,W,n_layers", [(4, 84, 84, 11), (37, 84, 84, 11), (3, 100, 100, 11), (2, 64, 72, 5)])
+def test_bf16_gradient_carrying_forward_through_chains_equals_per_layer(cuda, B, H, W, n_layers):
+    """bf16 mode with gradients: the chains also store every layer's bf16 output for the backward pass (each row once, by the
+    part that owns it) -- the forward value and every dW / db of the backward pass that reads those stores are bit-identical to
+    the per-layer kernels' (same products, same order, same roundings)."""
+    from augcl_amd import encoder_hip, encoder_ops
+    x = torch.from_numpy(np.random.RandomState(B + H).randint(0, 256, (B, 9, H, W)).astype(np.float32)).to(cuda)
+    ws, bs = _stack(41, n_layers, dev=cuda)
+    res = []
+    for chains in (True, False):
+        encoder_hip._CHAINS = chains
+        try:
+            wg = [w.clone().requires_grad_(True) for w in ws]
+            bg = [b.clone().requires_grad_(True) for b in bs]
+            out = encoder_ops.conv_stack(x, wg, bg, precision="bf16")
+            g = torch.from_numpy(np.random.RandomState(5).standard_normal(tuple(out.shape)).astype(np.float32)).to(cuda)
+            (out * g).sum().backward()
+            torch.cuda.synchronize()
+            res.append((out.detach().clone(), [w.grad.clone() for w in wg], [b.grad.clone() for b in bg]))
+        finally:
+            encoder_hip._CHAINS = True
+    (o1, dw1, db1), (o0, dw0, db0) = res
+    assert torch.equal(o1, o0)
+    for a, b in zip(dw1 + db1, dw0 + db0):
+        assert torch.equal(a, b), float((a - b).abs().max())
