@@ -125,7 +125,9 @@ _SIGS = {
     "augcl_enc_x2_conv32_backward_weights": [_P, _P, _P, _P, _P, _SZ, _I, _I, _I, _P, _P, _P],
     "augcl_enc_stack_forward": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P, _SZ, _P, _P, _P],
     "augcl_enc_frag_workspace_bytes": [_I, _I],
-    "augcl_enc_stack_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P, _SZ, _I, _I, _I, _I, _I, _I, _F, _I, _I, _P, _SZ, _P, _P, _P, _P],
+    "augcl_enc_stack_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P, _SZ, _I, _I, _I, _I, _I, _I, _F, _I, _I, _P, _SZ, _P, _P, _P, _P,
+                                 _SZ, _P],
+    "augcl_enc_stack_backward_chain_bytes": [_I, _I, _I, _I, _I, _I],
     "augcl_enc_stack_forward_dual": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P, _SZ, _P, _P],
     "augcl_enc_stack_infer_scratch_bytes": [_I, _I, _I, _I, _I, _I],
     "augcl_enc_stack_infer": [_P, _P, _P, _P, _P, _P, _P, _SZ, _I, _I, _I, _I, _I, _I, _F, _I, _P, _SZ, _P, _P],
@@ -141,7 +143,7 @@ _SIGS = {
     "augcl_enc_conv_first_backward_weights": [_P, _P, _P, _P, _P, _SZ, _I, _I, _I, _I, _I, _F, _P],
 }
 _RESTYPE = {"augcl_last_error": _c.c_char_p, "augcl_enc_wgrad_workspace_bytes": _SZ, "augcl_enc_frag_workspace_bytes": _SZ,
-            "augcl_enc_stack_infer_scratch_bytes": _SZ}
+            "augcl_enc_stack_infer_scratch_bytes": _SZ, "augcl_enc_stack_backward_chain_bytes": _SZ}
 
 _lib = None
 

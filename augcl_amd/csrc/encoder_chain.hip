@@ -543,6 +543,7 @@ struct PrepBfArgs {
     const float *w[32];
     char *out;     // [n] blocks of `stride` bytes
     int stride;
+    int mode;      // 0: forward W[co][ci][t];  1: backward-data W'[ci][co][t] = W[co][ci][8 - t]
 };
 
 __global__ __launch_bounds__(256) void k_bf16_prep(PrepBfArgs a)
@@ -553,7 +554,8 @@ __global__ __launch_bounds__(256) void k_bf16_prep(PrepBfArgs a)
     const float *w = a.w[blockIdx.y];
     bf16x8c f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) f[j] = (__bf16)w[l31 * 288 + (16 * s + 8 * h + j) * 9 + t];
+    for (int j = 0; j < 8; ++j)
+        f[j] = a.mode == 0 ? (__bf16)w[l31 * 288 + (16 * s + 8 * h + j) * 9 + t] : (__bf16)w[(16 * s + 8 * h + j) * 288 + l31 * 9 + (8 - t)];
     reinterpret_cast<vu4 *>(a.out + (size_t)blockIdx.y * a.stride)[i * 64 + lane] = __builtin_bit_cast(vu4, f);
 }
 
@@ -774,6 +776,219 @@ __global__ __launch_bounds__(512, 2) void k_conv32_chain_bf16(ChainBfArgs a)
     }
 }
 
+
+// =========================================================================================================================
+// bf16 mode, BACKWARD-DATA of the whole stack in one launch.  dZ of layer i - 1's output = full correlation of dZ_i with the
+// flipped, transposed weights, gated by the ReLU of layer i's input -- a map that GROWS by two pixels per step.  On a zeroed
+// canvas of (Ht + 2 nl + 2)^2 pixel slots with the incoming gradient placed at origin (2 nl, 2 nl), step s's output pixel at
+// canvas (r, c) is sum_k W'[k] canvas(r + ky, c + kx): the forward chain's access pattern (a pixel reads at and behind itself),
+// so every step runs IN PLACE exactly like a forward layer, its map's origin moving two pixels up and left; what lies behind
+// and below a map is zero because nothing has been written there yet.  Every step's output is also stored (bf16 NHWC) for the
+// backward-weights launches that follow; nothing is read back.  One work item = one image (the 43 x 43 canvas of the training
+// stack is 145 KiB).  Same products, order and roundings as k_conv32_bf16<1>: bit-identical gradients.
+constexpr int CW_NU = 8; // loader rounds for the incoming map: 256 lanes x 8 chunks of 16 B = 512 pixels
+
+struct ChainBwArgs {
+    const vu4 *dz_top;            // bf16 NHWC (B,Ht,Wt,32)
+    const vu4 *wfrag[CB_MAXL];    // step s: k_bf16_prep mode-1 fragments of layer n - 1 - s
+    const void *mask[CB_MAXL];    // step s: that layer's INPUT (bf16 NHWC (B,Ht+2s+2,Wt+2s+2,32)): the gate of the step's output; or null
+    void *dz_out[CB_MAXL];        // step s: receives the step's output, bf16 NHWC (B,Ht+2s+2,Wt+2s+2,32)
+    int nl, B, Ht, Wt;
+    uint32_t magic_w[CB_MAXL];    // floor(2^32 / (Wt + 2 s + 2)) + 1
+    uint32_t magic_p;             // floor(2^32 / canvas pitch) + 1
+};
+
+__global__ __launch_bounds__(512, 2) void k_bwd32_chain_bf16(ChainBwArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char ldsw[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = wave >= 4;
+    const int cw = wave & 3;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int nl = a.nl, Ht = a.Ht, Wt = a.Wt;
+    const int P = Wt + 2 * nl + 2, R = Ht + 2 * nl + 2; // canvas pitch / rows (two spare zero columns / rows at the far edges)
+    char *img = ldsw + CB_HDR;
+    const int G = (int)gridDim.x, n = a.B, first = xcd_slot((int)blockIdx.x, G);
+    const int rowb = P * CB_SLOT;
+    auto rounds_of = [&](int s_) {
+        const int npix = (Ht + 2 * s_ + 2) * (Wt + 2 * s_ + 2);
+        return (((npix + 31) >> 5) + 3) >> 2;
+    };
+
+    if (loader) {
+        const int lt = cw * 64 + lane;
+        vu4 d[CW_NU];
+        const int nchunk = Ht * Wt * 4;
+        auto issue = [&](int b) {
+            const vu4 *src = a.dz_top + (size_t)b * nchunk;
+#pragma unroll
+            for (int u = 0; u < CW_NU; ++u)
+                if (256 * u < nchunk) d[u] = src[min(u * 256 + lt, nchunk - 1)];
+        };
+        auto dump = [&](bool first_item) {
+            // zero what the previous image left (its last map covers rows / columns [0, 2 nl + Ht)); the first time: everything.
+            // The incoming map's own pixels are skipped: they are written below, by other lanes, in no particular order
+            const int zr = first_item ? R : Ht + 2 * nl;
+            const vu4 zero = {0u, 0u, 0u, 0u};
+            for (int id = lt; id < zr * P * 4; id += 256) {
+                const int px = id >> 2;
+                const int r = (int)__umulhi((uint32_t)px, a.magic_p), c = px - r * P;
+                const bool inside = r >= 2 * nl && r < 2 * nl + Ht && c >= 2 * nl && c < 2 * nl + Wt;
+                if (!inside) *reinterpret_cast<vu4 *>(img + px * CB_SLOT + (id & 3) * 16) = zero;
+            }
+#pragma unroll
+            for (int u = 0; u < CW_NU; ++u)
+                if (256 * u < nchunk) {
+                    const int q = min(u * 256 + lt, nchunk - 1), p_ = q >> 2;
+                    const int y = p_ / Wt, x = p_ - y * Wt;
+                    *reinterpret_cast<vu4 *>(img + ((2 * nl + y) * P + 2 * nl + x) * CB_SLOT + (q & 3) * 16) = d[u];
+                }
+        };
+        if (first < n) {
+            issue(first);
+            dump(true);
+        }
+        int nb = 0;
+        for (int s_ = 0; s_ + 1 < nl; ++s_) nb += rounds_of(s_) + 1;
+        for (int item = first; item < n; item += G) {
+            __syncthreads(); // A
+            const int nxt = item + G;
+            if (nxt < n) issue(nxt);
+            for (int i = 0; i < nb; ++i) __syncthreads();
+            __syncthreads(); // F
+            if (nxt < n) dump(false);
+        }
+        return;
+    }
+
+    bf16x8c wc[18], wn[18];
+    auto load_next = [&](const vu4 *wf) {
+#pragma unroll
+        for (int i = 0; i < 18; ++i) wn[i] = __builtin_bit_cast(bf16x8c, wf[i * 64 + lane]);
+    };
+    char *dump_slot = ldsw + 512 + 96 * cw;
+    constexpr unsigned kNoStore = 0xfffffff0u;
+    typedef uint32_t vu2 __attribute__((ext_vector_type(2)));
+    typedef unsigned short u16x2c __attribute__((ext_vector_type(2)));
+    if (first < n) load_next(a.wfrag[0]);
+
+    for (int item = first; item < n; item += G) {
+        __syncthreads(); // A
+        auto step = [&](int s_, auto last_tag) {
+            constexpr bool last = decltype(last_tag)::value;
+            const int Ho = Ht + 2 * s_ + 2, Wo = Wt + 2 * s_ + 2, oo = 2 * (nl - s_) - 2; // output size, its origin on the canvas
+            const int npix = Ho * Wo, ntiles = (npix + 31) >> 5, rounds = (ntiles + 3) >> 2;
+            const uint32_t magic = a.magic_w[s_];
+#pragma unroll
+            for (int i = 0; i < 18; ++i) wc[i] = wn[i];
+            load_next(a.wfrag[last ? 0 : s_ + 1]); // (the next image starts with step 0's again)
+            const unsigned osize = (unsigned)(a.B * Ho * Wo) * 64u;
+            const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.dz_out[s_], 0, (int)osize, 0x00020000);
+            // no gate: the loads read the output buffer itself (valid memory) and `gate_and` lets everything pass
+            const bool gated = a.mask[s_] != nullptr;
+            const __amdgpu_buffer_rsrc_t rs_mask = __builtin_amdgcn_make_buffer_rsrc(
+                gated ? const_cast<void *>(a.mask[s_]) : a.dz_out[s_], 0, (int)osize, 0x00020000);
+            const uint32_t gate_or = (uint32_t)__builtin_amdgcn_readfirstlane(gated ? 0 : (int)0x00010001);
+
+            auto locate = [&](int tl, bool &valid_, int &off_, unsigned &goff_) {
+                int m_ = tl * 32 + l31;
+                valid_ = m_ < npix;
+                if (!valid_) m_ = npix - 1;
+                const int yy_ = (int)__umulhi((uint32_t)m_, magic), xx_ = m_ - yy_ * Wo;
+                off_ = ((oo + yy_) * P + oo + xx_) * CB_SLOT + h * 16;
+                goff_ = (unsigned)(((item * Ho + yy_) * Wo + xx_) * 64 + 8 * h);
+            };
+            auto rd = [&](int off_, int i) {
+                const int t = i >> 1;
+                return *reinterpret_cast<const vu4 *>(img + off_ + (t / 3) * rowb + ((t % 3) * CB_SLOT + (i & 1) * 32));
+            };
+            f32x16 prev;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) prev[q] = 0.0f;
+            char *pdst = dump_slot;
+            unsigned pgoff = kNoStore;
+            vu2 pgate[4] = {vu2{0u, 0u}, vu2{0u, 0u}, vu2{0u, 0u}, vu2{0u, 0u}};
+            bool pending = false;
+            uint32_t pk[8];
+            // the previous tile's epilogue in the gaps: pair p = channels (2p, 2p + 1) of the lane's 16 -> packed bf16 (gap 2p), times the
+            // gate (a_prev != 0, as min(|bits|, 1) per 16-bit half: gap 2p + 1), stored with its neighbour pair two gaps later
+            auto epi_slot = [&](int g) {
+                if (g < 16 && !(g & 1)) {
+                    typedef float f32x2c __attribute__((ext_vector_type(2)));
+                    pk[g >> 1] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2c{prev[g], prev[g + 1]}, bf16x2c));
+                }
+                if (g < 16 && (g & 1)) {
+                    const int p_ = g >> 1;
+                    const uint32_t gb = (pgate[p_ >> 1][p_ & 1] & 0x7fff7fffu) | gate_or; // -0 counts as 0; no gate: every half is 1
+                    const u16x2c keep = __builtin_elementwise_min(__builtin_bit_cast(u16x2c, gb), u16x2c{1, 1});
+                    pk[p_] = __builtin_bit_cast(uint32_t, (u16x2c)(__builtin_bit_cast(u16x2c, pk[p_]) * keep));
+                }
+                if (g >= 5 && (g & 3) == 1 && g <= 17) {
+                    const int g4 = (g - 5) >> 2;
+                    if (!last) *reinterpret_cast<vu2 *>(pdst + 16 * g4) = vu2{pk[2 * g4], pk[2 * g4 + 1]};
+                    __builtin_amdgcn_raw_buffer_store_b64(vu2{pk[2 * g4], pk[2 * g4 + 1]}, rs_out, pgoff, (unsigned)(16 * g4), 0);
+                }
+            };
+            auto epilogue_now = [&]() {
+#pragma unroll
+                for (int g = 0; g < 18; ++g) epi_slot(g);
+            };
+            bool valid = false;
+            int off = 0;
+            unsigned goff = 0u;
+            constexpr int AH = 6;
+            vu4 raw[AH];
+            if (cw < ntiles) {
+                locate(cw, valid, off, goff);
+#pragma unroll
+                for (int i = 0; i < AH; ++i) raw[i] = rd(off, i);
+            }
+            for (int r = 0; r < rounds; ++r) {
+                const int tl = 4 * r + cw;
+                if (tl < ntiles) {
+                    bool valid2;
+                    int off2;
+                    unsigned goff2;
+                    locate(tl + 4 < ntiles ? tl + 4 : tl, valid2, off2, goff2);
+                    vu2 gcur[4]; // this tile's gates: requested now, used in its epilogue (one tile later)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4)
+                        gcur[g4] = __builtin_bit_cast(vu2, __builtin_amdgcn_raw_buffer_load_b64(rs_mask, valid ? goff : 0u, (unsigned)(16 * g4), 0));
+                    f32x16 acc;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
+#pragma unroll
+                    for (int i = 0; i < 18; ++i) {
+                        const vu4 cur = raw[i % AH];
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wc[i], __builtin_bit_cast(bf16x8c, cur), acc, 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        raw[i % AH] = i + AH < 18 ? rd(off, i + AH) : rd(off2, i + AH - 18);
+                        epi_slot(i);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    prev = acc;
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) pgate[g4] = gcur[g4];
+                    pdst = (valid && !last) ? img + off - h * 16 + 8 * h : dump_slot;
+                    pgoff = valid ? goff : kNoStore;
+                    pending = true;
+                    valid = valid2; off = off2; goff = goff2;
+                } else if (pending) {
+                    epilogue_now();
+                    pending = false;
+                }
+                if (!last) __syncthreads(); // R
+            }
+            if (pending) epilogue_now();
+            if (!last) __syncthreads(); // L
+        };
+        for (int s_ = 0; s_ + 1 < nl; ++s_) step(s_, std::false_type{});
+        step(nl - 1, std::true_type{});
+        __syncthreads(); // F
+    }
+}
+
 } // namespace augcl
 
 using namespace augcl;
@@ -881,7 +1096,13 @@ int augcl_internal_chain_bf16_rounds(int Hi, int Wi, int nl, int parts)
 }
 
 // bf16 fragments of n (<= 32) 32 -> 32 layers into out, `stride` bytes apart (>= 18 KiB each)
+int augcl_internal_bf16_prep_weights_mode(const float *const *w, int n, void *out, int stride, int mode, augcl_stream_t stream);
 int augcl_internal_bf16_prep_weights(const float *const *w, int n, void *out, int stride, augcl_stream_t stream)
+{
+    return augcl_internal_bf16_prep_weights_mode(w, n, out, stride, 0, stream);
+}
+
+int augcl_internal_bf16_prep_weights_mode(const float *const *w, int n, void *out, int stride, int mode, augcl_stream_t stream)
 {
     const char *name = "augcl_internal_bf16_prep_weights";
     AUGCL_REQUIRE(w && out && n >= 1 && n <= 32 && stride >= CB_FRAG_BYTES && (stride & 15) == 0 && aligned16(out), "%s: bad argument", name);
@@ -892,6 +1113,7 @@ int augcl_internal_bf16_prep_weights(const float *const *w, int n, void *out, in
     }
     a.out = reinterpret_cast<char *>(out);
     a.stride = stride;
+    a.mode = mode;
     hipLaunchKernelGGL(k_bf16_prep, dim3(5, n), dim3(256), 0, as_stream(stream), a);
     return augcl::check_launch(name);
 }
@@ -940,6 +1162,38 @@ int augcl_internal_chain_bf16_forward(const void *in_bf16_nhwc, void *out, const
         if (e != hipSuccess) return augcl::fail(AUGCL_E_LAUNCH, "%s: cannot set dynamic LDS %zu: %s", name, lds, hipGetErrorString(e));
         hipLaunchKernelGGL(k_conv32_chain_bf16<false>, dim3(grid), dim3(512), lds, as_stream(stream), a);
     }
+    return augcl::check_launch(name);
+}
+
+// Backward-data of nl (<= 12) consecutive 32 -> 32 layers in one launch (bf16 mode).  Step s handles layer n - 1 - s: wfrag[s] = its
+// mode-1 fragments, mask[s] = its input (the ReLU gate, or null), dz_out[s] receives the gradient w.r.t. that input's
+// producer.  Returns +1 when the canvas does not fit LDS (the caller runs the per-layer kernels).
+int augcl_internal_chain_bf16_backward(const void *dz_top, const void *const *wfrag, const void *const *mask, void *const *dz_out,
+                                       int nl, int B, int Ht, int Wt, augcl_stream_t stream)
+{
+    const char *name = "augcl_enc_stack_backward";
+    AUGCL_REQUIRE(dz_top && wfrag && mask && dz_out && B >= 1, "%s: null tensor", name);
+    if (nl < 1 || nl > CB_MAXL || Ht < 1 || Wt < 1) return 1;
+    const int P = Wt + 2 * nl + 2, R = Ht + 2 * nl + 2;
+    if ((size_t)CB_HDR + (size_t)R * P * CB_SLOT > (size_t)kLdsBytes || Ht * Wt * 4 > 256 * CW_NU) return 1;
+    if ((size_t)B * (Ht + 2 * nl) * (Wt + 2 * nl) * 64 >= ((size_t)1 << 31)) return 1;
+    ChainBwArgs a{};
+    a.dz_top = reinterpret_cast<const vu4 *>(dz_top);
+    for (int s_ = 0; s_ < nl; ++s_) {
+        AUGCL_REQUIRE(wfrag[s_] && dz_out[s_] && aligned16(dz_out[s_]), "%s: null / misaligned step buffer", name);
+        a.wfrag[s_] = reinterpret_cast<const vu4 *>(wfrag[s_]);
+        a.mask[s_] = mask[s_];
+        a.dz_out[s_] = dz_out[s_];
+        a.magic_w[s_] = (uint32_t)(0x100000000ull / (unsigned)(Wt + 2 * s_ + 2)) + 1u;
+    }
+    a.nl = nl; a.B = B; a.Ht = Ht; a.Wt = Wt;
+    a.magic_p = (uint32_t)(0x100000000ull / (unsigned)P) + 1u;
+    const size_t lds = (size_t)CB_HDR + (size_t)R * P * CB_SLOT;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bwd32_chain_bf16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return augcl::fail(AUGCL_E_LAUNCH, "%s: cannot set dynamic LDS %zu: %s", name, lds, hipGetErrorString(e));
+    const int cus = cu_count_chain();
+    const int grid = B < cus ? B : cus;
+    hipLaunchKernelGGL(k_bwd32_chain_bf16, dim3(grid), dim3(512), lds, as_stream(stream), a);
     return augcl::check_launch(name);
 }
 

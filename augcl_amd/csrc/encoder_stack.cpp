@@ -285,6 +285,9 @@ int augcl_enc_stack_forward_dual(const float *x, const float *const *wA, const f
 int augcl_internal_chain_rounds(int Hi, int Wi, int nl, int parts);
 int augcl_internal_chain_bf16_rounds(int Hi, int Wi, int nl, int parts);
 int augcl_internal_bf16_prep_weights(const float *const *w, int n, void *out, int stride, augcl_stream_t stream);
+int augcl_internal_bf16_prep_weights_mode(const float *const *w, int n, void *out, int stride, int mode, augcl_stream_t stream);
+int augcl_internal_chain_bf16_backward(const void *dz_top, const void *const *wfrag, const void *const *mask, void *const *dz_out,
+                                       int nl, int B, int Ht, int Wt, augcl_stream_t stream);
 int augcl_internal_chain_bf16_forward(const void *in_bf16_nhwc, void *out, const void *const *wfragA, const float *const *biasA,
                                       const void *const *wfragB, const float *const *biasB, int nl, int B, int Hi, int Wi, int parts,
                                       int relu_last, int out_f32_nchw, void *const *acts_out, augcl_stream_t stream);
@@ -374,6 +377,21 @@ static int bf16_forward_chained(const float *x, const float *const *w, const flo
         ww -= 2 * nl;
     }
     return AUGCL_OK;
+}
+
+size_t augcl_enc_stack_backward_chain_bytes(int n_layers, int B, int C, int H, int W, int first_stride)
+{
+    (void)C;
+    if (n_layers < 2 || B < 1 || H < 3 || W < 3 || first_stride < 1) return 0;
+    size_t tot = 0;
+    int h = out_hw(H, first_stride), w = out_hw(W, first_stride); // output of layer 0 = input of layer 1
+    for (int i = 1; i <= n_layers; ++i) { // inputs of layers 1 .. n - 1 (the steps' outputs) and the last layer's output (the top gradient)
+        if (h < 1 || w < 1) return 0;
+        tot += (((size_t)B * h * w * 64) + 255) & ~(size_t)255;
+        h -= 2;
+        w -= 2;
+    }
+    return tot;
 }
 
 size_t augcl_enc_stack_infer_scratch_bytes(int n_layers, int B_total, int C, int H, int W, int first_stride)
@@ -514,7 +532,8 @@ int augcl_enc_stack_backward(const void *const *acts_in, const float *const *w, 
                              const float *amax_acts /* precision 3: the forward pass's amax */,
                              float *amax_dz /* precision 3: n_layers floats of scratch */,
                              const void *const *gate_bits /* precision 3: the forward pass's gate bits, or null */,
-                             augcl_stream_t stream)
+                             void *dz_chain /* precision 1: augcl_enc_stack_backward_chain_bytes(...) of scratch, or null */,
+                             size_t dz_chain_bytes, augcl_stream_t stream)
 {
     const char *name = "augcl_enc_stack_backward";
     AUGCL_REQUIRE(acts_in && w && grad_out && dw && db && dz_a && dz_b && n_layers >= 1, "augcl_enc_stack_backward: bad argument");
@@ -550,6 +569,56 @@ int augcl_enc_stack_backward(const void *const *acts_in, const float *const *w, 
         if (rc != AUGCL_OK) return rc;
     }
     const void *dz = grad_out; // f32 NCHW (B,32,hs[n],ws[n])
+    if (precision == 1 && n_layers >= 2 && n_layers <= 13 && dz_chain != nullptr && frag_ws != nullptr &&
+        frag_ws_bytes >= augcl_enc_frag_workspace_bytes(n_layers - 1, 1) &&
+        dz_chain_bytes >= augcl_enc_stack_backward_chain_bytes(n_layers, B, C, H, W, first_stride)) {
+        // bf16 mode: backward-data of ALL 32 -> 32 layers as one launch on an LDS-resident canvas (encoder_chain.hip), every
+        // layer's gradient stored once; then the backward-weights launches read them.  dz_chain: [dZ of the last layer's output |
+        // step 0's output | step 1's | ...], each bf16 NHWC, 256-byte aligned.
+        const size_t block = augcl_enc_frag_workspace_bytes(1, 1);
+        const int nl = n_layers - 1;
+        const float *wrev[32];
+        for (int s_ = 0; s_ < nl; ++s_) wrev[s_] = w[n_layers - 1 - s_];
+        rc = augcl_internal_bf16_prep_weights_mode(wrev, nl, frag_ws, (int)block, 1, stream);
+        if (rc != AUGCL_OK) return rc;
+        char *p = reinterpret_cast<char *>(dz_chain);
+        auto take = [&](int h_, int w_) {
+            char *q = p;
+            p += (((size_t)B * h_ * w_ * 64) + 255) & ~(size_t)255;
+            return (void *)q;
+        };
+        void *dz_top = take(hs[n_layers], wsz[n_layers]);
+        rc = augcl_enc_nchw_f32_to_nhwc_bf16(grad_out, dz_top, B, hs[n_layers], wsz[n_layers], stream);
+        if (rc != AUGCL_OK) return rc;
+        const void *fr[12], *mk[12];
+        void *dzo[12];
+        for (int s_ = 0; s_ < nl; ++s_) {
+            const int i = n_layers - 1 - s_; // the layer this step differentiates: its input acts_in[i] is hs[i] x wsz[i]
+            fr[s_] = (char *)frag_ws + (size_t)s_ * block;
+            mk[s_] = acts_in[i];
+            dzo[s_] = take(hs[i], wsz[i]);
+        }
+        rc = augcl_internal_chain_bf16_backward(dz_top, fr, mk, dzo, nl, B, hs[n_layers], wsz[n_layers], stream);
+        if (rc < 0) return rc;
+        if (rc == 0) {
+            for (int i = n_layers - 1; i >= 1; --i) { // gradient w.r.t. the output of layer i: the top one, else step (n - 2 - i)'s output
+                const void *dzi = i == n_layers - 1 ? dz_top : dzo[n_layers - 2 - i];
+                float *ws_i = batched ? ws32 + (size_t)(i - 1) * (per_layer / sizeof(float)) : ws32;
+                const size_t ws_i_bytes = batched ? per_layer : ws32_bytes;
+                rc = bf16_wgrad_mfma ? augcl_enc_bf16_conv32_backward_weights_mfma(acts_in[i], dzi, dw[i], db[i], ws_i, ws_i_bytes, B, hs[i], wsz[i], stream)
+                                     : augcl_enc_bf16_conv32_backward_weights(acts_in[i], dzi, dw[i], db[i], ws_i, ws_i_bytes, B, hs[i], wsz[i], stream);
+                if (rc != AUGCL_OK) return rc;
+            }
+            rc = augcl_enc_bf16_conv_first_backward_weights((const float *)acts_in[0], dzo[nl - 1], dw[0], db[0], ws_first, ws_first_bytes, B,
+                                                            C, H, W, first_stride, scale, stream);
+            if (batched) {
+                scope.on = false;
+                const int rc2 = augcl::reduce_defer_flush((hipStream_t)stream, name);
+                if (rc == AUGCL_OK) rc = rc2;
+            }
+            return rc;
+        } // (+1: the canvas does not fit LDS -- the per-layer kernels below)
+    }
     if (precision == 1) {
         rc = augcl_enc_nchw_f32_to_nhwc_bf16(grad_out, dz_a, B, hs[n_layers], wsz[n_layers], stream);
         if (rc != AUGCL_OK) return rc;

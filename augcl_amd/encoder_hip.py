@@ -153,6 +153,7 @@ def _ptr_array(ptrs):
     return (_lib.ctypes.c_void_p * len(ptrs))(*ptrs)
 
 
+_CHAINS_BWD = True  # (A/B switch) bf16 mode: backward-data of the whole stack as one chain launch
 _CHAINS = True  # (A/B switch) no-grad passes of precision "f32" through augcl_enc_stack_infer: LDS-resident layer chains
 _infer_ws = {}
 
@@ -316,12 +317,16 @@ class ConvStackFn(torch.autograd.Function):
         dz = torch.empty(2 * half_n + (_AMAX if amax else 0), dtype=torch.bfloat16 if bf16 else torch.float32, device=dev)
         half = half_n * dz.element_size()
         ws32, wsf = _workspace(dev, 32, max(1, n_layers - 1)), _workspace(dev, C)
-        fws = _frag_ws(dev, n_layers - 1) if precision in _SPLIT and n_layers > 1 else None
+        fws = _frag_ws(dev, n_layers - 1) if (precision in _SPLIT or (bf16 and _CHAINS)) and n_layers > 1 else None
+        dzc, dzc_bytes = None, 0
+        if bf16 and _CHAINS and _CHAINS_BWD and n_layers > 1:  # every layer's gradient map, kept for the backward-weights launches (one-launch backward-data)
+            dzc_bytes = _lib.load().augcl_enc_stack_backward_chain_bytes(n_layers, B, C, H, W, first_stride)
+            dzc = torch.empty(max(dzc_bytes, 16), dtype=torch.uint8, device=dev) if dzc_bytes else None
         _lib.call("augcl_enc_stack_backward", _ptr_array([x.data_ptr()] + list(act_ptrs)),
                   _ptr_array([w.data_ptr() for w in weights]), g.data_ptr(), _ptr_array([t.data_ptr() for t in dws]),
                   _ptr_array([dbs[i].data_ptr() for i in range(n_layers)]), dz.data_ptr(), dz.data_ptr() + half,
                   ws32.data_ptr(), ws32.numel() * 4, wsf.data_ptr(), wsf.numel() * 4, n_layers, B, C, H, W, first_stride,
                   input_scale, PRECISION_CODE[precision], 1 if _BF16_WGRAD.endswith("_mfma") else 0, _lib.ptr(fws),
                   fws.numel() if fws is not None else 0, amax, dz.data_ptr() + 2 * half if amax else None, bits,
-                  _lib.current_stream(dev))
+                  _lib.ptr(dzc), dzc_bytes if dzc is not None else 0, _lib.current_stream(dev))
         return (None, None, None, None, None, *dws, *[dbs[i] for i in range(n_layers)])

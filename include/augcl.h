@@ -389,7 +389,14 @@ int augcl_enc_stack_backward(const void *const *acts_in, const float *const *w, 
                              float *const *db, void *dz_a, void *dz_b, float *ws32, size_t ws32_bytes, float *ws_first,
                              size_t ws_first_bytes, int n_layers, int B, int C, int H, int W, int first_stride,
                              float scale, int precision, int bf16_wgrad_mfma, void *frag_ws, size_t frag_ws_bytes,
-                             const float *amax_acts, float *amax_dz, const void *const *gate_bits, augcl_stream_t stream);
+                             const float *amax_acts, float *amax_dz, const void *const *gate_bits, void *dz_chain,
+                             size_t dz_chain_bytes, augcl_stream_t stream);
+/* dz_chain (precision 1; may be NULL): augcl_enc_stack_backward_chain_bytes(...) bytes of device scratch, 256-byte aligned.  Given
+ * it (and frag_ws), the bf16 mode computes the backward-data of ALL 32 -> 32 layers in ONE launch on an LDS-resident canvas
+ * (csrc/encoder_chain.hip: the gradient map grows by two pixels per layer in place, every layer's gradient is stored once for
+ * the backward-weights launches) -- bit-identical to the per-layer kernels, which run when it is NULL or the canvas does not
+ * fit LDS. */
+size_t augcl_enc_stack_backward_chain_bytes(int n_layers, int B, int C, int H, int W, int first_stride);
 
 /* Two encoders with identical shapes over the SAME input batch in one launch per layer (no-grad passes: the actor's CNN
  * and the target critic's CNN over next_obs, src/algorithms/sac.py:94-101).  acts_out[i] holds 2B images: [0,B) from

@@ -159,7 +159,7 @@ def hip_backward(x, acts_in, ws, gout):
     _lib.call("augcl_enc_stack_backward", _ptrs(acts_in), _ptrs(ws), gout.data_ptr(), _ptrs(dws), _ptrs(dbs), dz.data_ptr(),
               dz.data_ptr() + 4 * big, ws32.data_ptr(), ws32.numel() * 4, wsf.data_ptr(), wsf.numel() * 4, n, B, C, H, W, 2,
               255.0, encoder_hip.PRECISION_CODE[encoder_ops.PRECISION], 0, _lib.ptr(fws), fws.numel() if x2 else 0,
-              _lib.ptr(amax_acts), _lib.ptr(amax_dz), None, _lib.current_stream(dev))
+              _lib.ptr(amax_acts), _lib.ptr(amax_dz), None, None, 0, _lib.current_stream(dev))
     return dws, dbs
 
 
