@@ -60,4 +60,9 @@ def conv_stack(x, weights, biases, first_stride=2, input_scale=255.0, relu_first
         assert w.shape[0] == 32 and w.is_contiguous(), "encoder kernels are built for 32 contiguous filters"
     if len(weights) == 1 and prec == "bf16":
         prec = "f32"  # a lone first layer has no bf16 activation to hand on
+    if not torch.is_grad_enabled():
+        # under torch.no_grad() (the actor step's detached pass, src/algorithms/sac.py:119-122; acting) nothing will ask for a
+        # gradient, but the parameters still say requires_grad: hand them over detached, so that the node takes its no-grad
+        # form (LDS-resident layer chains, no activation arena, no gate bits) instead of the gradient-carrying kernels
+        weights, biases = [w.detach() for w in weights], [b.detach() for b in biases]
     return encoder_hip.ConvStackFn.apply(x, first_stride, float(input_scale), prec, len(weights), *weights, *biases)

@@ -146,12 +146,20 @@ def conv_mix(elem, gate_bits=False, chains=False):
     first = (256 + 512 + 0.5 * 256) * (9 * 84 * 84 * 4) + (512 + 512 + 0.5 * 256) * px(41) * elem  # dual launch reads x once
     wfirst = 512 * (9 * 84 * 84 * 4 + px(41) * elem)
     mix = {"fwd": (10 if chains else 25, fwd), "bwd": (10, bwd), "wgrad": (10, wg), "first": (2.5, first), "wfirst": (1, wfirst)}
-    if chains:
+    if chains and elem == 4:
         mix["chain"] = (3, (512 + 0.5 * 256) * 4 * (px(41) + 2 * px(33) + px(21)))
+    if chains and elem == 2:
+        # bf16 mode (round 4): ONE chain launch per pass (a whole image per work item).  No-grad passes read a_0 (bf16) and write
+        # the last layer (f32); the gradient-carrying pass also stores every intermediate layer once (bf16); backward-data is one
+        # launch as well: it reads the top gradient and every layer's gate (= that layer's bf16 input), writes every gradient map
+        inter = sum(px(HS[i]) * 2 for i in range(1, 10))
+        mix["fwd"] = (0, 0.0)
+        mix["chain"] = (2.5, (512 + 0.5 * 256) * (px(41) * 2 + px(21) * 4) + 512 * (px(41) * 2 + inter + px(21) * 4))
+        mix["bwd"] = (1, 512 * (px(21) * 2 + 2 * sum(px(HS[i]) * 2 for i in range(0, 10))))
     return mix
 
 
-KERNEL_ROLE = [("k_conv32_chain", "chain"), ("k_conv32_x2<0", "fwd"), ("k_conv32_x2<1", "bwd"), ("k_wgrad32_x2", "wgrad"), ("k_conv32_x3<0", "fwd"), ("k_conv32_x3<1", "bwd"), ("k_wgrad32_x3", "wgrad"), ("k_conv32_bf16<0", "fwd"),
+KERNEL_ROLE = [("k_bwd32_chain_bf16", "bwd"), ("k_conv32_chain", "chain"), ("k_conv32_x2<0", "fwd"), ("k_conv32_x2<1", "bwd"), ("k_wgrad32_x2", "wgrad"), ("k_conv32_x3<0", "fwd"), ("k_conv32_x3<1", "bwd"), ("k_wgrad32_x3", "wgrad"), ("k_conv32_bf16<0", "fwd"),
                ("k_conv32_bf16<1", "bwd"), ("k_wgrad32_bf16", "wgrad"), ("k_conv_first9", "first"), ("k_wgrad_first", "wfirst"),
                ("k_conv32<0", "fwd"), ("k_conv32<1", "bwd"), ("k_wgrad32<", "wgrad")]
 
@@ -208,6 +216,8 @@ for prec, elem in (("f32", 4), ("bf16", 2)):
     rows, tot_b, tot_t = {}, 0.0, 0.0
     for role, ks in by_role.items():
         launches, bytes_upd = mix[role]
+        if not launches:  # a role the launch mix says is gone but the trace still shows (fallback launches): time counted, no bytes
+            launches, bytes_upd = sum(c for _, c, _ in ks) / max(n_upd or 1, 1), 0.0
         calls = sum(c for _, c, _ in ks)
         total_us = sum(t for _, _, t in ks)
         us_per_update = total_us / n_upd if n_upd else total_us / calls * launches
