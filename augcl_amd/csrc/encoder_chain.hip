@@ -2,10 +2,11 @@
 // ONE launch, for passes whose intermediate activations nobody reads again: the two no-grad passes of
 // SAC.calculate_target_Q (src/algorithms/sac.py:94-101), the actor step's detached pass (sac.py:119-122) and acting
 // (sac.py:73-92).  Arithmetic = encoder_x2.hip's f16 pairs (float32-accurate products, three v_mfma_f32_32x32x16_f16 per
-// product group); what changes is where the data lives.
+// product group) with the residuals UNSCALED (x s = hi + lo, all three products into one sum: scales are per work item here,
+// see below); what changes is where the data lives.
 //
 // A work item is (image, part): the rows of the chain's LAST layer that one workgroup produces.  Its input -- those rows plus
-// two halo rows per layer, all 32 channels -- is staged ONCE into a pixel-major LDS image (slot = f16 hi | lo' x 32 channels +
+// two halo rows per layer, all 32 channels -- is staged ONCE into a pixel-major LDS image (slot = f16 hi | lo x 32 channels +
 // pad = 144 B, pitch = the input's width) and then every layer of the chain runs IN PLACE on that image: output pixel (y, x)
 // of layer j overwrites input pixel (y, x), which is dead as soon as every output pixel up to (y, x) in raster order has been
 // computed (a valid 3x3 convolution only looks right and down).  The four compute waves take the layer's 32-pixel tiles in
@@ -21,8 +22,11 @@
 // weights' row sums come with the prepared fragments, k_x2_prep), where max|x| is the exact maximum of the item's previous
 // layer (every epilogue takes the maximum of what it stores; one LDS atomic per wave and layer).  The bound is rigorous (no
 // overflow, no fallback) and does not compound: each layer's looseness (2^3..2^5) only costs that many bits at the BOTTOM
-// of f16's range (absolute error < 2^-36 of the bound), none of float32's 24.  The chain's input is scaled by its tensor's
-// maximum like encoder_x2.hip's (its producer leaves it).
+// of f16's range, none of float32's 24.  The chain's INPUT is scaled by the item's own maximum as well (the loader waves take
+// it over the registers they stage): no image's accuracy depends on what else is in the batch, which is what allows the
+// unscaled residuals (the f16 matrix pipe drops subnormal operands: under a TENSOR-wide scale an image 2^20 dimmer than the
+// brightest one came out 1e-4 off; tests/test_referee_gpu.py::test_stack_with_one_outlier_sample...).  A one-layer chain,
+// which has no barriers for the loaders to agree on a maximum, uses the tensor's (amax_in).
 //
 // Loader waves: they fetch the NEXT item's whole input into registers (160 per lane) while the compute waves work, split it
 // there, and dump it into LDS between two barriers when the image is free -- the global loads of an item hide behind the
@@ -42,11 +46,11 @@ struct ChainArgs {
     const float *in;              // (B,32,Hi,Wi) f32 NCHW: input of the chain's first layer (post-ReLU activations)
     float *out;                   // (B,32,Hi-2nl,Wi-2nl) f32 NCHW: output of its last layer
     const float *bias[2][CH_MAXL]; // [weight set][layer] (32) or null
-    const vu4 *wfrag[2][CH_MAXL];  // prepared by k_x2_prep (mode 0)
+    const vu4 *wfrag[2][CH_MAXL];  // prepared by k_x2_prep (mode 2: forward fragments, unscaled residuals)
     int nl, B, Hi, Wi, parts, rows_out, relu_last, dual, n_items;
     uint32_t magic_w[CH_MAXL];    // floor(2^32 / width of layer j's output) + 1
     uint32_t magic_parts;         // floor(2^32 / parts) + 1 (parts == 1 is tested for)
-    const uint32_t *amax_in;      // max |in| (float bits); dual: [0] images [0, B/2), [1] images [B/2, B)
+    const uint32_t *amax_in;      // max |in| (float bits), used by one-layer chains only; dual: [0] images [0, B/2), [1] images [B/2, B)
     uint32_t *amax_out;           // max |out| is atomically max-ed into it (zeroed by the caller), or null; dual: [0], [1]
 };
 
@@ -55,9 +59,6 @@ struct ChainArgs {
 // round barriers, [2] epilogues, [3] layer hand-over (barrier + next layer's set-up), [4] item switch (F .. A), [5] rounds,
 // [6] whole kernel, [7] 100 MHz ticks of the whole kernel
 __device__ unsigned long long g_chain_clk[8];
-#define CH_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
-#else
-#define CH_STAMP(var)
 #endif
 
 struct ChainItem {
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(512, 2) void k_conv32_chain(ChainArgs a)
         const unsigned cs4 = (unsigned)(a.Hi * Wi) * 4u; // bytes per channel plane
         const unsigned lane_c = (unsigned)cg * 8u * cs4;
         const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.in), 0, -1, 0x00020000);
-        vu4 d[CH_NU][8]; // the next item: raw f32 (8 channels x 4 pixels per unit), then in place its f16 (hi | lo') pairs
+        vu4 d[CH_NU][8]; // the next item: raw f32 (8 channels x 4 pixels per unit), then in place its f16 (hi | lo) pairs
         int npx = 0;     // pixels of the staged item
         auto issue = [&](int item) {
             const ChainItem it = chain_item(a, item);
@@ -215,10 +216,10 @@ __global__ __launch_bounds__(512, 2) void k_conv32_chain(ChainArgs a)
 
     // ---- compute waves.  Operand i = (tap t = i / 2, channel half s = i & 1); A fragment: W[row l31][k = 16 s + 8 h + j][t], hi and
     // (unscaled) lo parts in registers for one layer; the next layer's are requested as soon as the layer's last matrix instruction is out.
-    // All three products of a group (wl xh, wh xl, wh xh) go into ONE accumulator -- the residuals are unscaled here, unlike
+    // All three products of a group (wl xh, wh xl, wh xh) go into ONE sum -- the residuals are unscaled here, unlike
     // encoder_x2.hip's, because a chain's scales are per work item (no outlier image can push another one's values down f16's
-    // range) -- which leaves room for a SECOND accumulator set: a tile's epilogue (un-scale, ReLU, maximum, split, in-place store)
-    // is spread over the gaps of the NEXT tile's 54 matrix instructions, where a lone wave's vector instructions are free.
+    // range) -- which leaves room to keep the PREVIOUS tile's raw results: a tile's epilogue (un-scale, ReLU, maximum, split,
+    // in-place store) is spread over the gaps of the NEXT tile's 54 matrix instructions.
     f16x8 wh[18], wl[18];
     auto load_weights = [&](const vu4 *wf) {
 #pragma unroll
@@ -315,10 +316,10 @@ __global__ __launch_bounds__(512, 2) void k_conv32_chain(ChainArgs a)
             unsigned pboff = kNoStore;
             bool pending = false;
             // The previous tile's epilogue as a SOFTWARE PIPELINE over the 54 gaps between the current tile's matrix instructions
-            // (slot g = 3 i + {0, 1, 2} behind the three instructions of operand group i): a lone wave's vector instruction is free
-            // in a gap only while it does not wait for the one just before it (a dependent instruction issues ~7 cycles later, an
-            // independent one 4: three dependent ones plus the group's LDS read overran the 32-cycle gap -- +400 cycles per tile in
-            // the first version).  So every slot holds instructions whose inputs are at least one slot old:
+            // (slot g = 3 i + {0, 1, 2} behind the three instructions of operand group i); every slot holds instructions whose inputs
+            // are at least one slot old, so none waits for the one just before it.  (Measured: the loop costs ~2350 cycles with the
+            // epilogue in its gaps against ~1930 bare + 1070 for the epilogue behind it; dependent or independent slices, one or two
+            // accumulation chains made no difference to the 2350 -- DESIGN.md 4d.)
             //   3q      s_q = prev_q 2^kk                      (v_ldexp_f32: the un-scale and the next layer's scale in one, any kk)
             //   3q + 1  t_q = max(s_q, 0 | -inf)               (ReLU as an integer maximum)           [chain's last layer: 3q + 2 store]
             //   3q + 2  (q odd)  hi = f16x2(t_{q-1}, t_q),  vmax = max(vmax, t_{q-1}, t_q)
