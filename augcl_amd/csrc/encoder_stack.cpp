@@ -430,8 +430,18 @@ int augcl_enc_stack_infer(const float *x, const float *const *wA, const float *c
                       "%s: scratch smaller than augcl_enc_stack_infer_scratch_bytes", name);
         const size_t half = augcl_enc_stack_infer_scratch_bytes(n_layers, Bt, C, H, W, first_stride) / 2;
         void *buf[2] = {scratch, reinterpret_cast<char *>(scratch) + half};
-        int rc = augcl_internal_bf16_prep_weights(wA + 1, n_layers - 1, frag_ws, (int)block, stream);
-        if (rc == AUGCL_OK && wB) rc = augcl_internal_bf16_prep_weights(wB + 1, n_layers - 1, (char *)frag_ws + setB, (int)block, stream);
+        int rc;
+        if (wB && 2 * (n_layers - 1) <= 32) { // both sets in ONE launch: set B's blocks follow set A's in frag_ws
+            const float *wl[32];
+            for (int i = 1; i < n_layers; ++i) {
+                wl[i - 1] = wA[i];
+                wl[n_layers - 1 + i - 1] = wB[i];
+            }
+            rc = augcl_internal_bf16_prep_weights(wl, 2 * (n_layers - 1), frag_ws, (int)block, stream);
+        } else {
+            rc = augcl_internal_bf16_prep_weights(wA + 1, n_layers - 1, frag_ws, (int)block, stream);
+            if (rc == AUGCL_OK && wB) rc = augcl_internal_bf16_prep_weights(wB + 1, n_layers - 1, (char *)frag_ws + setB, (int)block, stream);
+        }
         if (rc != AUGCL_OK) return rc;
         rc = augcl::conv_first9_try(x, wA[0], bA[0], buf[0], Bt, C, H, W, first_stride, scale, 1, true, (hipStream_t)stream, name,
                                     wB ? wB[0] : nullptr, wB ? bB[0] : nullptr);
@@ -481,11 +491,21 @@ int augcl_enc_stack_infer(const float *x, const float *const *wA, const float *c
     // fragments of both sets (the first launch also zeroes the maxima: amax[2 c + set] = max |input of chain c| of that half)
     const size_t block = augcl_enc_frag_workspace_bytes(1, 1), setB = (size_t)(n_layers - 1) * block;
     if (n_layers >= 2) {
-        x3_prepare(wA, n_layers, 2, (char *)frag_ws, frag_ws_bytes, 0, stream, &rc, true, amax, 2 * (n_layers + 1));
-        if (rc != AUGCL_OK) return rc;
-        if (wB) {
-            x3_prepare(wB, n_layers, 2, (char *)frag_ws, frag_ws_bytes, setB, stream, &rc, true);
+        if (wB && 2 * (n_layers - 1) <= 32) { // both sets in ONE launch: set B's blocks follow set A's in frag_ws
+            const float *wl[32];
+            for (int i = 1; i < n_layers; ++i) {
+                wl[i - 1] = wA[i];
+                wl[n_layers - 1 + i - 1] = wB[i];
+            }
+            rc = augcl_internal_x2_prep_weights(wl, 2 * (n_layers - 1), 2, frag_ws, amax, 2 * (n_layers + 1), stream);
             if (rc != AUGCL_OK) return rc;
+        } else {
+            x3_prepare(wA, n_layers, 2, (char *)frag_ws, frag_ws_bytes, 0, stream, &rc, true, amax, 2 * (n_layers + 1));
+            if (rc != AUGCL_OK) return rc;
+            if (wB) {
+                x3_prepare(wB, n_layers, 2, (char *)frag_ws, frag_ws_bytes, setB, stream, &rc, true);
+                if (rc != AUGCL_OK) return rc;
+            }
         }
     }
     // first layer (f32 MFMA, stride 2, x / scale fused): leaves max |a_0| per half

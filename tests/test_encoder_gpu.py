@@ -65,8 +65,12 @@ def test_no_grad_path_and_determinism(cuda):
     bs = [st[f"encoder.shared_cnn.layers.{i}.bias"].to(cuda).requires_grad_(True) for i in ids]
     with torch.no_grad():
         a = encoder_ops.conv_stack(x, ws, bs)
+        a2 = encoder_ops.conv_stack(x, ws, bs)
     b = encoder_ops.conv_stack(x, ws, bs)
-    assert torch.equal(a, b)
+    # under no_grad the 32 -> 32 layers run as LDS-resident chains (per-item scales, csrc/encoder_chain.hip), with gradients as
+    # the per-layer f16-pair kernels (per-tensor scales): the same float32-accurate products, equal to float32 rounding
+    assert torch.equal(a, a2) and torch.equal(b, encoder_ops.conv_stack(x, ws, bs))
+    assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())
     b.square().sum().backward()
     g1 = [w.grad.clone() for w in ws]
     for w in ws:
