@@ -310,6 +310,9 @@ __global__ __launch_bounds__(512, 2) void k_conv32_x2(ConvX2Args a)
         };
         auto rd1 = [&](int off_, int i, Ops &o, int part) { // one of the operand's two reads: row base + immediate
             const int t = i >> 1;
+#ifdef AUGCL_TUNING
+            if ((a.abl & 32) && (t % 3) != 0) return; // ablation: only the kx = 0 taps' operand reads (a third of the LDS read bytes)
+#endif
             const char *p = tile + off_ + (t / 3) * rowb + ((t % 3) * X2_SLOT + (i & 1) * 32);
             if (part == 0) o.xh = *reinterpret_cast<const vu4 *>(p);
             else o.xl = *reinterpret_cast<const vu4 *>(p + 64);
