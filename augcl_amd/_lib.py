@@ -131,6 +131,8 @@ _SIGS = {
     "augcl_enc_stack_forward_dual": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P, _SZ, _P, _P],
     "augcl_enc_stack_infer_scratch_bytes": [_I, _I, _I, _I, _I, _I],
     "augcl_enc_stack_infer": [_P, _P, _P, _P, _P, _P, _P, _SZ, _I, _I, _I, _I, _I, _I, _F, _I, _P, _SZ, _P, _P],
+    "augcl_enc_stack_infer_u8": [_P, _P, _P, _P, _P, _P, _P, _SZ, _I, _I, _I, _I, _I, _I, _F, _I, _P, _SZ, _P, _P],
+    "augcl_enc_conv_first_forward_u8": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
     "augcl_replay_gather": [_P, _P, _P, _I, _I, _I, _I, _P],
     "augcl_enc_conv_first_forward": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
     "augcl_enc_conv32_forward": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
@@ -166,8 +168,8 @@ def load():
         fn.argtypes = argtypes
         fn.restype = _RESTYPE.get(name, _I)
     ver = lib.augcl_abi_version()
-    if ver != 4:
-        raise AugclError(f"libaugcl_hip.so ABI version {ver} != 4 (stale build: run `make -C augcl_amd/csrc`)")
+    if ver != 5:
+        raise AugclError(f"libaugcl_hip.so ABI version {ver} != 5 (stale build: run `make -C augcl_amd/csrc`)")
     _lib = lib
     return lib
 

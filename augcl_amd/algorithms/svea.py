@@ -9,9 +9,9 @@ from .rad import RAD
 
 
 def _accepts(fn, name):
-    key = getattr(fn, "__func__", fn)
+    key = (getattr(fn, "__func__", fn), name)
     hit = _accepts.cache.get(key)
-    if hit is None or hit[0] != name:
+    if hit is None:
         try:
             params = inspect.signature(fn).parameters
             ok = name in params or any(p.kind is inspect.Parameter.VAR_KEYWORD for p in params.values())
@@ -71,17 +71,34 @@ class SVEA(RAD):
         hw = (getattr(replay_buffer, "h", None), getattr(replay_buffer, "w", None))
         if fused is None or not self._fused_front_end(None, hw=hw):
             return replay_buffer.sample()
+        # next_obs is never augmented here (svea.py:66-68): it can stay uint8 all the way into the target pass's first conv layer
+        u8 = torch.uint8 if (self._u8_next_obs() and hw == (84, 84) and _accepts(fused, "next_dtype")) else None
         static = self._graph["static"] if self._graph is not None and self._graph["seen"] >= self._graph["warmup"] else None
         if static is not None and static[0].shape[0] != 2 * replay_buffer.batch_size:
             static = None  # another batch size: the graphs are about to be re-captured
+        if static is not None and (static[3].dtype == torch.uint8) != (u8 is not None):
+            static = None  # the switch was flipped after the capture: hand over fresh tensors, _graph_update copies them in
         if static is None:
-            return fused()
+            return fused(next_dtype=u8) if u8 is not None else fused()
         # the graph's static obs_both / next_obs tensors are written in place: nothing to copy before the replay.  Whether
         # the buffer's sample_shift_conv takes out_next is read off its signature ONCE -- catching TypeError around the
         # call would also swallow one raised inside it, after the index draw had advanced the RNG streams
         if _accepts(fused, "out_next"):
             return fused(out=static[0], out_next=static[3])
         return fused(out=static[0])
+
+    def _u8_next_obs(self):
+        """uint8 next_obs from the replay ring straight into the target pass (precision "f32", no head conv layers: the no-grad
+        stack's first layer reads uint8 observations, ABI v5).  `u8_next_obs = False` on the agent switches it off."""
+        from .. import encoder_hip, encoder_ops
+        cnn = self.critic_target.encoder.shared_cnn
+        key = (cnn.precision, encoder_ops.PRECISION, encoder_hip._U8_FIRST, getattr(self, "u8_next_obs", True))
+        hit = self.__dict__.get("_u8_next_hit")
+        if hit is None or hit[0] != key:  # (asked once per update(): the answer only moves with the four switches above)
+            heads = len(list(self.critic_target.encoder.head_cnn.parameters())) + len(list(self.actor.encoder.head_cnn.parameters()))
+            ok = bool(key[3]) and key[2] and (key[0] or key[1]) == "f32" and heads == 0 and cnn.num_layers >= 2
+            self._u8_next_hit = hit = (key, ok)
+        return hit[1]
 
     def _front_end(self, obs, action, reward, next_obs, not_done, out=None):
         """svea.py:66-68.  Returns (obs_both | obs, action, reward, next_obs, not_done): with the fused front end

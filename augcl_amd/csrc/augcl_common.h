@@ -73,6 +73,13 @@ int conv_first9_try(const float *in, const float *w, const float *bias, void *ou
                     float scale, int relu, bool out_bf16, hipStream_t s, const char *name, const float *w2 = nullptr,
                     const float *bias2 = nullptr, float *amax_out = nullptr, void *gate_bits_out = nullptr);
 
+// the same layer fed with uint8 observations (encoder_first_u8.hip; 9 x 84 x 84, stride 2, f32 NCHW output only): AUGCL_OK /
+// negative error after launching, +1 if the shape is not covered.  w2 != null: both weight sets over the SAME B inputs, out =
+// (2B,...) with images [0,B) from set 1 and [B,2B) from set 2; amax_out: one float per set
+int conv_first9_u8_try(const uint8_t *in, const float *w, const float *bias, float *out, int B, int C, int Hi, int Wi, int stride,
+                       float scale, int relu, hipStream_t s, const char *name, const float *w2 = nullptr, const float *bias2 = nullptr,
+                       float *amax_out = nullptr, void *gate_bits_out = nullptr);
+
 #define AUGCL_REQUIRE(cond, ...)                                 \
     do {                                                         \
         if (!(cond)) return augcl::fail(AUGCL_E_INVALID, __VA_ARGS__); \

@@ -405,14 +405,15 @@ size_t augcl_enc_stack_infer_scratch_bytes(int n_layers, int B_total, int C, int
 // x (B,C,H,W) raw f32; out ((wB ? 2 : 1) x B, 32, h, w) f32 NCHW: rows [0,B) from weight set A, [B,2B) from set B over the SAME
 // input.  amax: 2 x (n_layers + 1) floats of device scratch.  AUGCL_E_UNSUPPORTED: a shape the chains (or, with two weight
 // sets, the pipelined first-layer kernel) do not cover -- the caller runs augcl_enc_stack_forward[_dual].
-int augcl_enc_stack_infer(const float *x, const float *const *wA, const float *const *bA, const float *const *wB,
-                          const float *const *bB, float *out, void *scratch, size_t scratch_bytes, int n_layers, int B, int C,
-                          int H, int W, int first_stride, float scale, int precision, void *frag_ws, size_t frag_ws_bytes,
-                          float *amax, augcl_stream_t stream)
+static int stack_infer_impl(const char *name, const float *x, const uint8_t *x8, const float *const *wA, const float *const *bA,
+                            const float *const *wB, const float *const *bB, float *out, void *scratch, size_t scratch_bytes,
+                            int n_layers, int B, int C, int H, int W, int first_stride, float scale, int precision, void *frag_ws,
+                            size_t frag_ws_bytes, float *amax, augcl_stream_t stream)
 {
-    const char *name = "augcl_enc_stack_infer";
-    AUGCL_REQUIRE(x && wA && bA && out && n_layers >= 1 && B >= 1, "%s: bad argument", name);
+    AUGCL_REQUIRE((x || x8) && wA && bA && out && n_layers >= 1 && B >= 1, "%s: bad argument", name);
     AUGCL_REQUIRE(precision == 3 || precision == 1, "%s: precision must be 3 (f16 pairs) or 1 (bf16 mode)", name);
+    if (x8 && (precision != 3 || n_layers < 2))
+        return augcl::fail(AUGCL_E_UNSUPPORTED, "%s: uint8 observations are built for precision 3 stacks of >= 2 layers", name);
     if (precision == 1) {
         // ---- bf16 performance mode: first layer (bf16 NHWC out), one fragment launch per weight set, the 32 -> 32 layers as chains
         AUGCL_REQUIRE((wB == nullptr) == (bB == nullptr), "%s: weight set B needs both arrays", name);
@@ -511,8 +512,13 @@ int augcl_enc_stack_infer(const float *x, const float *const *wA, const float *c
     // first layer (f32 MFMA, stride 2, x / scale fused): leaves max |a_0| per half
     float *a0 = n_layers >= 2 ? buf[0] : out;
     const int relu0 = n_layers >= 2;
-    rc = augcl::conv_first9_try(x, wA[0], bA[0], a0, Bt, C, H, W, first_stride, scale, relu0, false, (hipStream_t)stream, name,
-                                wB ? wB[0] : nullptr, wB ? bB[0] : nullptr, n_layers >= 2 ? amax : nullptr);
+    if (x8) { // uint8 observations: a quarter of the input bytes, exact bf16 operands (encoder_first_u8.hip)
+        rc = augcl::conv_first9_u8_try(x8, wA[0], bA[0], a0, B, C, H, W, first_stride, scale, relu0, (hipStream_t)stream, name,
+                                       wB ? wB[0] : nullptr, wB ? bB[0] : nullptr, amax);
+        if (rc > 0) return augcl::fail(AUGCL_E_UNSUPPORTED, "%s: uint8 first layer covers (9,84,84) stride 2, got (%d,%d,%d) stride %d", name, C, H, W, first_stride);
+    } else
+        rc = augcl::conv_first9_try(x, wA[0], bA[0], a0, Bt, C, H, W, first_stride, scale, relu0, false, (hipStream_t)stream, name,
+                                    wB ? wB[0] : nullptr, wB ? bB[0] : nullptr, n_layers >= 2 ? amax : nullptr);
     if (rc > 0) {
         if (wB) return augcl::fail(AUGCL_E_UNSUPPORTED, "%s: first-layer shape (%d,%d,%d) stride %d not covered", name, C, H, W, first_stride);
         rc = augcl_enc_conv_first_forward(x, wA[0], bA[0], a0, B, C, H, W, first_stride, scale, relu0, stream);
@@ -540,6 +546,26 @@ int augcl_enc_stack_infer(const float *x, const float *const *wA, const float *c
         cur ^= 1;
     }
     return AUGCL_OK;
+}
+
+int augcl_enc_stack_infer(const float *x, const float *const *wA, const float *const *bA, const float *const *wB,
+                          const float *const *bB, float *out, void *scratch, size_t scratch_bytes, int n_layers, int B, int C,
+                          int H, int W, int first_stride, float scale, int precision, void *frag_ws, size_t frag_ws_bytes,
+                          float *amax, augcl_stream_t stream)
+{
+    AUGCL_REQUIRE(x != nullptr, "augcl_enc_stack_infer: bad argument");
+    return stack_infer_impl("augcl_enc_stack_infer", x, nullptr, wA, bA, wB, bB, out, scratch, scratch_bytes, n_layers, B, C, H, W,
+                            first_stride, scale, precision, frag_ws, frag_ws_bytes, amax, stream);
+}
+
+int augcl_enc_stack_infer_u8(const uint8_t *x, const float *const *wA, const float *const *bA, const float *const *wB,
+                             const float *const *bB, float *out, void *scratch, size_t scratch_bytes, int n_layers, int B, int C,
+                             int H, int W, int first_stride, float scale, int precision, void *frag_ws, size_t frag_ws_bytes,
+                             float *amax, augcl_stream_t stream)
+{
+    AUGCL_REQUIRE(x != nullptr, "augcl_enc_stack_infer_u8: bad argument");
+    return stack_infer_impl("augcl_enc_stack_infer_u8", nullptr, x, wA, bA, wB, bB, out, scratch, scratch_bytes, n_layers, B, C, H, W,
+                            first_stride, scale, precision, frag_ws, frag_ws_bytes, amax, stream);
 }
 
 // acts_in[i] = input of layer i (acts_in[0] = x raw f32; i >= 1: post-ReLU activation, f32 NCHW or bf16 NHWC);

@@ -154,6 +154,7 @@ def _ptr_array(ptrs):
 
 
 _CHAINS_BWD = True  # (A/B switch) bf16 mode: backward-data of the whole stack as one chain launch
+_U8_FIRST = True  # (A/B switch) uint8 observations go into the first layer as they are (no-grad passes of precision "f32")
 _CHAINS = True  # (A/B switch) no-grad passes of precision "f32" through augcl_enc_stack_infer: LDS-resident layer chains
 _infer_ws = {}
 
@@ -179,9 +180,12 @@ def conv_stack_infer(x, weights_a, biases_a, weights_b, biases_b, first_stride, 
     rows [0,B) from set A, [B,2B) from set B -- or None when the shape is not covered."""
     n_layers = len(weights_a)
     B, C, H, W = x.shape
-    if not _CHAINS or not x.is_contiguous() or x.dtype != torch.float32 or 2 * (n_layers + 1) > 2 * _AMAX:
+    u8 = x.dtype == torch.uint8  # observations as the replay ring stores them: the first layer reads them as they are (ABI v5)
+    if not _CHAINS or not x.is_contiguous() or not (u8 or x.dtype == torch.float32) or 2 * (n_layers + 1) > 2 * _AMAX:
         return None
     if precision not in ("f32", "bf16") or (precision == "bf16" and n_layers < 2):
+        return None
+    if u8 and (not _U8_FIRST or precision != "f32" or n_layers < 2 or (C, H, W) != (9, 84, 84) or first_stride != 2 or x.data_ptr() % 8):
         return None
     dev = x.device
     sets = 1 if weights_b is None else 2
@@ -193,7 +197,8 @@ def conv_stack_infer(x, weights_a, biases_a, weights_b, biases_b, first_stride, 
     ws, need = _infer_scratch(dev, n_layers, sets * B, C, H, W, first_stride)
     fws = _frag_ws(dev, max(n_layers - 1, 1), sets)
     d = lambda ts: _ptr_array([t.detach().data_ptr() for t in ts])  # noqa: E731
-    rc = _lib.load().augcl_enc_stack_infer(
+    entry = _lib.load().augcl_enc_stack_infer_u8 if u8 else _lib.load().augcl_enc_stack_infer
+    rc = entry(
         x.data_ptr(), d(weights_a), d(biases_a), d(weights_b) if sets == 2 else None, d(biases_b) if sets == 2 else None,
         out.data_ptr(), ws.data_ptr(), need, n_layers, B, C, H, W, first_stride, input_scale, PRECISION_CODE[precision],
         fws.data_ptr(), fws.numel(), ws.data_ptr() + need, _lib.current_stream(dev))
@@ -215,6 +220,8 @@ def conv_stack_dual(x, weights_a, biases_a, weights_b, biases_b, first_stride, i
         out = conv_stack_infer(x, weights_a, biases_a, weights_b, biases_b, first_stride, input_scale, precision)
         if out is not None:
             return out
+    if x.dtype == torch.uint8:  # the per-layer kernels read float32 observations
+        x = x.to(torch.float32)
     dev = x.device
     bf16 = precision == "bf16"
     adt = torch.bfloat16 if bf16 else torch.float32

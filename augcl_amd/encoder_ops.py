@@ -36,8 +36,8 @@ def conv_stack_dual(x, weights_a, biases_a, weights_b, biases_b, first_stride=2,
     outputs, or None when the fused path does not cover the case (it needs a 9 x H x 84 input and stride 2)."""
     if not x.is_cuda or len(weights_a) != len(weights_b) or len(weights_a) < 2:
         return None
-    if any(a.shape != b.shape for a, b in zip(weights_a, weights_b)) or x.dtype != torch.float32:
-        return None
+    if any(a.shape != b.shape for a, b in zip(weights_a, weights_b)) or x.dtype not in (torch.float32, torch.uint8):
+        return None  # (uint8: observations as the replay ring stores them -- the first layer reads them as they are)
     from . import encoder_hip
     out = encoder_hip.conv_stack_dual(x, weights_a, biases_a, weights_b, biases_b, first_stride, float(input_scale),
                                       _check(precision or PRECISION))
@@ -48,11 +48,19 @@ def conv_stack_dual(x, weights_a, biases_a, weights_b, biases_b, first_stride=2,
 
 
 def conv_stack(x, weights, biases, first_stride=2, input_scale=255.0, relu_first=False, precision=None):
-    """x: (B,C,H,W) f32 (0..255 when input_scale=255).  Returns the last conv's output (no final ReLU).
-    precision: None = the process default (`set_precision`)."""
+    """x: (B,C,H,W) f32 (0..255 when input_scale=255), or uint8 observations as the replay ring stores them (no-grad passes of
+    precision "f32" feed them to the first layer as they are; every other case converts first).  Returns the last conv's output
+    (no final ReLU).  precision: None = the process default (`set_precision`)."""
     _lib.require_cuda(x, "conv_stack input")
     from . import encoder_hip
     prec = _check(precision or PRECISION)
+    if x.dtype == torch.uint8:
+        if not relu_first and not torch.is_grad_enabled() and prec == "f32":
+            out = encoder_hip.conv_stack_infer(x, [w.detach() for w in weights], [b.detach() for b in biases], None, None,
+                                               first_stride, float(input_scale), prec)
+            if out is not None:
+                return out
+        x = x.to(torch.float32)
     if relu_first:  # HeadCNN stacks (num_head_layers > 0): per-layer path, f32
         return encoder_hip.ConvStackLayerwiseFn.apply(x, first_stride, float(input_scale), True, len(weights),
                                                       "f32_mfma" if prec == "f32_mfma" else "f32_x3", *weights, *biases)

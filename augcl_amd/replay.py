@@ -226,13 +226,17 @@ class ReplayBuffer(object):
                   1 if dtype == torch.float32 else 0, _lib.current_stream(self.device))
         return (obs, sc[:B * A].view(B, A), sc[B * A:B * A + B].view(B, 1), next_obs, sc[B * A + B:].view(B, 1))
 
-    def sample_shift_conv(self, n=None, idxs=None, pad=4, *, oy=None, ox=None, weights=None, out=None, out_next=None):
+    def sample_shift_conv(self, n=None, idxs=None, pad=4, *, oy=None, ox=None, weights=None, out=None, out_next=None,
+                          next_dtype=torch.float32):
         """sample() + SVEA's front end (src/algorithms/svea.py:66-68 and :49) in one pass over the uint8 ring: returns
         (obs_both, actions, rewards, next_obs, not_dones) where obs_both is the (2B, C, H, W) stack
         [random_shift(obs); random_conv(random_shift(obs))] -- the sampled obs batch itself is never materialised
         (63.5 KB read per observation instead of 63.5 KB read + 254 KB written + 254 KB read again).  Bit-identical to
         `sample()` followed by `augmentations.shift_conv(obs, stacked=True)` with the same parameters / Philox call.
-        out / out_next: write obs_both / next_obs into these tensors (a hipGraph's static inputs: no copy afterwards)."""
+        out / out_next: write obs_both / next_obs into these tensors (a hipGraph's static inputs: no copy afterwards).
+        next_dtype = torch.uint8: next_obs stays in the ring's own format (it is never augmented on this path, svea.py:66-68, so
+        its pixels are integers): a quarter of the bytes written here and read by the encoder's first layer, which takes uint8
+        observations as they are (csrc/encoder_first_u8.hip)."""
         from . import augmentations
         if idxs is None and self.index_stream == "device":
             it = self._device_idxs(n)
@@ -252,11 +256,15 @@ class ReplayBuffer(object):
         _lib.call("augcl_replay_shift_conv_u8_f32", self.frames.data_ptr(), self.slot_tab.data_ptr(), it.data_ptr(),
                   2 * self.stack, both[:B].data_ptr(), both[B:].data_ptr(), B, self.stack, self.h, self.w, int(pad),
                   _lib.ptr(oy), _lib.ptr(ox), _lib.ptr(weights), seed, off, s0, st)
-        next_obs = out_next if out_next is not None else torch.empty((B, C, self.h, self.w), dtype=torch.float32, device=self.device)
-        assert next_obs.shape == (B, C, self.h, self.w) and next_obs.dtype == torch.float32 and next_obs.is_contiguous()
+        if out_next is not None:
+            next_dtype = out_next.dtype
+        assert next_dtype in (torch.float32, torch.uint8)
+        next_obs = out_next if out_next is not None else torch.empty((B, C, self.h, self.w), dtype=next_dtype, device=self.device)
+        assert next_obs.shape == (B, C, self.h, self.w) and next_obs.is_contiguous()
         sc = torch.empty(B * (A + 2), dtype=torch.float32, device=self.device)
         _lib.call("augcl_replay_sample", self.frames.data_ptr(), self.slot_tab.data_ptr(), self.scal.data_ptr(), it.data_ptr(),
-                  None, next_obs.data_ptr(), sc.data_ptr(), B, self.stack, self.frame_bytes, A + 2, 1, st)
+                  None, next_obs.data_ptr(), sc.data_ptr(), B, self.stack, self.frame_bytes, A + 2,
+                  1 if next_dtype == torch.float32 else 0, st)
         return (both, sc[:B * A].view(B, A), sc[B * A:B * A + B].view(B, 1), next_obs, sc[B * A + B:].view(B, 1))
 
     def sample_obs(self, n=None):

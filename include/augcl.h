@@ -36,8 +36,9 @@
 extern "C" {
 #endif
 
-#define AUGCL_ABI_VERSION 4 /* 2: the whole-stack entry points take a weight-fragment workspace; 3: ... and the per-tensor maxima of precision 3;
-                             * 4: augcl_enc_stack_infer (no-grad forward with LDS-resident layer chains) */
+#define AUGCL_ABI_VERSION 5 /* 2: the whole-stack entry points take a weight-fragment workspace; 3: ... and the per-tensor maxima of precision 3;
+                             * 4: augcl_enc_stack_infer (no-grad forward with LDS-resident layer chains); 5: uint8 observations into the first layer
+                             * (augcl_enc_stack_infer_u8, augcl_enc_conv_first_forward_u8) */
 
 #define AUGCL_OK 0
 #define AUGCL_E_INVALID (-1)   /* bad argument (null pointer, bad shape, misalignment) */
@@ -425,6 +426,18 @@ int augcl_enc_stack_forward_dual(const float *x, const float *const *wA, const f
  * AUGCL_E_UNSUPPORTED: a shape the chains (or, with two weight sets, the pipelined first-layer kernel) do not cover -- run
  * augcl_enc_stack_forward / augcl_enc_stack_forward_dual instead. */
 size_t augcl_enc_stack_infer_scratch_bytes(int n_layers, int B_total, int C, int H, int W, int first_stride);
+/* first layer alone from uint8 observations (see augcl_enc_stack_infer_u8): out (B,32,41,41) f32 NCHW */
+int augcl_enc_conv_first_forward_u8(const uint8_t *in /* (B,9,84,84) */, const float *w /* (32,9,3,3) */, const float *bias,
+                                    float *out, int B, int C, int Hi, int Wi, int stride, float scale, int relu,
+                                    augcl_stream_t stream);
+/* ..._u8: the same with UINT8 observations (the replay ring's own format, src/utils.py:206-214, wherever the pixels are still
+ * integers: next_obs of every algorithm, shifted-only observations): the first layer reads a quarter of the bytes and multiplies
+ * exact bf16 pixel operands with three-piece bf16 weights (csrc/encoder_first_u8.hip; conv(x) accumulated exactly in float32,
+ * times 1 / scale, plus bias).  precision 3, n_layers >= 2, x (B,9,84,84), first_stride 2; anything else: AUGCL_E_UNSUPPORTED. */
+int augcl_enc_stack_infer_u8(const uint8_t *x, const float *const *wA, const float *const *bA, const float *const *wB,
+                             const float *const *bB, float *out, void *scratch, size_t scratch_bytes, int n_layers, int B, int C,
+                             int H, int W, int first_stride, float scale, int precision, void *frag_ws, size_t frag_ws_bytes,
+                             float *amax, augcl_stream_t stream);
 int augcl_enc_stack_infer(const float *x, const float *const *wA, const float *const *bA, const float *const *wB,
                           const float *const *bB, float *out, void *scratch, size_t scratch_bytes, int n_layers, int B, int C,
                           int H, int W, int first_stride, float scale, int precision, void *frag_ws, size_t frag_ws_bytes,

@@ -236,18 +236,23 @@ def test_fused_sample_shift_conv_equals_sample_then_front_end(cuda):
     assert got[0].data_ptr() == o1.data_ptr() and got[3].data_ptr() == o2.data_ptr()
     assert torch.equal(o1, ref[0]) and torch.equal(o2, ref[3])
     # SVEA through the fused path walks the same trajectory as through sample() + its own front end
+    # (bit for bit with float32 next_obs; with next_obs kept uint8 into the target pass -- the default on the ring, ABI v5 -- the
+    # first layer's products are accumulated in another order: float32 rounding)
     snaps = []
-    for fused in (True, False):
+    for fused, u8 in ((True, False), (False, False), (True, True)):
         torch.manual_seed(3)
         aug.manual_seed(9)
         np.random.seed(9)
         agent = make_agent((9, 84, 84), (A,), au.dotdict(algorithm="svea", data_aug="conv", aug_params=None, **so.DEFAULTS))
+        agent.u8_next_obs = u8
         buf = rb if fused else type("Plain", (), {"sample": lambda self, n=None: rb.sample(), "batch_size": B})()
         for step in range(3):
             agent.update(buf, None, step)
         torch.cuda.synchronize()
         snaps.append((agent.critic_group.param.clone(), agent.actor_group.param.clone()))
     assert torch.equal(snaps[0][0], snaps[1][0]) and torch.equal(snaps[0][1], snaps[1][1])
+    for x, y in zip(snaps[0], snaps[2]):
+        assert float((x.double() - y.double()).abs().max()) <= 1e-5 * max(1.0, float(x.abs().max()))
 
 
 @pytest.mark.gpu
@@ -281,6 +286,21 @@ def test_svea_hip_graph_update_on_the_device_ring_and_other_frame_sizes(cuda):
             assert len(agent._graph["graphs"]) >= 2 and agent._graph["static"][0].shape[0] == 2 * B
         snaps.append((agent.critic_group.param.clone(), agent.actor_group.param.clone(), agent.log_alpha.detach().clone()))
     for x, y in zip(*snaps):
+        assert float((x.double() - y.double()).abs().max()) <= 1e-5 * max(1.0, float(x.abs().max()))
+    # next_obs travelled as uint8 from the ring into the target pass's first conv layer (ABI v5); the same trajectory with float32
+    # next_obs (u8_next_obs = False: the round 1-4 path) agrees to float32 rounding
+    assert agent._graph["static"][3].dtype == torch.uint8 and agent._u8_next_obs()
+    torch.manual_seed(3)
+    aug.manual_seed(9)
+    np.random.seed(9)
+    agent32 = make_agent((9, 84, 84), (A,), au.dotdict(algorithm="svea", data_aug="conv", aug_params=None, **so.DEFAULTS))
+    agent32.u8_next_obs = False
+    agent32.enable_hip_graphs(warmup=2)
+    for step in range(8):
+        agent32.update(rb, None, step)
+    torch.cuda.synchronize()
+    assert agent32._graph["static"][3].dtype == torch.float32
+    for x, y in zip(snaps[1], (agent32.critic_group.param, agent32.actor_group.param, agent32.log_alpha.detach())):
         assert float((x.double() - y.double()).abs().max()) <= 1e-5 * max(1.0, float(x.abs().max()))
     # another geometry: the gate looks at the ring's own frame size
     odd = ReplayBuffer((9, 64, 64), (A,), capacity=32, batch_size=4, device=cuda)
