@@ -73,6 +73,11 @@ int conv_first9_try(const float *in, const float *w, const float *bias, void *ou
                     float scale, int relu, bool out_bf16, hipStream_t s, const char *name, const float *w2 = nullptr,
                     const float *bias2 = nullptr, float *amax_out = nullptr, void *gate_bits_out = nullptr);
 
+// ... and the float32-input, float32-output case on the bf16 matrix pipe (encoder_first_x3.hip: three exact bf16 pieces per operand,
+// six piece products; 9 x 84 x 84, stride 2): what conv_first9_try launches for that case; same return convention
+int conv_first9_x3_try(const float *in, const float *w, const float *bias, float *out, int B, int C, int Hi, int Wi, int stride,
+                       float scale, int relu, hipStream_t s, const char *name, const float *w2 = nullptr, const float *bias2 = nullptr,
+                       float *amax_out = nullptr, void *gate_bits_out = nullptr);
 // the same layer fed with uint8 observations (encoder_first_u8.hip; 9 x 84 x 84, stride 2, f32 NCHW output only): AUGCL_OK /
 // negative error after launching, +1 if the shape is not covered.  w2 != null: both weight sets over the SAME B inputs, out =
 // (2B,...) with images [0,B) from set 1 and [B,2B) from set 2; amax_out: one float per set

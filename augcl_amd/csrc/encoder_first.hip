@@ -409,6 +409,11 @@ int conv_first9_try(const float *in, const float *w, const float *bias, void *ou
 {
     if (C != 9 || Wi != 84 || stride != 2 || Hi < 3) return 1;
     if (w2 != nullptr && (B & 1)) return 1;
+    if (!out_bf16) { // float32 activations: the three-piece bf16 kernel (encoder_first_x3.hip) where it covers the shape
+        const int rc = conv_first9_x3_try(in, w, bias, static_cast<float *>(out), B, C, Hi, Wi, stride, scale, relu, s, name, w2, bias2,
+                                          amax_out, gate_bits_out);
+        if (rc <= 0) return rc;
+    }
     if ((size_t)B * 32 * ((Hi - 3) / 2 + 1) * ((Wi - 3) / 2 + 1) >= ((size_t)1 << 30)) return 1; // 32-bit byte offsets in the epilogue
     if ((reinterpret_cast<uintptr_t>(in) & 15u) != 0 || ((size_t)Hi * Wi) % 4 != 0) return 1;
     First9Args a{};

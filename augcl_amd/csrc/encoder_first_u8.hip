@@ -65,9 +65,14 @@ __global__ __launch_bounds__(512, 2) void k_conv_first9_u8(FirstU8Args a)
     auto prep = [&]() {
         // ---- weight fragments of both sets -> LDS: vector (piece p, chunk i, lane) = 8 bf16, k = 16 i + 8 h + j <-> pair P = 4 i + 2 h + (j >> 2),
         // kx = j & 3; the weight of (P = 3 c + ky, kx) is w[co][c][ky][kx]; pairs >= 27 and kx = 3 carry zero
+        // the weights: one coalesced copy into LDS (tile buffer 1 is first written behind the next barrier but one), fragments built
+        // from there (lanes = filters, stride 81 words: every bank once) instead of from scattered global loads
+        float *wraw = reinterpret_cast<float *>(tiles + U8_TILE);
+        for (int i = tid; i < (DUAL ? 2 : 1) * 32 * 81; i += 512) wraw[i] = i < 32 * 81 ? a.w[i] : a.w2[i - 32 * 81];
+        __syncthreads();
         for (int v = tid; v < (DUAL ? 2 : 1) * 3 * U8_NCH * 64; v += 512) {
             const int ln = v & 63, i = (v >> 6) % U8_NCH, p = ((v >> 6) / U8_NCH) % 3, set = v / (3 * U8_NCH * 64);
-            const float *wsrc = set ? a.w2 : a.w;
+            const float *wsrc = wraw + set * (32 * 81);
             const int co = ln & 31, hh = ln >> 5;
             bf16x8 f;
 #pragma unroll

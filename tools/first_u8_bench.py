@@ -36,6 +36,11 @@ for B in (256, 512):
     out = torch.empty((B, 32, 41, 41), device=dev)
     t8 = graph_time(lambda: _lib.call("augcl_enc_conv_first_forward_u8", P(x8.data_ptr()), P(w.data_ptr()), P(b.data_ptr()), P(out.data_ptr()), B, 9, 84, 84, 2, 255.0, 1, st()))
     tf = graph_time(lambda: _lib.call("augcl_enc_conv_first_forward", P(xf.data_ptr()), P(w.data_ptr()), P(b.data_ptr()), P(out.data_ptr()), B, 9, 84, 84, 2, 255.0, 1, st()))
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    raw.augcl_internal_first_layer_x3(0)  # the float32 matrix pipe (rounds 1-4) for comparison
+    t32 = graph_time(lambda: _lib.call("augcl_enc_conv_first_forward", P(xf.data_ptr()), P(w.data_ptr()), P(b.data_ptr()), P(out.data_ptr()), B, 9, 84, 84, 2, 255.0, 1, st()))
+    raw.augcl_internal_first_layer_x3(1)
+    print(f"first layer B={B}: f32 in, f32 MFMA pipe {t32:6.1f} us ({B * (63504 * 4 + 32 * 1681 * 4) / t32 / 1e6:5.2f} TB/s)", flush=True)
     by8, byf = B * (63504 + 32 * 1681 * 4), B * (63504 * 4 + 32 * 1681 * 4)
     print(f"first layer B={B}: f32 in {tf:6.1f} us ({byf / tf / 1e6:5.2f} TB/s)   uint8 in {t8:6.1f} us ({by8 / t8 / 1e6:5.2f} TB/s)", flush=True)
 ws = [w] + [torch.randn(32, 32, 3, 3, device=dev) * (2.0 / 288) ** 0.5 for _ in range(10)]
