@@ -124,6 +124,7 @@ _SIGS = {
     "augcl_enc_x2_conv32_backward_data": [_P, _P, _P, _P, _I, _I, _I, _P, _SZ, _P, _P, _P],
     "augcl_enc_x2_conv32_backward_weights": [_P, _P, _P, _P, _P, _SZ, _I, _I, _I, _P, _P, _P],
     "augcl_enc_stack_forward": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P, _SZ, _P, _P, _P],
+    "augcl_enc_stack_forward_chained": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P, _SZ, _P, _P, _P],
     "augcl_enc_frag_workspace_bytes": [_I, _I],
     "augcl_enc_stack_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P, _SZ, _I, _I, _I, _I, _I, _I, _F, _I, _I, _P, _SZ, _P, _P, _P, _P,
                                  _SZ, _P],
@@ -168,8 +169,8 @@ def load():
         fn.argtypes = argtypes
         fn.restype = _RESTYPE.get(name, _I)
     ver = lib.augcl_abi_version()
-    if ver != 5:
-        raise AugclError(f"libaugcl_hip.so ABI version {ver} != 5 (stale build: run `make -C augcl_amd/csrc`)")
+    if ver != 6:
+        raise AugclError(f"libaugcl_hip.so ABI version {ver} != 6 (stale build: run `make -C augcl_amd/csrc`)")
     _lib = lib
     return lib
 

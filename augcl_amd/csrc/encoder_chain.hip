@@ -52,6 +52,12 @@ struct ChainArgs {
     uint32_t magic_parts;         // floor(2^32 / parts) + 1 (parts == 1 is tested for)
     const uint32_t *amax_in;      // max |in| (float bits), used by one-layer chains only; dual: [0] images [0, B/2), [1] images [B/2, B)
     uint32_t *amax_out;           // max |out| is atomically max-ed into it (zeroed by the caller), or null; dual: [0], [1]
+    // KEEP (the gradient-carrying forward, src/algorithms/sac.py:103-116 -> modules.py:145-165 with autograd on): every layer's
+    // output is ALSO stored for the backward pass -- float32 NCHW, each row once (a part stores the rows it owns) -- together
+    // with its ReLU gate bits (one word per pixel, bit c = channel c > 0: encoder_x2.hip's format) and its tensor-wide maximum
+    float *acts[CH_MAXL];         // [j], j < nl - 1: (B,32,Hj,Wj) output of layer j (the last layer's is `out`)
+    uint32_t *bits[CH_MAXL];      // [j], j < nl: (B,Hj,Wj) gate words of layer j's output, or null
+    uint32_t *amax_acts[CH_MAXL]; // [j], j < nl - 1: max |output of layer j| (float bits) is atomically max-ed into it
 };
 
 #ifdef AUGCL_TUNING
@@ -83,6 +89,7 @@ __device__ __forceinline__ int chain_rounds(const ChainArgs &a, int j, int ny)
     return (((npix + 31) >> 5) + 3) >> 2;
 }
 
+template <bool KEEP>
 __global__ __launch_bounds__(512, 2) void k_conv32_chain(ChainArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char ldsc[];
@@ -252,6 +259,8 @@ __global__ __launch_bounds__(512, 2) void k_conv32_chain(ChainArgs a)
         load_weights(a.wfrag[g0][0]);
         load_consts(a.wfrag[g0][0], a.bias[g0][0]);
     }
+    uint32_t *lkeep = reinterpret_cast<uint32_t *>(ldsc + 1216); // KEEP: [j] = max |output of layer j| over this workgroup's items (true units)
+    if (KEEP && tid < CH_MAXL) lkeep[tid] = 0u;
     __syncthreads(); // P0
     __syncthreads(); // P1 (the loaders agree on the first item's maximum between the two)
     typedef uint32_t vu2 __attribute__((ext_vector_type(2)));
@@ -272,7 +281,6 @@ __global__ __launch_bounds__(512, 2) void k_conv32_chain(ChainArgs a)
             const int Wout = Wi - 2 * (j + 1), nrow = it.ny + 2 * (nl - 1 - j);
             const int npix = nrow * Wout, ntiles = (npix + 31) >> 5, rounds = (ntiles + 3) >> 2;
             const uint32_t magic = a.magic_w[j];
-            const vu4 *wf = a.wfrag[it.grp][j];
             // the layer's constants (weights' exponent, their largest row sum, the bias) were requested together with its weight
             // fragments, a layer ago: nothing global is waited for between two layers
             const int k_w = __builtin_amdgcn_readfirstlane((int)nx_kw);
@@ -290,6 +298,31 @@ __global__ __launch_bounds__(512, 2) void k_conv32_chain(ChainArgs a)
             const int j_next = !last ? j + 1 : (item + G < n ? 0 : j);
             const vu4 *wf_next = a.wfrag[grp_next][j_next];
             const float *b_next = a.bias[grp_next][j_next];
+            // KEEP: where this layer's output goes for the backward pass.  Rows [y0, y0 + ny) of every layer belong to this part,
+            // the rows behind them to the next one (the last part: all of them); a lane that owns no pixel names an offset beyond
+            // the buffer and its store is dropped.  The chain's last layer already stores float32 (`out`): only its gate words are new.
+            const int Hj = a.Hi - 2 * (j + 1), chwj = Hj * Wout;
+            float *keep = (KEEP && !last) ? a.acts[j] : nullptr;
+            uint32_t *kbits = KEEP ? a.bits[j] : nullptr;
+            const __amdgpu_buffer_rsrc_t rs_keep = __builtin_amdgcn_make_buffer_rsrc(
+                keep ? keep : a.out, 0, keep ? (int)((unsigned)(a.B * 32 * chwj) * 4u) : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs_bits = __builtin_amdgcn_make_buffer_rsrc(
+                kbits ? kbits : reinterpret_cast<uint32_t *>(a.out), 0, kbits ? (int)((unsigned)(a.B * chwj) * 4u) : 0, 0x00020000);
+            const bool last_part = it.y0 + it.ny >= Hf;
+            unsigned pkoff = kNoStore, pgoff = kNoStore;
+            uint32_t gb = 0u;
+            float uv = 0.0f;
+            // byte offset of accumulator row q's channel plane.  KEEP: computed where it is used (one s_mul per store) -- hoisted out
+            // of the loops, the 16 offsets per plane size sat in scalar registers the kernel does not have (spills into vector lanes)
+            auto plane_off = [&](int q, int plane) -> unsigned {
+                const int rowc = (q & 3) + 8 * (q >> 2);
+                if (KEEP) {
+                    unsigned c4 = (unsigned)plane * 4u;
+                    asm volatile("" : "+s"(c4));
+                    return (unsigned)rowc * c4;
+                }
+                return (unsigned)(rowc * plane) * 4u;
+            };
 
             auto locate = [&](int tl, bool &valid_, int &off_, int &yy_, int &xx_) {
                 int m_ = tl * 32 + l31;
@@ -332,10 +365,28 @@ __global__ __launch_bounds__(512, 2) void k_conv32_chain(ChainArgs a)
                 const int q = g / 3, ph = g % 3;
                 if (ph == 0 && q < 16) sv[q] = __builtin_amdgcn_ldexpf(prev[q], kk);
                 if (ph == 1 && q < 16) tvv[q] = __int_as_float(max(__float_as_int(sv[q]), relu_floor));
+                if (KEEP) {
+                    // gate bit of accumulator row q (channel (q & 3) + 8 (q >> 2) + 4 h): post-ReLU values are >= +0, positive <=>
+                    // bit pattern >= 1 (a last layer without ReLU has no gate words: its store is dropped)
+                    if (ph == 2 && q < 16) {
+                        if (q == 0) gb = 0u;
+                        gb = (min(__float_as_uint(tvv[q]), 1u) << ((q & 3) + 8 * (q >> 2))) | gb;
+                    }
+                    if (g == 49) { // the two half-waves hold channels {0-3, 8-11, ..} and {4-7, 12-15, ..} of the same 32 pixels
+                        const uint32_t mine = gb << (4 * h);
+                        const auto sw = __builtin_amdgcn_permlane32_swap(mine, mine, false, false);
+                        gb = mine | (uint32_t)sw[1];
+                    }
+                    if (g == 51) __builtin_amdgcn_raw_buffer_store_b32(gb, rs_bits, pgoff, 0, 0);
+                    if (!last) { // the float32 copy: the stored value without the next layer's scale (a power of two: exact)
+                        if (ph == 0 && q >= 1 && q <= 16)
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, uv), rs_keep, pkoff, plane_off(q - 1, chwj), 0);
+                        if (ph == 2 && q < 16) uv = __builtin_amdgcn_ldexpf(tvv[q], -k_out);
+                    }
+                }
                 if (last) {
                     if (ph == 2 && q < 16) {
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, tvv[q]), rs_out, pboff,
-                                                              (unsigned)(((q & 3) + 8 * (q >> 2)) * chw) * 4u, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, tvv[q]), rs_out, pboff, plane_off(q, chw), 0);
                         if (q & 1) vmax = fmaxf(vmax, fmaxf(fabsf(tvv[q - 1]), fabsf(tvv[q])));
                     }
                     return;
@@ -407,7 +458,13 @@ __global__ __launch_bounds__(512, 2) void k_conv32_chain(ChainArgs a)
 #pragma unroll
                     for (int q = 0; q < 16; ++q) acc2[q] = 0.0f;
 #define CH_MM(A_, B_) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_, __builtin_bit_cast(f16x8, B_), acc, 0, 0, 0)
-#define CH_MM2(A_, B_) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_, __builtin_bit_cast(f16x8, B_), acc2, 0, 0, 0)
+// (KEEP: ONE accumulator -- measured flat in the no-grad kernel, 2382 against 2348 cycles per tile loop -- which frees the sixteen
+// registers the kept copy's offsets and gate word need; with two, the kernel spilled into its matrix loop)
+#define CH_MM2(A_, B_)                                                                                              \
+    do {                                                                                                            \
+        if (KEEP) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_, __builtin_bit_cast(f16x8, B_), acc, 0, 0, 0);    \
+        else acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A_, __builtin_bit_cast(f16x8, B_), acc2, 0, 0, 0);       \
+    } while (0)
 #pragma unroll
                     for (int i = 0; i < 18; ++i) {
                         Ops &cur = o[i % 3];
@@ -432,9 +489,15 @@ __global__ __launch_bounds__(512, 2) void k_conv32_chain(ChainArgs a)
                     }
 #undef CH_MM
 #undef CH_MM2
-                    prev = acc + acc2;
+                    if (KEEP) prev = acc;
+                    else prev = acc + acc2;
                     pdst = valid ? img + (yy * Wi + xx) * X2_SLOT + 8 * h : dump_slot;
                     pboff = valid ? (unsigned)((it.b * 32 * Hf + (it.y0 + yy)) * Wf + xx + 4 * h * chw) * 4u : kNoStore;
+                    if (KEEP) {
+                        const bool mine_ = valid && (last || yy < it.ny || last_part);
+                        pkoff = mine_ ? (unsigned)((it.b * 32 * Hj + (it.y0 + yy)) * Wout + xx + 4 * h * chwj) * 4u : kNoStore;
+                        pgoff = (mine_ && h == 0) ? (unsigned)((it.b * Hj + (it.y0 + yy)) * Wout + xx) * 4u : kNoStore;
+                    }
                     pending = true;
                     valid = valid2; off = off2; yy = yy2; xx = xx2;
                 } else if (pending) { // out of tiles: finish the last one (its round's barrier is behind us)
@@ -466,6 +529,7 @@ __global__ __launch_bounds__(512, 2) void k_conv32_chain(ChainArgs a)
                 __syncthreads(); // L: the layer's output is in place
                 amax_true = __uint_as_float(__builtin_amdgcn_readfirstlane((int)lred[j])) * pow2f(-k_out);
                 k_in = k_out;
+                if (KEEP && cw == 0 && lane == 0) atomicMax(lkeep + j, __float_as_uint(amax_true)); // (halo rows are other parts' rows: same tensor)
             } else {
                 vmax_out[it.grp] = fmaxf(vmax_out[it.grp], vmax);
             }
@@ -494,6 +558,11 @@ __global__ __launch_bounds__(512, 2) void k_conv32_chain(ChainArgs a)
                 if (a.dual) atomicMax(a.amax_out + 1, lred[9]);
             }
         }
+    }
+    if (KEEP) { // the kept layers' maxima: wave 0 collected them in LDS (its own earlier instructions), one global atomic per layer
+        if (cw == 0 && lane == 0)
+            for (int j = 0; j + 1 < nl; ++j)
+                if (a.amax_acts[j] != nullptr) atomicMax(a.amax_acts[j], lkeep[j]);
     }
 }
 
@@ -1040,11 +1109,11 @@ int augcl_internal_chain_rounds(int Hi, int Wi, int nl, int parts)
 
 // One chain launch.  wfrag[set][j] / bias[set][j]: the prepared fragments (k_x2_prep, mode 0) and biases of its layers; sets = 2:
 // images [B/2, B) use set 1.  +1: the shape is not covered.
-int augcl_internal_chain_forward(const float *in, float *out, const void *const *wfragA, const float *const *biasA,
-                                 const void *const *wfragB, const float *const *biasB, int nl, int B, int Hi, int Wi, int parts,
-                                 int relu_last, const float *amax_in, float *amax_out, augcl_stream_t stream)
+static int chain_forward_launch(const char *name, const float *in, float *out, const void *const *wfragA, const float *const *biasA,
+                                const void *const *wfragB, const float *const *biasB, int nl, int B, int Hi, int Wi, int parts,
+                                int relu_last, const float *amax_in, float *amax_out, bool keep, void *const *acts_out,
+                                void *const *bits_out, float *amax_acts, augcl_stream_t stream)
 {
-    const char *name = "augcl_enc_stack_infer";
     AUGCL_REQUIRE(in && out && wfragA && biasA && amax_in, "%s: null tensor", name);
     if (B == 0) return AUGCL_OK;
     if (augcl_internal_chain_rounds(Hi, Wi, nl, parts) < 0) return 1;
@@ -1069,13 +1138,46 @@ int augcl_internal_chain_forward(const float *in, float *out, const void *const 
     a.magic_parts = (uint32_t)(0x100000000ull / (unsigned)parts) + 1u;
     a.amax_in = reinterpret_cast<const uint32_t *>(amax_in);
     a.amax_out = reinterpret_cast<uint32_t *>(amax_out);
+    if (keep) {
+        AUGCL_REQUIRE(wfragB == nullptr && acts_out && amax_acts, "%s: the kept forward takes one weight set, the activation buffers and the maxima", name);
+        for (int j = 0; j < nl; ++j) {
+            if (j + 1 < nl) {
+                AUGCL_REQUIRE(acts_out[j] != nullptr && aligned4(acts_out[j]), "%s: null / misaligned activation buffer", name);
+                a.acts[j] = reinterpret_cast<float *>(acts_out[j]);
+                a.amax_acts[j] = reinterpret_cast<uint32_t *>(amax_acts + j);
+            }
+            a.bits[j] = bits_out ? reinterpret_cast<uint32_t *>(bits_out[j]) : nullptr;
+        }
+        if (!relu_last) a.bits[nl - 1] = nullptr; // gate words are those of a ReLU layer
+    }
     const size_t lds = (size_t)CH_HDR + (size_t)(a.rows_out + 2 * nl) * Wi * X2_SLOT;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv32_chain), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const void *fn = keep ? reinterpret_cast<const void *>(&k_conv32_chain<true>) : reinterpret_cast<const void *>(&k_conv32_chain<false>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return augcl::fail(AUGCL_E_LAUNCH, "%s: cannot set dynamic LDS %zu: %s", name, lds, hipGetErrorString(e));
     const int cus = cu_count_chain();
     const int grid = a.n_items < cus ? a.n_items : cus;
-    hipLaunchKernelGGL(k_conv32_chain, dim3(grid), dim3(512), lds, as_stream(stream), a);
+    if (keep) hipLaunchKernelGGL(k_conv32_chain<true>, dim3(grid), dim3(512), lds, as_stream(stream), a);
+    else hipLaunchKernelGGL(k_conv32_chain<false>, dim3(grid), dim3(512), lds, as_stream(stream), a);
     return augcl::check_launch(name);
+}
+
+int augcl_internal_chain_forward(const float *in, float *out, const void *const *wfragA, const float *const *biasA,
+                                 const void *const *wfragB, const float *const *biasB, int nl, int B, int Hi, int Wi, int parts,
+                                 int relu_last, const float *amax_in, float *amax_out, augcl_stream_t stream)
+{
+    return chain_forward_launch("augcl_enc_stack_infer", in, out, wfragA, biasA, wfragB, biasB, nl, B, Hi, Wi, parts, relu_last, amax_in,
+                                amax_out, false, nullptr, nullptr, nullptr, stream);
+}
+
+// The same launch for the GRADIENT-CARRYING forward: acts_out[j] (j < nl - 1) receives layer j's float32 output, bits_out[j] (j < nl,
+// entries may be null) its gate words, amax_acts[j] (j < nl - 1; zeroed by the caller) its maximum; the last layer's output, gate
+// words and maximum go to out / bits_out[nl - 1] / amax_out as in the no-grad launch.
+int augcl_internal_chain_forward_keep(const float *in, float *out, const void *const *wfrag, const float *const *bias, int nl, int B,
+                                      int Hi, int Wi, int parts, int relu_last, const float *amax_in, float *amax_out,
+                                      void *const *acts_out, void *const *bits_out, float *amax_acts, augcl_stream_t stream)
+{
+    return chain_forward_launch("augcl_enc_stack_forward_chained", in, out, wfrag, bias, nullptr, nullptr, nl, B, Hi, Wi, parts, relu_last,
+                                amax_in, amax_out, true, acts_out, bits_out, amax_acts, stream);
 }
 
 // ---- bf16 performance mode (k_conv32_chain_bf16) ----

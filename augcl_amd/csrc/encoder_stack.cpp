@@ -379,6 +379,65 @@ static int bf16_forward_chained(const float *x, const float *const *w, const flo
     return AUGCL_OK;
 }
 
+int augcl_internal_chain_forward_keep(const float *in, float *out, const void *const *wfrag, const float *const *bias, int nl, int B,
+                                      int Hi, int Wi, int parts, int relu_last, const float *amax_in, float *amax_out,
+                                      void *const *acts_out, void *const *bits_out, float *amax_acts, augcl_stream_t stream);
+
+// The GRADIENT-CARRYING forward of precision 3 with the 32 -> 32 layers as chains (encoder_chain.hip, k_conv32_chain<true>): the
+// critic's pass over the (augmented) batch in SAC.update_critic (src/algorithms/sac.py:103-116 -> modules.py:145-165).  Same
+// tensors on return as augcl_enc_stack_forward(precision 3) -- every layer's float32 output in acts_out[i], amax[i], the gate
+// words -- but a layer reads its input from LDS, where the previous layer left it as f16 pairs, instead of from HBM: the
+// activations are WRITTEN once and not read back (the per-layer kernels read each one once), 4 launches instead of 12.  Values:
+// the chains' (per-item scales; the accuracy class of the per-layer kernels, not their bits).  AUGCL_E_UNSUPPORTED: a shape the
+// chains do not cover -- the caller runs augcl_enc_stack_forward.
+int augcl_enc_stack_forward_chained(const float *x, const float *const *w, const float *const *b, void *const *acts_out,
+                                    int n_layers, int B, int C, int H, int W, int first_stride, float scale, void *frag_ws,
+                                    size_t frag_ws_bytes, float *amax, void *const *gate_bits, augcl_stream_t stream)
+{
+    const char *name = "augcl_enc_stack_forward_chained";
+    AUGCL_REQUIRE(x && w && b && acts_out && n_layers >= 1 && B >= 0, "%s: bad argument", name);
+    if (n_layers < 2 || n_layers > 33) return augcl::fail(AUGCL_E_UNSUPPORTED, "%s: 2..33 layers", name);
+    if (B == 0) return AUGCL_OK;
+    int rc;
+    if ((rc = x2_require(name, n_layers, frag_ws, frag_ws_bytes, 1, amax)) != AUGCL_OK) return rc;
+    const int h1 = out_hw(H, first_stride), w1 = out_hw(W, first_stride);
+    AUGCL_REQUIRE(h1 >= 1 && w1 >= 1 && h1 - 2 * (n_layers - 1) >= 1 && w1 - 2 * (n_layers - 1) >= 1, "%s: image too small", name);
+    ChainPlan plan;
+    if (!plan_chains(h1, w1, n_layers - 1, B, cu_count_stack(), plan, augcl_internal_chain_rounds, 6))
+        return augcl::fail(AUGCL_E_UNSUPPORTED, "%s: no chain plan for a %d x %d input", name, h1, w1);
+    // fragments with unscaled residuals (mode 2); the same launch zeroes the maxima
+    rc = augcl_internal_x2_prep_weights(w + 1, n_layers - 1, 2, frag_ws, amax, n_layers, stream);
+    if (rc != AUGCL_OK) return rc;
+    void *gb0 = gate_bits ? gate_bits[0] : nullptr;
+    rc = augcl::conv_first9_try(x, w[0], b[0], acts_out[0], B, C, H, W, first_stride, scale, 1, false, (hipStream_t)stream, name, nullptr,
+                                nullptr, amax, gb0);
+    if (rc > 0) {
+        rc = augcl_enc_conv_first_forward(x, w[0], b[0], (float *)acts_out[0], B, C, H, W, first_stride, scale, 1, stream);
+        if (rc == AUGCL_OK) rc = augcl_internal_amax_f32((const float *)acts_out[0], (size_t)B * 32 * h1 * w1, amax, stream);
+        if (rc == AUGCL_OK && gb0) rc = augcl_internal_gate_bits((const float *)acts_out[0], gb0, B, h1, w1, stream);
+    }
+    if (rc != AUGCL_OK) return rc;
+    const size_t block = augcl_enc_frag_workspace_bytes(1, 1);
+    int layer = 1, h = h1, ww = w1;
+    for (int c = 0; c < plan.n; ++c) {
+        const int nl = plan.nl[c];
+        const bool final_chain = c == plan.n - 1;
+        const void *fa[6];
+        for (int j = 0; j < nl; ++j) fa[j] = (char *)frag_ws + (size_t)(layer + j - 1) * block;
+        // stack layer (layer + j) = the chain's layer j; its last layer's output goes through the kernel's `out`
+        rc = augcl_internal_chain_forward_keep((const float *)acts_out[layer - 1], (float *)acts_out[layer + nl - 1], fa, b + layer, nl, B, h,
+                                               ww, plan.parts[c], final_chain ? 0 : 1, amax + layer - 1,
+                                               final_chain ? nullptr : amax + layer + nl - 1, acts_out + layer,
+                                               gate_bits ? gate_bits + layer : nullptr, amax + layer, stream);
+        if (rc > 0) return augcl::fail(AUGCL_E_UNSUPPORTED, "%s: chain of %d layers at %d x %d not covered", name, nl, h, ww);
+        if (rc != AUGCL_OK) return rc;
+        layer += nl;
+        h -= 2 * nl;
+        ww -= 2 * nl;
+    }
+    return AUGCL_OK;
+}
+
 size_t augcl_enc_stack_backward_chain_bytes(int n_layers, int B, int C, int H, int W, int first_stride)
 {
     (void)C;

@@ -156,6 +156,13 @@ def _ptr_array(ptrs):
 _CHAINS_BWD = True  # (A/B switch) bf16 mode: backward-data of the whole stack as one chain launch
 _U8_FIRST = True  # (A/B switch) uint8 observations go into the first layer as they are (no-grad passes of precision "f32")
 _CHAINS = True  # (A/B switch) no-grad passes of precision "f32" through augcl_enc_stack_infer: LDS-resident layer chains
+_CHAINS_GRAD = True  # (A/B switch) ... and the gradient-carrying forward of precision "f32" through augcl_enc_stack_forward_chained
+# ... for batches of at most this many images.  Measured (tools/keep_bench.py, one MI355X, forward / forward + backward of the
+# eleven-layer stack, us): B = 64: 125 / 520 against the per-layer kernels' 159-165 / 550; 128: 160 / 672 against 192 / 688;
+# 256: 250 / 911 against 283 / 933; 320: 356 / 1131 against 332 / 1084; 512: 438 / 1417 against 440 / 1408.  The stores, un-scales
+# and gate bits in the wave that issues the matrix instructions cost what the chain saves once every CU has more than one
+# image (and 320 images x 2 parts on 256 CUs quantise badly): above one image per CU the per-layer kernels run.
+_CHAINS_GRAD_MAX_B = 256
 _infer_ws = {}
 
 
@@ -300,10 +307,21 @@ class ConvStackFn(torch.autograd.Function):
         amax = arena.data_ptr() + tot * 4 if tail else None
         # (bf16 mode: the chains' prepared bf16 fragments live in the same workspace; _CHAINS off = per-layer kernels, no workspace)
         fws = _frag_ws(dev, n_layers - 1) if (precision in _SPLIT or (bf16 and _CHAINS)) and n_layers > 1 else None
-        _lib.call("augcl_enc_stack_forward", x.data_ptr(), _ptr_array([t.data_ptr() for t in weights]),
-                  _ptr_array([t.data_ptr() for t in biases]), _ptr_array(ptrs), n_layers, B, C, H, W, first_stride,
-                  input_scale, PRECISION_CODE[precision], _lib.ptr(fws), fws.numel() if fws is not None else 0, amax, bits,
-                  _lib.current_stream(dev))
+        done = False
+        if need_grad and precision == "f32" and _CHAINS and _CHAINS_GRAD and n_layers > 1 and bits is not None and B <= _CHAINS_GRAD_MAX_B:
+            # every layer's output is written once and read from LDS by the next layer (ABI v6); same tensors for the backward pass
+            rc = _lib.load().augcl_enc_stack_forward_chained(
+                x.data_ptr(), _ptr_array([t.data_ptr() for t in weights]), _ptr_array([t.data_ptr() for t in biases]),
+                _ptr_array(ptrs), n_layers, B, C, H, W, first_stride, input_scale, fws.data_ptr(), fws.numel(), amax, bits,
+                _lib.current_stream(dev))
+            if rc != _lib.AUGCL_E_UNSUPPORTED:
+                _lib.check(rc, "augcl_enc_stack_forward_chained")
+                done = True
+        if not done:
+            _lib.call("augcl_enc_stack_forward", x.data_ptr(), _ptr_array([t.data_ptr() for t in weights]),
+                      _ptr_array([t.data_ptr() for t in biases]), _ptr_array(ptrs), n_layers, B, C, H, W, first_stride,
+                      input_scale, PRECISION_CODE[precision], _lib.ptr(fws), fws.numel() if fws is not None else 0, amax, bits,
+                      _lib.current_stream(dev))
         if need_grad:
             ctx.save_for_backward(x, arena, *weights)
             ctx.meta = (first_stride, input_scale, precision, n_layers, ptrs[:-1], max(numel), amax, bits)

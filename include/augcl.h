@@ -36,9 +36,10 @@
 extern "C" {
 #endif
 
-#define AUGCL_ABI_VERSION 5 /* 2: the whole-stack entry points take a weight-fragment workspace; 3: ... and the per-tensor maxima of precision 3;
+#define AUGCL_ABI_VERSION 6 /* 2: the whole-stack entry points take a weight-fragment workspace; 3: ... and the per-tensor maxima of precision 3;
                              * 4: augcl_enc_stack_infer (no-grad forward with LDS-resident layer chains); 5: uint8 observations into the first layer
-                             * (augcl_enc_stack_infer_u8, augcl_enc_conv_first_forward_u8) */
+                             * (augcl_enc_stack_infer_u8, augcl_enc_conv_first_forward_u8); 6: augcl_enc_stack_forward_chained (the
+                             * gradient-carrying forward of precision 3 with LDS-resident layer chains) */
 
 #define AUGCL_OK 0
 #define AUGCL_E_INVALID (-1)   /* bad argument (null pointer, bad shape, misalignment) */
@@ -386,6 +387,17 @@ size_t augcl_enc_frag_workspace_bytes(int n_layers32, int weight_sets);
 int augcl_enc_stack_forward(const float *x, const float *const *w, const float *const *b, void *const *acts_out,
                             int n_layers, int B, int C, int H, int W, int first_stride, float scale, int precision,
                             void *frag_ws, size_t frag_ws_bytes, float *amax, void *const *gate_bits, augcl_stream_t stream);
+/* The gradient-carrying forward of precision 3 -- the critic's pass over the augmented batch, src/algorithms/sac.py:103-116 ->
+ * src/algorithms/modules.py:145-165 with autograd recording -- with the 32 -> 32 layers as the CHAINS of augcl_enc_stack_infer
+ * (csrc/encoder_chain.hip, k_conv32_chain<true>): a layer reads its input from the LDS image the previous layer left, and every
+ * layer's output is stored ONCE for the backward pass (float32 NCHW into acts_out[i], each row by the part that owns it), with
+ * its gate words and amax[i] exactly as augcl_enc_stack_forward(precision 3) leaves them: augcl_enc_stack_backward takes the
+ * result unchanged.  Values are the chains' (per-work-item scales: same accuracy class as the per-layer kernels, not the same
+ * bits).  Arguments as augcl_enc_stack_forward with precision 3 (frag_ws and amax required).  AUGCL_E_UNSUPPORTED: a stack the
+ * chains do not cover (fewer than 2 layers, an input no plan fits) -- run augcl_enc_stack_forward. */
+int augcl_enc_stack_forward_chained(const float *x, const float *const *w, const float *const *b, void *const *acts_out,
+                                    int n_layers, int B, int C, int H, int W, int first_stride, float scale, void *frag_ws,
+                                    size_t frag_ws_bytes, float *amax, void *const *gate_bits, augcl_stream_t stream);
 int augcl_enc_stack_backward(const void *const *acts_in, const float *const *w, const float *grad_out, float *const *dw,
                              float *const *db, void *dz_a, void *dz_b, float *ws32, size_t ws32_bytes, float *ws_first,
                              size_t ws_first_bytes, int n_layers, int B, int C, int H, int W, int first_stride,

@@ -16,7 +16,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in _lib.declared_symbols():
         assert hasattr(lib, name), f"libaugcl_hip.so lacks {name}"
-    assert _lib.load().augcl_abi_version() == 5
+    assert _lib.load().augcl_abi_version() == 6
 
 
 def test_bad_arguments_are_reported_not_crashed():

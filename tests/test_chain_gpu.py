@@ -240,3 +240,110 @@ def test_bf16_gradient_carrying_forward_through_chains_equals_per_layer(cuda, B,
     assert torch.equal(o1, o0)
     for a, b in zip(dw1 + db1, dw0 + db0):
         assert torch.equal(a, b), float((a - b).abs().max())
+
+
+def _kept(out, B, hs, wsz):
+    """what the gradient-carrying f32 forward left for the backward pass: (activations, maxima, gate words) per intermediate layer,
+    read out of the autograd node's arena"""
+    fn = out.grad_fn
+    _, _, _, n_layers, act_ptrs, _, amax_ptr, bits = fn.meta
+    arena = fn.saved_tensors[1]
+    base = arena.data_ptr()
+    acts, words = [], []
+    for i, p in enumerate(act_ptrs):
+        o = (p - base) // 4
+        acts.append(arena[o:o + B * 32 * hs[i] * wsz[i]].view(B, 32, hs[i], wsz[i]))
+        bo = (bits[i] - base) // 4
+        words.append(arena[bo:bo + B * hs[i] * wsz[i]].view(torch.int32).view(B, hs[i], wsz[i]))
+    ao = (amax_ptr - base) // 4
+    return acts, arena[ao:ao + n_layers].clone(), words
+
+
+@pytest.mark.parametrize("B,H,W,n_layers", [(3, 84, 84, 11), (37, 84, 84, 11), (300, 84, 84, 11), (2, 100, 100, 11), (5, 64, 72, 5),
+                                            (4, 84, 84, 2), (1, 84, 84, 11), (16, 50, 70, 4)])
+def test_f32_gradient_carrying_forward_through_chains(cuda, B, H, W, n_layers):
+    """Precision "f32" with gradients (the critic's pass, src/algorithms/sac.py:103-116): the 32 -> 32 layers as chains that also
+    store every layer's float32 output, gate words and maximum (augcl_enc_stack_forward_chained, ABI v6).  What the backward pass
+    is handed must be self-consistent -- maxima that bound the stored tensors tightly, gate words exactly (stored value > 0), every
+    row of every layer written (parts own disjoint rows) -- every layer float32-accurate against float64, and the gradients of
+    the backward pass that reads those stores as close to float64's as the per-layer kernels'."""
+    from augcl_amd import encoder_hip, encoder_ops
+    x = torch.from_numpy(np.random.RandomState(B + H).randint(0, 256, (B, 9, H, W)).astype(np.float32)).to(cuda)
+    ws, bs = _stack(43, n_layers, dev=cuda)
+    hs, wsz = [(H - 3) // 2 + 1], [(W - 3) // 2 + 1]
+    for _ in range(1, n_layers):
+        hs.append(hs[-1] - 2)
+        wsz.append(wsz[-1] - 2)
+    g = torch.from_numpy(np.random.RandomState(5).standard_normal((B, 32, hs[-1], wsz[-1])).astype(np.float32)).to(cuda)
+
+    def ref64(gates):
+        """float64 forward / backward; gates = None: ReLU; else the gate of every intermediate layer as the HIP forward took it (a
+        pre-activation within rounding of zero may fall on either side, and ONE flipped gate moves a random-sign sum over B x h x w
+        terms by 1 / sqrt(terms) ~ 1e-3: the gradients are compared on the gates the kernels actually used, as the referee does)"""
+        w64 = [w.double().requires_grad_(True) for w in ws]
+        b64 = [b.double().requires_grad_(True) for b in bs]
+        y, acts64 = x.double() / 255.0, []
+        for i in range(n_layers):
+            y = F.conv2d(y, w64[i], b64[i], stride=2 if i == 0 else 1)
+            if i < n_layers - 1:
+                y = torch.relu(y) if gates is None else y * gates[i]
+                acts64.append(y.detach())
+        (y * g.double()).sum().backward()
+        return y.detach(), acts64, [w.grad for w in w64] + [b.grad for b in b64]
+
+    want_out, want_acts, _ = ref64(None)
+    max_b = encoder_hip._CHAINS_GRAD_MAX_B
+    for chains in (True, False):
+        encoder_hip._CHAINS_GRAD = chains
+        encoder_hip._CHAINS_GRAD_MAX_B = 1 << 30  # (the product takes the chains up to one image per CU; the kernel covers any batch)
+        try:
+            wg = [w.clone().requires_grad_(True) for w in ws]
+            bg = [b.clone().requires_grad_(True) for b in bs]
+            out = encoder_ops.conv_stack(x, wg, bg, precision="f32")
+            acts, amax, words = _kept(out, B, hs, wsz)
+            bit = torch.arange(32, device=cuda, dtype=torch.int32).view(1, 32, 1, 1)
+            for i, a in enumerate(acts):
+                assert torch.isfinite(a).all()
+                # the maximum bounds the stored values to rounding (the backward-weights kernel scales its f16 pairs by it: 2^15 of
+                # f16's 65504 are used) and is tight; not to the bit: the stored value is the (hi + lo) pair the next layer read, the
+                # maximum that of the float32 it was cut from, and a part's halo rows are another part's rows under another scale
+                assert float(a.abs().max()) * (1 - 1e-6) <= float(amax[i]) <= float(a.abs().max()) * (1 + 1e-6), (i, float(amax[i]), float(a.abs().max()))
+                assert torch.equal(((words[i].unsqueeze(1) >> bit) & 1).bool(), a > 0), i
+                assert _rel(a, want_acts[i]) <= 3e-6, (i, _rel(a, want_acts[i]))
+            assert _rel(out, want_out) <= 3e-6
+            gates = [(a > 0).double() for a in acts]
+            (out * g).sum().backward()
+            torch.cuda.synchronize()
+            _, _, want = ref64(gates)
+            for k, (got, r) in enumerate(zip([w.grad for w in wg] + [b.grad for b in bg], want)):
+                assert _rel(got, r) <= 3e-6, (chains, k, _rel(got, r))
+        finally:
+            encoder_hip._CHAINS_GRAD = True
+            encoder_hip._CHAINS_GRAD_MAX_B = max_b
+
+
+def test_f32_kept_forward_arena_is_fully_written(cuda):
+    """every row of every kept layer is stored once: a poisoned arena comes back without a single poison value (two parts per
+    image in the first chain: the rows of the second part start where the first part's end)"""
+    from augcl_amd import _lib, encoder_hip
+    B, n_layers = 7, 11
+    x = torch.from_numpy(np.random.RandomState(3).randint(0, 256, (B, 9, 84, 84)).astype(np.float32)).to(cuda)
+    ws, bs = _stack(44, n_layers, dev=cuda)
+    hs = [41 - 2 * i for i in range(n_layers)]
+    acts = [torch.full((B, 32, h, h), float("nan"), device=cuda) for h in hs]
+    bits = [torch.full((B, h, h), -1, dtype=torch.int32, device=cuda) for h in hs[:-1]]
+    amax = torch.zeros(n_layers, device=cuda)
+    fws = encoder_hip._frag_ws(cuda, n_layers - 1)
+    P = encoder_hip._ptr_array
+    rc = _lib.load().augcl_enc_stack_forward_chained(
+        x.data_ptr(), P([w.data_ptr() for w in ws]), P([b.data_ptr() for b in bs]), P([a.data_ptr() for a in acts]), n_layers, B, 9, 84,
+        84, 2, 255.0, fws.data_ptr(), fws.numel(), amax.data_ptr(), P([b.data_ptr() for b in bits] + [None]), _lib.current_stream(cuda))
+    assert rc == 0
+    torch.cuda.synchronize()
+    for a in acts:
+        assert torch.isfinite(a).all()
+    want = _ref64(x, ws, bs, 2, 255.0)
+    assert _rel(acts[-1], want) <= 3e-6
+    for i, w_ in enumerate(bits):
+        bit = torch.arange(32, device=cuda, dtype=torch.int32).view(1, 32, 1, 1)
+        assert torch.equal(((w_.unsqueeze(1) >> bit) & 1).bool(), acts[i] > 0), i
