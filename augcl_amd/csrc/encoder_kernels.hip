@@ -1014,7 +1014,8 @@ __global__ __launch_bounds__(256, (NT <= 3 ? 4 : NT <= 6 ? 2 : 1)) void k_wgrad_
 // 2 dwordx4 of bf16) into registers before the MFMAs of the current strip, and writes them to LDS after.  (The loop
 // above copies channel pair after channel pair, each waiting for its own loads: 137 us at B = 512 with the MFMA pipe
 // busy 25 % of the time.)
-constexpr int WG1_XU = 4;   // x chunks (16 B) per thread per strip
+constexpr int WG1_XU = 4;   // x chunks (16 B) per thread per strip (bf16 dZ: four workgroups per CU, 2-row strips)
+constexpr int WG1_XU32 = 6; // ... with float32 dZ: three workgroups per CU and 3-row strips (7 input rows of 9 x 84: 1323 chunks)
 constexpr int WG1_ZP = 128; // dZ pixel slots per channel in the f32 fetch pattern (>= pixels per strip)
 
 // Workgroups per CU: 4 with bf16 dZ; 3 with f32 dZ, whose 16 prefetch registers more do not fit a 128-VGPR budget.
@@ -1069,8 +1070,9 @@ __global__ __launch_bounds__(256, (BF16DZ ? 4 : 3)) void k_wgrad_first_pipe(Wgra
 
     typedef float vf4 __attribute__((ext_vector_type(4)));
     typedef uint32_t vu4 __attribute__((ext_vector_type(4)));
+    constexpr int XU = BF16DZ ? WG1_XU : WG1_XU32;
     struct Regs {
-        vf4 x[WG1_XU];
+        vf4 x[XU];
         float z[BF16DZ ? 1 : 16];
         vu4 zb[BF16DZ ? 2 : 1];
     };
@@ -1094,7 +1096,7 @@ __global__ __launch_bounds__(256, (BF16DZ ? 4 : 3)) void k_wgrad_first_pipe(Wgra
         const Geo g = geom(item);
         const float *src = a.x + ((size_t)g.b * a.C * a.Hi + (size_t)st * g.y0) * a.Wi;
 #pragma unroll
-        for (int u = 0; u < WG1_XU; ++u) {
+        for (int u = 0; u < XU; ++u) {
             const int q = min(u * 256 + tid, g.nchunk - 1); // idempotent tail
             const int c = (int)__umulhi((uint32_t)q, g.magic);
             R.x[u] = *reinterpret_cast<const vf4 *>(src + (size_t)c * a.Hi * a.Wi + (q - c * g.run4) * 4);
@@ -1117,7 +1119,7 @@ __global__ __launch_bounds__(256, (BF16DZ ? 4 : 3)) void k_wgrad_first_pipe(Wgra
         const Geo g = geom(item);
         const XfScale xf{a.scale};
 #pragma unroll
-        for (int u = 0; u < WG1_XU; ++u) {
+        for (int u = 0; u < XU; ++u) {
             const int q = min(u * 256 + tid, g.nchunk - 1);
             const int c = (int)__umulhi((uint32_t)q, g.magic);
             vf4 v = R.x[u];
@@ -1487,6 +1489,9 @@ int augcl_enc_bf16_conv32_backward_weights(const void *act_prev_bf16_nhwc, const
                         "augcl_enc_bf16_conv32_backward_weights");
 }
 
+static int g_wg1_rows3 = 1; // (A/B switch for tools: augcl_internal_wgrad_first_rows3)
+constexpr int kWg1Lds3 = 50 * 1024; // float32 dZ: three workgroups per CU (the kernel's register budget), 3-row strips
+
 static int wgrad_first_impl(const float *x, const float *dz, float *dw, float *db, float *workspace,
                             size_t workspace_bytes, int B, int C, int Hi, int Wi, int stride, float scale,
                             bool bf16dz, augcl_stream_t stream, const char *name)
@@ -1509,6 +1514,21 @@ static int wgrad_first_impl(const float *x, const float *dz, float *dw, float *d
     }
     AUGCL_REQUIRE(rt >= 1, "%s: image row too wide for LDS", name);
     if (rt > a.Ho) rt = a.Ho;
+    // float32 dZ runs three workgroups per CU whatever the strip (153 registers): their LDS share holds a taller strip -- more
+    // bytes in flight per workgroup (the launch is bound by how many it keeps in flight) and fewer halo rows per output row.
+    // Taken only where the pipelined kernel covers the taller strip.
+    size_t lds_cap = (size_t)kWg1Lds * kWg1PerCu / per_cu;
+    if (g_wg1_rows3 && !bf16dz && nt <= 3 && per_cu == kWg1PerCu && Wi % 4 == 0 && aligned16(x)) {
+        int rt3 = (kWg1Lds3 / 4 - 3 * C * Wi - 64) / (C * stride * Wi + 32 * a.Wo);
+        if (rt3 > a.Ho) rt3 = a.Ho;
+        if (rt3 > rt) {
+            const int s3 = (a.Ho + rt3 - 1) / rt3, r3 = (a.Ho + s3 - 1) / s3;
+            if (r3 * a.Wo <= WG1_ZP && C * (stride * (r3 - 1) + 3) * (Wi / 4) <= 256 * WG1_XU32) {
+                rt = rt3;
+                lds_cap = kWg1Lds3;
+            }
+        }
+    }
     a.S = (a.Ho + rt - 1) / rt;
     a.RT = (a.Ho + a.S - 1) / a.S;
     a.n_items = B * a.S;
@@ -1529,8 +1549,8 @@ static int wgrad_first_impl(const float *x, const float *dz, float *dw, float *d
     // its LDS: X planes, dZ planes with a spare zero word each, the pair tables
     const int planeZp = (a.RT * a.Wo + 1) | 1, ntab = 2 * (((a.RT * a.Wo + 1) >> 1) + 8);
     const size_t lds_pipe = std::max((size_t)(((C * planeX + 32 * planeZp + 1) & ~1) + 2 * ntab * 2) * 4, red);
-    const bool pipe = Wi % 4 == 0 && aligned16(x) && a.RT * a.Wo <= WG1_ZP && C * run4_full <= 256 * WG1_XU &&
-                      (!bf16dz || a.RT * a.Wo * 4 <= 512) && NT <= 3 && lds_pipe <= (size_t)kWg1Lds * kWg1PerCu / per_cu;
+    const bool pipe = Wi % 4 == 0 && aligned16(x) && a.RT * a.Wo <= WG1_ZP && C * run4_full <= 256 * (bf16dz ? WG1_XU : WG1_XU32) &&
+                      (!bf16dz || a.RT * a.Wo * 4 <= 512) && NT <= 3 && lds_pipe <= lds_cap;
     if (pipe) {
         const size_t lds = lds_pipe;
         const int grid = grid_for(a.n_items, bf16dz ? 4 : 3); // = the kernel's launch bounds: every workgroup resident
@@ -1582,6 +1602,13 @@ static int wgrad_first_impl(const float *x, const float *dz, float *dw, float *d
     if (int rc = augcl::check_launch(name)) return rc;
     if (int rc = augcl::reduce_slabs(ReduceDesc{workspace, part2, dw, db, grid, slab, 32 * K}, s, name)) return rc;
     return augcl::check_launch(name);
+}
+
+int augcl_internal_wgrad_first_rows3(int on) // (tools: A/B of the taller strips; returns the previous setting)
+{
+    const int was = g_wg1_rows3;
+    g_wg1_rows3 = on ? 1 : 0;
+    return was;
 }
 
 int augcl_enc_conv_first_backward_weights(const float *x, const float *dz, float *dw, float *db, float *workspace,
