@@ -1,5 +1,6 @@
 """Where a compute wave's cycles go inside one chain launch (tuning build: tools/build_tuning.sh).
-python tools/chain_stamps.py [B]  -> per launch of the two chains of the 84x84 stack: cycles per round by phase"""
+python tools/chain_stamps.py [B] [keep]  -> per launch of the two chains of the 84x84 stack: cycles per round by phase
+(keep: the gradient-carrying launch, k_conv32_chain<true>, which also stores every layer, its gate words and maxima)"""
 import ctypes, os, sys
 import numpy as np
 import torch
@@ -9,8 +10,10 @@ _lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libaug
 L = _lib.load()
 dev = torch.device('cuda:0')
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+KEEP = len(sys.argv) > 2 and sys.argv[2] == "keep"
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 L.augcl_internal_chain_forward.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_int] * 6 + [ctypes.c_void_p] * 3
+L.augcl_internal_chain_forward_keep.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 6 + [ctypes.c_void_p] * 6
 fb = L.augcl_enc_frag_workspace_bytes(1, 1)
 for (Hi, nl, parts) in ((41, 4, 2), (33, 6, 1), (41, 1, 1), (41, 2, 1), (33, 1, 1)):
     if L.augcl_internal_chain_rounds(Hi, Hi, nl, parts) < 0:
@@ -25,8 +28,17 @@ for (Hi, nl, parts) in ((41, 4, 2), (33, 6, 1), (41, 1, 1), (41, 2, 1), (33, 1, 
     out = torch.empty(B, 32, Hi - 2 * nl, Hi - 2 * nl, device=dev)
     fa = (ctypes.c_void_p * nl)(*[frag.data_ptr() + j * fb for j in range(nl)])
     ba = (ctypes.c_void_p * nl)(*[b.data_ptr() for b in bs])
+    acts = [torch.empty(B, 32, Hi - 2 * (j + 1), Hi - 2 * (j + 1), device=dev) for j in range(nl - 1)]
+    bits = [torch.empty(B, Hi - 2 * (j + 1), Hi - 2 * (j + 1), dtype=torch.int32, device=dev) for j in range(nl)]
+    aa = (ctypes.c_void_p * max(nl - 1, 1))(*[t.data_ptr() for t in acts]) if nl > 1 else (ctypes.c_void_p * 1)(None)
+    bb = (ctypes.c_void_p * nl)(*[t.data_ptr() for t in bits])
+    amk = torch.zeros(8, device=dev)
     def run():
-        rc = L.augcl_internal_chain_forward(x.data_ptr(), out.data_ptr(), fa, ba, None, None, nl, B, Hi, Hi, parts, 0, am.data_ptr(), None, st)
+        if KEEP:
+            rc = L.augcl_internal_chain_forward_keep(x.data_ptr(), out.data_ptr(), fa, ba, nl, B, Hi, Hi, parts, 1, am.data_ptr(), amk.data_ptr() + 28,
+                                                     aa, bb, amk.data_ptr(), st)
+        else:
+            rc = L.augcl_internal_chain_forward(x.data_ptr(), out.data_ptr(), fa, ba, None, None, nl, B, Hi, Hi, parts, 0, am.data_ptr(), None, st)
         assert rc == 0, L.augcl_last_error()
     for _ in range(5): run()
     torch.cuda.synchronize()

@@ -53,6 +53,7 @@ for B in [int(a) for a in sys.argv[1:]] or [512, 256, 128]:
     def fwd_bwd():
         fwd().backward(g)
 
+    encoder_hip._CHAINS_GRAD_MAX_B = 1 << 30  # (the product takes the chains up to one image per CU: measured here beyond it)
     for rep in range(2):
         for on in (False, True):
             encoder_hip._CHAINS_GRAD = on
