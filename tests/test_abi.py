@@ -103,3 +103,18 @@ def test_chain_planner_and_infer_argument_checks():
     assert rb(41, 41, 10, 1) == 12 + 11 + 10 + 9 + 8 + 7 + 6 + 5 + 5 + 4 and rb(41, 41, 13, 1) == -1 and rb(47, 47, 3, 1) == -1
     assert lib.augcl_enc_stack_infer(16, one, one, None, None, 16, 16, 1 << 30, 11, 4, 9, 84, 84, 2, 255.0, 1, 16, 64, None, None) == -1
     assert b"frag_ws" in lib.augcl_last_error()
+
+
+def test_chained_gradient_forward_argument_checks():
+    """augcl_enc_stack_forward_chained (ABI v6: the gradient-carrying forward of precision 3 through the layer chains): everything it
+    refuses is refused before a launch -- no GPU needed."""
+    lib = _lib.load()
+    p = ctypes.c_void_p
+    one = (p * 11)(*([1 << 20] * 11))
+    fn = lib.augcl_enc_stack_forward_chained
+    assert fn(None, one, one, one, 11, 4, 9, 84, 84, 2, 255.0, 16, 1 << 30, 16, None, None) == -1            # null input
+    assert fn(16, one, one, one, 1, 4, 9, 84, 84, 2, 255.0, 16, 1 << 30, 16, None, None) == _lib.AUGCL_E_UNSUPPORTED  # a lone first layer has no chain
+    assert fn(16, one, one, one, 11, 0, 9, 84, 84, 2, 255.0, 16, 1 << 30, 16, None, None) == 0                # an empty batch is done
+    assert fn(16, one, one, one, 11, 4, 9, 84, 84, 2, 255.0, 16, 64, 16, None, None) == -1 and b"frag_ws" in lib.augcl_last_error()
+    assert fn(16, one, one, one, 11, 4, 9, 84, 84, 2, 255.0, 16, 1 << 30, None, None, None) == -1 and b"amax" in lib.augcl_last_error()
+    assert fn(16, one, one, one, 11, 4, 9, 20, 20, 2, 255.0, 16, 1 << 30, 16, None, None) == -1 and b"too small" in lib.augcl_last_error()
