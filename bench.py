@@ -521,6 +521,18 @@ def main():
                         str(b_): bench_update.run(dev, None, 1, 0, steps=max(10, n_upd // 4), B=b_, algo="augcl", data_aug="conv-overlay",
                                                   precision="f32", graph=True, min_s=0.3)["ms_per_update"]
                         for b_ in (1024, 512, 256, 128)}
+                    # critic passes of at most one image per CU run the gradient-carrying forward through the storing layer chains
+                    # (augcl_enc_stack_forward_chained): RAD at the config's batch, both arms on this box
+                    from augcl_amd import encoder_hip
+                    ab = {}
+                    for arm, on in (("per_layer_kernels", False), ("storing_chains", True)):
+                        encoder_hip._CHAINS_GRAD = on
+                        try:
+                            ab[arm] = bench_update.run(dev, None, 1, 0, steps=max(10, n_upd // 2), B=256, algo="rad", data_aug="shift",
+                                                       precision="f32", graph=True, min_s=0.5)["ms_per_update"]
+                        finally:
+                            encoder_hip._CHAINS_GRAD = True
+                    res["sac"]["rad_shift_B256_ms_per_update"] = ab
             res["sac"]["select_action_us"] = bench_update.action_latency(dev)  # batch-1 acting, eager vs captured graph
         except Exception as e:  # noqa: BLE001 -- the headline above is measured: report the failure, do not lose the line
             import traceback
