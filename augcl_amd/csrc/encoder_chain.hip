@@ -505,7 +505,9 @@ __global__ __launch_bounds__(512, 2) void k_conv32_chain(ChainArgs a)
                     pending = false;
                 }
                 if (FINAL) {
+#ifndef AUGCL_ABL_NO_WEIGHT_FETCH // (tuning builds: AUGCL_ABL=-DAUGCL_ABL_NO_WEIGHT_FETCH tools/build_tuning.sh -- timing only, wrong results)
                     load_weights(wf_next);
+#endif
                     load_consts(wf_next, b_next);
                 }
 #ifdef AUGCL_TUNING

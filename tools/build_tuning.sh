@@ -7,5 +7,5 @@ T=/tmp/augcl_tuning_build/augcl_amd/csrc
 mkdir -p $T /tmp/augcl_tuning_build/include
 cp $ROOT/include/augcl.h /tmp/augcl_tuning_build/include/
 cp $ROOT/augcl_amd/csrc/*.hip $ROOT/augcl_amd/csrc/*.cpp $ROOT/augcl_amd/csrc/*.h $ROOT/augcl_amd/csrc/Makefile $T/
-make -j8 -C $T EXTRA_FLAGS=-DAUGCL_TUNING OUT=$ROOT/tools/libaugcl_tuning.so 2>&1 | grep -E "error|Error" || true
+make -j8 -C $T EXTRA_FLAGS="-DAUGCL_TUNING $AUGCL_ABL" OUT=$ROOT/tools/libaugcl_tuning.so 2>&1 | grep -E "error|Error" || true
 ls -la $ROOT/tools/libaugcl_tuning.so
