@@ -260,7 +260,7 @@ def _kept(out, B, hs, wsz):
 
 
 @pytest.mark.parametrize("B,H,W,n_layers", [(3, 84, 84, 11), (37, 84, 84, 11), (300, 84, 84, 11), (2, 100, 100, 11), (5, 64, 72, 5),
-                                            (4, 84, 84, 2), (1, 84, 84, 11), (16, 50, 70, 4)])
+                                            (4, 84, 84, 2), (1, 84, 84, 11), (16, 50, 70, 4), (2, 100, 100, 14), (3, 84, 60, 7)])
 def test_f32_gradient_carrying_forward_through_chains(cuda, B, H, W, n_layers):
     """Precision "f32" with gradients (the critic's pass, src/algorithms/sac.py:103-116): the 32 -> 32 layers as chains that also
     store every layer's float32 output, gate words and maximum (augcl_enc_stack_forward_chained, ABI v6).  What the backward pass
